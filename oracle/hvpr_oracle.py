@@ -1,0 +1,440 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+CPU restatement (numpy + CPU torch, fp32) of the reference's forward hot path, stage by
+stage.  Nothing under ``hvpr_amd/`` may import this module: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg use it, and only as
+the checker / the reported CPU baseline.
+
+Pinning (see DESIGN.md "Oracle"):
+  * PINNED against the importable reference modules (fixtures under tests/golden/, made by
+    tests/golden/make_golden.py in the build container): pillar VFE, memory read-out,
+    scatter, BEV backbone, anchors + box decode, limit_period, ResidualCoder.
+  * PARITY UNPINNED (source absent from /root/reference, no reference test exists):
+    voxelizer (third-party spconv v1.x), rotated-BEV NMS / IoU (pcdet/ops/iou3d_nms).
+    Those live in the C files next to this one and follow SURVEY.md Appendix B.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    """The C half of the oracle (voxelize_ref.c, iou3d_nms_ref.c -> liboracle.so)."""
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            import subprocess
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        lib = ctypes.CDLL(path)
+        fp = ctypes.POINTER(ctypes.c_float)
+        ip = ctypes.POINTER(ctypes.c_int)
+        lib.hvpr_oracle_voxelize.restype = ctypes.c_int
+        lib.hvpr_oracle_voxelize.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, fp, ip, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, fp, ip, ip, ip]
+        lib.hvpr_oracle_box_overlap.restype = ctypes.c_float
+        lib.hvpr_oracle_box_overlap.argtypes = [fp, fp]
+        for name in ("hvpr_oracle_boxes_overlap_bev", "hvpr_oracle_boxes_iou_bev", "hvpr_oracle_boxes_iou3d"):
+            fn = getattr(lib, name)
+            fn.restype = None
+            fn.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, fp]
+        lib.hvpr_oracle_nms_sorted.restype = ctypes.c_int
+        lib.hvpr_oracle_nms_sorted.argtypes = [fp, ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_int64)]
+        _LIB = lib
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+
+
+# ----------------------------------------------------------------------------------------
+# a1  voxelizer — pcdet/datasets/processor/data_processor.py:43-75 -> spconv VoxelGenerator
+# ----------------------------------------------------------------------------------------
+def grid_size_of(point_cloud_range, voxel_size):
+    """data_processor.py:56-57 — round((hi-lo)/vs) with the range held in float32 (dataset.py:25)."""
+    r = np.asarray(point_cloud_range, dtype=np.float32)
+    g = (r[3:6] - r[0:3]) / np.asarray(voxel_size, dtype=np.float32)
+    return np.round(g).astype(np.int64)
+
+
+def voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels, mode="v2"):
+    """Sequential first-touch voxel hash (C).  Returns voxels (M,P,C) f32, coords (M,3) i32 zyx, num (M,) i32."""
+    pts = _f32(points)
+    n, c = pts.shape
+    rng = _f32(point_cloud_range)
+    vs = _f32(voxel_size)
+    grid = grid_size_of(point_cloud_range, voxel_size).astype(np.int32)
+    voxels = np.zeros((max_voxels, max_points, c), dtype=np.float32)
+    coords = np.zeros((max_voxels, 3), dtype=np.int32)
+    num = np.zeros((max_voxels,), dtype=np.int32)
+    cmap = np.full((int(grid[2]) * int(grid[1]) * int(grid[0]),), -1, dtype=np.int32)
+    lo = np.ascontiguousarray(rng[:3])
+    m = _lib().hvpr_oracle_voxelize(_fp(pts), n, c, _fp(lo), _fp(vs), _ip(grid), int(max_points), int(max_voxels),
+                                    1 if mode == "v1" else 0, _fp(voxels), _ip(coords), _ip(num), _ip(cmap))
+    assert (cmap == -1).all()
+    return voxels[:m].copy(), coords[:m].copy(), num[:m].copy()
+
+
+def voxelize_py(points, voxel_size, point_cloud_range, max_points, max_voxels, mode="v2"):
+    """Pure-python twin of the C loop (small inputs only) — cross-checks the C build."""
+    pts = _f32(points)
+    rng = _f32(point_cloud_range)
+    vs = _f32(voxel_size)
+    grid = grid_size_of(point_cloud_range, voxel_size)
+    table = {}
+    voxels, coords, num = [], [], []
+    for i in range(pts.shape[0]):
+        c = np.floor((pts[i, :3] - rng[:3]) / vs)          # fp32 sub, div, floor
+        if (c < 0).any() or (c >= grid.astype(np.float32)).any():
+            continue
+        key = (int(c[2]), int(c[1]), int(c[0]))
+        vid = table.get(key)
+        if vid is None:
+            if len(coords) >= max_voxels:
+                if mode == "v1":
+                    break
+                continue
+            vid = len(coords)
+            table[key] = vid
+            coords.append(key)
+            voxels.append(np.zeros((max_points, pts.shape[1]), np.float32))
+            num.append(0)
+        if num[vid] < max_points:
+            voxels[vid][num[vid]] = pts[i]
+            num[vid] += 1
+    if not coords:
+        return (np.zeros((0, max_points, pts.shape[1]), np.float32), np.zeros((0, 3), np.int32),
+                np.zeros((0,), np.int32))
+    return np.stack(voxels), np.asarray(coords, np.int32), np.asarray(num, np.int32)
+
+
+# ----------------------------------------------------------------------------------------
+# a2  pillar VFE — pcdet/models/backbones_3d/vfe/pillar_vfe.py:184-221, PFNLayer :29-49
+# ----------------------------------------------------------------------------------------
+def _bn_eval(x, bn, eps=1e-3):
+    """Eval-mode BatchNorm over the last (channel) dim with running stats."""
+    w, b, mean, var = bn
+    return (x - mean) / torch.sqrt(var + eps) * w + b
+
+
+def _bn_train(x2d, w, b, eps=1e-3):
+    """Train-mode BatchNorm: biased batch variance over dim 0."""
+    mean = x2d.mean(dim=0)
+    var = x2d.var(dim=0, unbiased=False)
+    return (x2d - mean) / torch.sqrt(var + eps) * w + b, mean, var
+
+
+def pillar_vfe_scale(voxels, num_points, coords, params, voxel_size, point_cloud_range, training=False):
+    """Restates PillarVFE_Scale.forward with USE_ABSLOTE_XYZ=True, WITH_DISTANCE=False.
+
+    voxels (M,P,4) f32, num_points (M,) f32, coords (M,4) f32 [b,z,y,x].
+    params: dict of torch tensors keyed like the reference state_dict
+        pfn_layers.{0,1}.linear.weight / .norm.{weight,bias,running_mean,running_var}
+        pfn_scale_layers.{0,1}.0.weight / .1.{weight,bias,running_mean,running_var}
+    Returns pillar_features (M,C1), pillar_scale_features (M,Cs), pillar_mask (M,P,1)
+    (+ list of batch (mean,var) per BN when training=True).
+    """
+    v = torch.as_tensor(voxels, dtype=torch.float32)
+    n = torch.as_tensor(num_points, dtype=torch.float32)
+    c = torch.as_tensor(coords, dtype=torch.float32)
+    M, P, _ = v.shape
+    vx, vy, vz = [float(s) for s in voxel_size]
+    x_off = vx / 2 + point_cloud_range[0]                    # pillar_vfe.py:166-171
+    y_off = vy / 2 + point_cloud_range[1]
+    z_off = vz / 2 + point_cloud_range[2]
+    mean = v[:, :, :3].sum(dim=1, keepdim=True) / n.view(-1, 1, 1)       # :187
+    f_cluster = v[:, :, :3] - mean                                       # :188
+    f_center = torch.zeros_like(v[:, :, :3])
+    f_center[:, :, 0] = v[:, :, 0] - (c[:, 3].unsqueeze(1) * vx + x_off)   # :190-193
+    f_center[:, :, 1] = v[:, :, 1] - (c[:, 2].unsqueeze(1) * vy + y_off)
+    f_center[:, :, 2] = v[:, :, 2] - (c[:, 1].unsqueeze(1) * vz + z_off)
+    feats = torch.cat([v, f_cluster, f_center], dim=-1)                  # :195-203  (M,P,10)
+    slot = torch.arange(P, dtype=torch.int32).view(1, -1)
+    mask = (n.int().view(-1, 1) > slot).unsqueeze(-1).float()            # :205-207
+    feats = feats * mask                                                 # :208
+    stats = []
+    x = feats
+    for li in (0, 1):
+        w = params[f"pfn_layers.{li}.linear.weight"]
+        bn = [params[f"pfn_layers.{li}.norm.{k}"] for k in ("weight", "bias", "running_mean", "running_var")]
+        y = x @ w.t()                                                    # Linear, no bias (:22)
+        if training:
+            flat, bm, bv = _bn_train(y.reshape(M * P, -1), bn[0], bn[1])   # stats over all M*P slots
+            y = flat.reshape(M, P, -1)
+            stats.append((bm, bv))
+        else:
+            y = _bn_eval(y, bn)
+        y = torch.relu(y)
+        y_max = y.max(dim=1, keepdim=True)[0]                            # :42
+        x = y_max if li == 1 else torch.cat([y, y_max.expand(-1, P, -1)], dim=2)   # :44-49
+    # NB the reference does .squeeze(), which collapses M==1 to (C,) (:211); the oracle keeps (M,C).
+    pillar = x.reshape(M, -1)
+    d_mean = torch.norm(mean, 2, 2, keepdim=True)                        # :213
+    s = torch.cat([n.unsqueeze(1), d_mean.squeeze(1), mean.squeeze(1)], dim=-1)   # :214  (M,5)
+    for li in (0, 1):
+        w = params[f"pfn_scale_layers.{li}.0.weight"]
+        bn = [params[f"pfn_scale_layers.{li}.1.{k}"] for k in ("weight", "bias", "running_mean", "running_var")]
+        s = s @ w.t()
+        if training:
+            s, bm, bv = _bn_train(s, bn[0], bn[1])
+            stats.append((bm, bv))
+        else:
+            s = _bn_eval(s, bn)
+        s = torch.relu(s)
+    if training:
+        return pillar, s, mask, stats
+    return pillar, s, mask
+
+
+# ----------------------------------------------------------------------------------------
+# a3  memory read-out (eval) — map_to_bev/memory_module.py:60-77 (line 75 is a stray fragment)
+# ----------------------------------------------------------------------------------------
+def memory_readout_eval(f, W, k):
+    """f (M,C), W (items,C) -> output (M,C), indices (M,k) (descending score), logits (M,items)."""
+    f = torch.as_tensor(f, dtype=torch.float32)
+    W = torch.as_tensor(W, dtype=torch.float32)
+    logits = f @ W.t()                                                   # :64
+    score = torch.softmax(logits, dim=1)                                 # :65
+    _, idx = torch.topk(score, k, dim=1)                                 # :66
+    mp = W[idx]                                                          # :67  (M,k,C)
+    agg = (mp * f.unsqueeze(1)).sum(dim=2)                               # :70-71
+    agg = torch.softmax(agg, dim=1)                                      # :72
+    out = (agg.unsqueeze(2) * mp).sum(dim=1)                             # :73-74
+    return out, idx, logits
+
+
+# ----------------------------------------------------------------------------------------
+# a4  scatter (eval) — map_to_bev/pointpillar_scatter.py:169-222
+# ----------------------------------------------------------------------------------------
+def scatter_eval(pillar_features, memory_out, pillar_scale_features, coords, batch_size, nx, ny):
+    """-> spatial_features (B,2C,ny,nx) [pillar | memory], spatial_scale_features (B,Cs,ny,nx)."""
+    pf = torch.as_tensor(pillar_features, dtype=torch.float32)
+    mo = torch.as_tensor(memory_out, dtype=torch.float32)
+    sf = torch.as_tensor(pillar_scale_features, dtype=torch.float32)
+    c = torch.as_tensor(coords, dtype=torch.float32)
+    C, Cs = pf.shape[1], sf.shape[1]
+    canv = torch.zeros(batch_size, 2 * C, ny * nx)
+    canv_s = torch.zeros(batch_size, Cs, ny * nx)
+    for b in range(batch_size):
+        m = c[:, 0] == b
+        idx = (c[m, 1] + c[m, 2] * nx + c[m, 3]).long()                  # :192
+        canv[b][:, idx] = torch.cat([pf[m], mo[m]], dim=1).t()           # :204,207
+        canv_s[b][:, idx] = sf[m].t()                                    # :208
+    return canv.view(batch_size, 2 * C, ny, nx), canv_s.view(batch_size, Cs, ny, nx)
+
+
+# ----------------------------------------------------------------------------------------
+# a5  BEV backbone (eval) — backbones_2d/base_bev_backbone.py:280-315, spatial_attention.py:47-63
+# ----------------------------------------------------------------------------------------
+def _conv_bn_relu(x, w, bn, stride=1, pad=1, eps=1e-3, bias=None, relu=True):
+    y = F.conv2d(x, w, bias=bias, stride=stride, padding=pad)
+    g, b, mean, var = bn
+    y = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    return torch.relu(y) if relu else y
+
+
+def _bn_of(params, prefix):
+    return [params[f"{prefix}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")]
+
+
+def spatial_gate(y, params):
+    """sigmoid(BN(conv3x3_{2->1,bias}(cat[max_c y, mean_c y])))  — spatial_attention.py:47-62."""
+    pooled = torch.cat([y.max(dim=1, keepdim=True)[0], y.mean(dim=1, keepdim=True)], dim=1)
+    a = _conv_bn_relu(pooled, params["attention.spatial.conv.weight"], _bn_of(params, "attention.spatial.norm"),
+                      bias=params["attention.spatial.conv.bias"], relu=False)
+    return torch.sigmoid(a)
+
+
+def bev_backbone_eval(spatial_features, spatial_scale_features, params, layer_nums, layer_strides, sfm_layer_nums,
+                      upsample_strides):
+    """params keyed like the reference state_dict of BaseBEVBackbone_Scale."""
+    x = torch.as_tensor(spatial_features, dtype=torch.float32)
+    y = torch.as_tensor(spatial_scale_features, dtype=torch.float32)
+    ups = []
+    for i in range(len(layer_nums)):
+        # blocks[i]: ZeroPad(1)+Conv3x3(stride)+BN+ReLU, then layer_nums[i] x (Conv3x3 pad1+BN+ReLU)  (:154-169)
+        x = _conv_bn_relu(x, params[f"blocks.{i}.1.weight"], _bn_of(params, f"blocks.{i}.2"), stride=layer_strides[i])
+        for k in range(layer_nums[i]):
+            x = _conv_bn_relu(x, params[f"blocks.{i}.{4 + 3 * k}.weight"], _bn_of(params, f"blocks.{i}.{5 + 3 * k}"))
+        y = _conv_bn_relu(y, params[f"scale_layers.{i}.1.weight"], _bn_of(params, f"scale_layers.{i}.2"),
+                          stride=layer_strides[i])                        # :200-209
+        x_att = x
+        for _ in range(sfm_layer_nums[i]):                                # :291-295, shared weights
+            t = _conv_bn_relu(x_att, params[f"sfmblocks_down.{i}.0.weight"], _bn_of(params, f"sfmblocks_down.{i}.1"))
+            x_att = spatial_gate(y, params) * t + x_att
+        s = upsample_strides[i]
+        u = F.conv_transpose2d(x_att, params[f"deblocks.{i}.0.weight"], stride=s)   # :177-188
+        g, b, mean, var = _bn_of(params, f"deblocks.{i}.1")
+        u = (u - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-3) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+        ups.append(torch.relu(u))
+    return torch.cat(ups, dim=1)                                          # :303-304
+
+
+# ----------------------------------------------------------------------------------------
+# a6/a7  head + anchors + decode — dense_heads/anchor_head_single.py:109-145,
+#        anchor_head_template.py:293-340, target_assigner/anchor_generator.py:17-60,
+#        utils/box_coder_utils.py:45-77, utils/common_utils.py:20-23
+# ----------------------------------------------------------------------------------------
+def limit_period(val, offset=0.5, period=math.pi):
+    val = torch.as_tensor(val, dtype=torch.float32)
+    return val - torch.floor(val / period + offset) * period
+
+
+def generate_anchors(point_cloud_range, feature_map_size_xy, anchor_sizes, anchor_rotations, anchor_bottom_heights,
+                     align_center=False):
+    """-> (nz, ny, nx, n_size, n_rot, 7) f32, as anchor_generator.py:56-58."""
+    # the reference holds the range as a float32 ndarray (dataset.py:25) and the feature-map size as
+    # int64 (anchor_head_template.py:43); numpy scalar promotion decides the bits of the strides.
+    r = np.asarray(point_cloud_range, dtype=np.float32)
+    gx, gy = np.int64(feature_map_size_xy[0]), np.int64(feature_map_size_xy[1])
+    if align_center:
+        xs, ys = (r[3] - r[0]) / gx, (r[4] - r[1]) / gy
+        xo, yo = xs / 2, ys / 2
+    else:
+        xs, ys = (r[3] - r[0]) / (gx - 1), (r[4] - r[1]) / (gy - 1)
+        xo, yo = 0, 0
+    x_shifts = torch.arange(r[0] + xo, r[3] + 1e-5, step=xs, dtype=torch.float32)
+    y_shifts = torch.arange(r[1] + yo, r[4] + 1e-5, step=ys, dtype=torch.float32)
+    z_shifts = torch.tensor(anchor_bottom_heights, dtype=torch.float32)
+    sizes = torch.tensor(anchor_sizes, dtype=torch.float32)              # (S,3)
+    rots = torch.tensor(anchor_rotations, dtype=torch.float32)           # (R,)
+    nxx, nyy, nzz, S, R = len(x_shifts), len(y_shifts), len(z_shifts), sizes.shape[0], rots.shape[0]
+    a = torch.zeros(nzz, nyy, nxx, S, R, 7)
+    a[..., 0] = x_shifts.view(1, 1, -1, 1, 1)
+    a[..., 1] = y_shifts.view(1, -1, 1, 1, 1)
+    a[..., 2] = z_shifts.view(-1, 1, 1, 1, 1)
+    a[..., 3:6] = sizes.view(1, 1, 1, S, 1, 3)
+    a[..., 6] = rots.view(1, 1, 1, 1, R)
+    a[..., 2] += a[..., 5] / 2                                           # :58
+    return a
+
+
+def residual_decode(enc, anchors):
+    """ResidualCoder.decode_torch — box_coder_utils.py:45-77."""
+    xa, ya, za, dxa, dya, dza, ra = torch.split(anchors, 1, dim=-1)
+    xt, yt, zt, dxt, dyt, dzt, rt = torch.split(enc, 1, dim=-1)
+    diag = torch.sqrt(dxa ** 2 + dya ** 2)
+    return torch.cat([xt * diag + xa, yt * diag + ya, zt * dza + za,
+                      torch.exp(dxt) * dxa, torch.exp(dyt) * dya, torch.exp(dzt) * dza, rt + ra], dim=-1)
+
+
+def residual_encode(boxes, anchors):
+    """ResidualCoder.encode_torch — box_coder_utils.py:13-43 (without the in-place clamp side effect)."""
+    anchors = anchors.clone()
+    boxes = boxes.clone()
+    anchors[:, 3:6] = torch.clamp_min(anchors[:, 3:6], 1e-5)
+    boxes[:, 3:6] = torch.clamp_min(boxes[:, 3:6], 1e-5)
+    xa, ya, za, dxa, dya, dza, ra = torch.split(anchors[:, :7], 1, dim=-1)
+    xg, yg, zg, dxg, dyg, dzg, rg = torch.split(boxes[:, :7], 1, dim=-1)
+    diag = torch.sqrt(dxa ** 2 + dya ** 2)
+    return torch.cat([(xg - xa) / diag, (yg - ya) / diag, (zg - za) / dza,
+                      torch.log(dxg / dxa), torch.log(dyg / dya), torch.log(dzg / dza), rg - ra], dim=-1)
+
+
+def head_forward(spatial_features_2d, params):
+    """Three 1x1 convs + NHWC permute — anchor_head_single.py:109-127."""
+    x = torch.as_tensor(spatial_features_2d, dtype=torch.float32)
+    out = []
+    for name in ("conv_cls", "conv_box", "conv_dir_cls"):
+        y = F.conv2d(x, params[f"{name}.weight"], params[f"{name}.bias"])
+        out.append(y.permute(0, 2, 3, 1).contiguous())
+    return out
+
+
+def generate_predicted_boxes(cls_preds, box_preds, dir_cls_preds, anchors, dir_offset, dir_limit_offset, num_dir_bins):
+    """anchor_head_template.py:293-340 (single head, ResidualCoder)."""
+    B = cls_preds.shape[0]
+    anc = anchors.reshape(-1, 7)
+    A = anc.shape[0]
+    batch_cls = cls_preds.reshape(B, A, -1).float()
+    enc = box_preds.reshape(B, A, -1)
+    boxes = residual_decode(enc, anc.unsqueeze(0).expand(B, -1, -1))
+    dirp = dir_cls_preds.reshape(B, A, -1)
+    labels = torch.max(dirp, dim=-1)[1]
+    period = 2 * np.pi / num_dir_bins
+    rot = limit_period(boxes[..., 6] - dir_offset, dir_limit_offset, period)
+    boxes = boxes.clone()
+    boxes[..., 6] = rot + dir_offset + period * labels.to(boxes.dtype)
+    return batch_cls, boxes
+
+
+# ----------------------------------------------------------------------------------------
+# a8  post-processing — detectors/detector3d_template.py:168-274, model_utils/model_nms_utils.py:6-25
+# ----------------------------------------------------------------------------------------
+def stable_order_desc(scores):
+    """The build's defined tie rule: descending score, ascending index on ties."""
+    s = np.asarray(scores, dtype=np.float32)
+    return np.lexsort((np.arange(s.shape[0]), -s.astype(np.float64))).astype(np.int64)
+
+
+def nms_bev(boxes, scores, thresh):
+    """nms_gpu restatement: sort desc (stable), bit-mask, sweep.  Returns indices into `boxes`."""
+    b = _f32(boxes)[:, :7]
+    order = stable_order_desc(scores)
+    sb = np.ascontiguousarray(b[order])
+    keep = np.zeros((sb.shape[0],), dtype=np.int64)
+    nk = _lib().hvpr_oracle_nms_sorted(_fp(sb), sb.shape[0], float(thresh),
+                                       keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+    return order[keep[:nk]]
+
+
+def boxes_iou_bev(a, b):
+    a, b = _f32(a)[:, :7].copy(), _f32(b)[:, :7].copy()
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    _lib().hvpr_oracle_boxes_iou_bev(_fp(a), a.shape[0], _fp(b), b.shape[0], _fp(out))
+    return out
+
+
+def boxes_overlap_bev(a, b):
+    a, b = _f32(a)[:, :7].copy(), _f32(b)[:, :7].copy()
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    _lib().hvpr_oracle_boxes_overlap_bev(_fp(a), a.shape[0], _fp(b), b.shape[0], _fp(out))
+    return out
+
+
+def boxes_iou3d(a, b):
+    a, b = _f32(a)[:, :7].copy(), _f32(b)[:, :7].copy()
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    _lib().hvpr_oracle_boxes_iou3d(_fp(a), a.shape[0], _fp(b), b.shape[0], _fp(out))
+    return out
+
+
+def class_agnostic_nms(box_scores, box_preds, score_thresh, nms_thresh, pre_maxsize, post_maxsize):
+    """model_nms_utils.py:6-25 with the stable-descending tie rule.  Returns selected anchor ids + scores."""
+    s = np.asarray(box_scores, dtype=np.float32)
+    bx = _f32(box_preds)
+    passing = np.nonzero(s >= np.float32(score_thresh))[0]
+    if passing.size == 0:
+        return np.zeros((0,), np.int64), np.zeros((0,), np.float32)
+    ps = s[passing]
+    top = stable_order_desc(ps)[: min(pre_maxsize, ps.shape[0])]          # torch.topk (:15)
+    keep = nms_bev(bx[passing][top], ps[top], nms_thresh)[:post_maxsize]   # :17-20
+    sel = passing[top[keep]]
+    return sel.astype(np.int64), s[sel]
+
+
+def post_process_frame(cls_logits, boxes, score_thresh, nms_thresh, pre_maxsize, post_maxsize):
+    """One frame of post_processing (class-agnostic branch, :241-259)."""
+    cls = torch.sigmoid(torch.as_tensor(cls_logits, dtype=torch.float32))
+    score, label = torch.max(cls, dim=-1)
+    sel, sc = class_agnostic_nms(score.numpy(), np.asarray(boxes), score_thresh, nms_thresh, pre_maxsize, post_maxsize)
+    return {"pred_boxes": np.asarray(boxes)[sel], "pred_scores": sc, "pred_labels": (label.numpy()[sel] + 1),
+            "selected": sel}

@@ -1,0 +1,114 @@
+"""CPU: pin the oracle (oracle/hvpr_oracle.py) against the fixtures generated from the imported
+reference modules (tests/golden/make_golden.py).  Tolerances are fp32 round-off class."""
+import os
+
+import numpy as np
+import torch
+
+from detparams import det_state, det_tensor
+from oracle import hvpr_oracle as O
+
+VOXEL_SIZE = [0.16, 0.16, 3.0]
+PC_RANGE = [0, -19.84, -2.5, 47.36, 19.84, 0.5]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _params(z, prefix="param."):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def _det_params(z):
+    shapes = {str(n): tuple(eval(str(s))) for n, s in zip(z["param_names"], z["param_shapes"])}
+    return {k: torch.from_numpy(v) for k, v in det_state(shapes, int(z["param_seed"])).items()}
+
+
+def test_g1_vfe_eval(golden_dir):
+    z = _load(golden_dir, "g1_vfe.npz")
+    pf, sf, mask = O.pillar_vfe_scale(z["voxels"], z["voxel_num_points"], z["voxel_coords"], _params(z), VOXEL_SIZE, PC_RANGE)
+    np.testing.assert_allclose(pf.numpy(), z["eval_pillar_features"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(sf.numpy(), z["eval_pillar_scale_features"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(mask.numpy(), z["eval_pillar_mask"])
+
+
+def test_g1_vfe_train(golden_dir):
+    z = _load(golden_dir, "g1_vfe.npz")
+    pf, sf, _, stats = O.pillar_vfe_scale(z["voxels"], z["voxel_num_points"], z["voxel_coords"], _params(z), VOXEL_SIZE,
+                                          PC_RANGE, training=True)
+    np.testing.assert_allclose(pf.numpy(), z["train_pillar_features"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(sf.numpy(), z["train_pillar_scale_features"], rtol=1e-4, atol=1e-4)
+    # running-stat update: momentum 0.01, unbiased variance for the running estimate
+    names = ["pfn_layers.0.norm", "pfn_layers.1.norm", "pfn_scale_layers.0.1", "pfn_scale_layers.1.1"]
+    counts = [z["voxels"].shape[0] * 32] * 2 + [z["voxels"].shape[0]] * 2
+    for (bm, bv), name, cnt in zip(stats, names, counts):
+        rm = 0.99 * z[f"param.{name}.running_mean"] + 0.01 * bm.numpy()
+        rv = 0.99 * z[f"param.{name}.running_var"] + 0.01 * bv.numpy() * cnt / (cnt - 1)
+        np.testing.assert_allclose(rm, z[f"after_train.{name}.running_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rv, z[f"after_train.{name}.running_var"], rtol=1e-5, atol=1e-6)
+
+
+def test_g2_memory_eval(golden_dir):
+    z = _load(golden_dir, "g2_memory_eval.npz")
+    W = det_tensor(str(z["W_name"]), (2000, 64), int(z["W_seed"]))
+    out, idx, _ = O.memory_readout_eval(z["f"], W, int(z["k"]))
+    np.testing.assert_allclose(out.numpy(), z["output"], rtol=1e-5, atol=1e-6)
+    assert (np.sort(idx.numpy(), 1) == np.sort(z["topk_idx"], 1)).all()
+
+
+def test_g3_scatter_eval(golden_dir):
+    z = _load(golden_dir, "g3_scatter_eval.npz")
+    W = det_tensor(str(z["W_name"]), (2000, 64), int(z["W_seed"]))
+    mem, _, _ = O.memory_readout_eval(z["pillar_features"], W, 20)
+    sp, sc = O.scatter_eval(z["pillar_features"], mem, z["pillar_scale_features"], z["voxel_coords"], int(z["batch_size"]),
+                            int(z["nx"]), int(z["ny"]))
+    np.testing.assert_allclose(sp.numpy(), z["spatial_features"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(sc.numpy(), z["spatial_scale_features"])
+
+
+def test_g4_backbone(golden_dir):
+    for tag in ("small", "full"):
+        z = _load(golden_dir, f"g4_backbone_{tag}.npz")
+        out = O.bev_backbone_eval(z["spatial_features"], z["spatial_scale_features"], _det_params(z), list(z["layer_nums"]),
+                                  list(z["layer_strides"]), list(z["sfm_layer_nums"]), list(z["upsample_strides"]))
+        ref = z["spatial_features_2d"]
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out.numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_g5_head_and_decode(golden_dir):
+    for stride in (1, 2):
+        z = _load(golden_dir, f"g5_head_stride{stride}.npz")
+        nx, ny = int(z["nx"]), int(z["ny"])
+        anc = O.generate_anchors(list(z["point_cloud_range"]), (nx // stride, ny // stride), [[3.9, 1.6, 1.56]], [0, 1.57], [-1.78])
+        np.testing.assert_allclose(anc.numpy(), z["anchors"], rtol=0, atol=1e-6)
+        cls, box, dirp = O.head_forward(z["spatial_features_2d"], _params(z))
+        np.testing.assert_allclose(cls.numpy(), z["cls_preds"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(box.numpy(), z["box_preds"], rtol=1e-5, atol=1e-5)
+        bc, bb = O.generate_predicted_boxes(torch.from_numpy(z["cls_preds"]), torch.from_numpy(z["box_preds"]),
+                                            torch.from_numpy(z["dir_cls_preds"]), torch.from_numpy(z["anchors"]), 0.78539, 0.0, 2)
+        np.testing.assert_allclose(bc.numpy(), z["batch_cls_preds"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(bb.numpy(), z["batch_box_preds"], rtol=1e-5, atol=1e-5)
+
+
+def test_g5_anchors_full(golden_dir):
+    z = _load(golden_dir, "g5_anchors_full.npz")
+    anc = O.generate_anchors(PC_RANGE, (296, 248), [[3.9, 1.6, 1.56]], [0, 1.57], [-1.78])
+    assert tuple(anc.shape) == tuple(z["shape"])
+    a = anc.reshape(-1, 7).numpy()
+    np.testing.assert_array_equal(a[z["sample_idx"]], z["sample"])
+    np.testing.assert_array_equal(anc[0, 0, :, 0, 0, 0].numpy(), z["x_row"])
+    np.testing.assert_array_equal(anc[0, :, 0, 0, 0, 1].numpy(), z["y_col"])
+    np.testing.assert_allclose(a.astype(np.float64).sum(0), z["sum64"], rtol=1e-12)
+
+
+def test_g6_g7_coder_and_limit_period(golden_dir):
+    z = _load(golden_dir, "g6_g7_coder.npz")
+    enc = O.residual_encode(torch.from_numpy(z["boxes"]), torch.from_numpy(z["anchors"]))
+    np.testing.assert_allclose(enc.numpy(), z["enc"], rtol=1e-6, atol=1e-6)
+    dec = O.residual_decode(torch.from_numpy(z["enc"]), torch.from_numpy(z["anchors"]))
+    np.testing.assert_allclose(dec.numpy(), z["dec"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(O.limit_period(z["lp_val"], 0.0, np.pi).numpy(), z["lp_0_pi"])
+    np.testing.assert_array_equal(O.limit_period(z["lp_val"], 0.5, 2 * np.pi).numpy(), z["lp_05_2pi"])
+    np.testing.assert_array_equal(O.limit_period(z["lp_val"], 0.0, 2 * np.pi).numpy(), z["lp_0_2pi"])
