@@ -1,0 +1,61 @@
+"""ctypes binding of libhvpr_amd.so (the C-ABI declared in include/hvpr_amd.h).
+
+The product path has NO CPU fallback: if the library is missing or fails to load, every op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhvpr_amd.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_F = _c.c_float
+_Z = _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/hvpr_amd.h one to one (checked by tests/test_capi_symbols.py)
+SIGNATURES = {
+    "hvpr_abi_version": (_I, []),
+    "hvpr_status_string": (_c.c_char_p, [_I]),
+    "hvpr_voxelize_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "hvpr_voxelize_workspace_reset": (_I, [_P, _Z, _I, _I, _I, _I, _I, _P]),
+    "hvpr_voxelize_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I,
+                               _P, _P, _P, _P, _I, _P, _Z, _P]),
+    "hvpr_pillar_vfe_fwd_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, _P, _P]),
+    "hvpr_memory_readout_fwd_f32": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P]),
+    "hvpr_scatter_workspace_bytes": (_Z, [_I, _I, _I]),
+    "hvpr_scatter_bev_fwd_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+class HvprLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HvprLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -m hvpr_amd.build` (hipcc --offload-arch=gfx950). "
+                "hvpr_amd has no CPU fallback.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise HvprLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().hvpr_status_string(int(status))
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else status}")

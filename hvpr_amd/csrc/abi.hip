@@ -1,0 +1,15 @@
+// ABI bookkeeping for libhvpr_amd.so (include/hvpr_amd.h).
+#include "common.h"
+
+extern "C" int hvpr_abi_version(void) { return 1; }
+
+extern "C" const char *hvpr_status_string(int status) {
+    switch (status) {
+        case HVPR_OK: return "ok";
+        case HVPR_ERR_INVALID_ARG: return "invalid argument";
+        case HVPR_ERR_UNSUPPORTED: return "unsupported shape for this build of the kernels";
+        case HVPR_ERR_WORKSPACE: return "workspace too small";
+        case HVPR_ERR_LAUNCH: return "HIP launch failed";
+        default: return "unknown status";
+    }
+}

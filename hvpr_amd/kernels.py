@@ -1,0 +1,128 @@
+"""Tensor-level wrappers over the C-ABI (include/hvpr_amd.h): torch is used for device memory and streams only.
+
+Every wrapper validates its tensors (device, dtype, contiguity), passes raw pointers plus the current HIP
+stream, and raises on a non-zero status.  There is no CPU path: CPU tensors are rejected.
+"""
+import torch
+
+from ._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"hvpr_amd: {name} must live on the GPU (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"hvpr_amd: {name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"hvpr_amd: {name} must be contiguous")
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------ voxelizer
+class VoxelizeWorkspace:
+    """Persistent device workspace of the voxelizer (two cell maps + per-point scratch)."""
+
+    def __init__(self, batch, n_points, grid, device):
+        self.key = (int(batch), int(n_points), tuple(int(g) for g in grid), torch.device(device))
+        nx, ny, nz = self.key[2]
+        nbytes = lib().hvpr_voxelize_workspace_bytes(batch, n_points, nx, ny, nz)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.reset()
+
+    def reset(self):
+        batch, n_points, (nx, ny, nz), _ = self.key
+        check(lib().hvpr_voxelize_workspace_reset(self.buf.data_ptr(), self.buf.numel(), batch, n_points, nx, ny, nz,
+                                                  _stream()), "hvpr_voxelize_workspace_reset")
+
+
+def voxelize(points, frame_offsets, batch, point_cloud_range, voxel_size, grid, max_points, max_voxels, workspace,
+             xyz_col=0, n_feat=None, cap_mode=0, capacity=None):
+    """points (N, stride) f32 cuda; frame_offsets (batch+1,) i32 cuda.
+
+    Returns voxels (cap, P, n_feat) f32, coords (cap, 4) i32 [b,z,y,x], num_points (cap,) i32,
+    voxel_offsets (batch+1,) i32 — rows past voxel_offsets[batch] are unspecified.
+    """
+    n, stride = points.shape
+    n_feat = stride - xyz_col if n_feat is None else n_feat
+    if capacity is None:
+        capacity = min(n, batch * max_voxels)
+    dev = points.device
+    voxels = torch.empty((capacity, max_points, n_feat), dtype=torch.float32, device=dev)
+    coords = torch.empty((capacity, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((capacity,), dtype=torch.int32, device=dev)
+    offs = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
+    nx, ny, nz = [int(g) for g in grid]
+    lo = [float(torch.tensor(v, dtype=torch.float32)) for v in point_cloud_range[:3]]
+    vs = [float(torch.tensor(v, dtype=torch.float32)) for v in voxel_size]
+    if (batch, n) != workspace.key[:2] and (workspace.key[0] < batch or workspace.key[1] < n):
+        raise ValueError("voxelize workspace too small for this call")
+    check(lib().hvpr_voxelize_f32(_ptr(points, torch.float32, "points"), n, stride, xyz_col, n_feat,
+                                  _ptr(frame_offsets, torch.int32, "frame_offsets"), batch, lo[0], lo[1], lo[2],
+                                  vs[0], vs[1], vs[2], nx, ny, nz, int(max_points), int(max_voxels), int(cap_mode),
+                                  voxels.data_ptr(), coords.data_ptr(), num.data_ptr(), offs.data_ptr(), capacity,
+                                  workspace.buf.data_ptr(), workspace.buf.numel(), _stream()), "hvpr_voxelize_f32")
+    return voxels, coords, num, offs
+
+
+# ------------------------------------------------------------------------------------------------ VFE
+def pillar_vfe_fwd(voxels, num_points, coords, folded, voxel_size, offsets, m_device=None, want_mask=True):
+    """folded: dict w0,b0,w1,b1,ws0,bs0,ws1,bs1 (f32 cuda, BN folded). Returns (pillar, scale, mask|None)."""
+    M, P, C = voxels.shape
+    if C != 4:
+        raise ValueError("hvpr_pillar_vfe_fwd_f32 is built for 4 raw point features")
+    dev = voxels.device
+    pf = torch.empty((M, 64), dtype=torch.float32, device=dev)
+    sf = torch.empty((M, 32), dtype=torch.float32, device=dev)
+    mask = torch.empty((M, P, 1), dtype=torch.float32, device=dev) if want_mask else None
+    check(lib().hvpr_pillar_vfe_fwd_f32(
+        _ptr(voxels, torch.float32, "voxels"), _ptr(num_points, torch.int32, "voxel_num_points"),
+        _ptr(coords, torch.int32, "voxel_coords"), M, P, _ptr(m_device, torch.int32, "m_device"),
+        float(voxel_size[0]), float(voxel_size[1]), float(voxel_size[2]), float(offsets[0]), float(offsets[1]),
+        float(offsets[2]), _ptr(folded["w0"], torch.float32), _ptr(folded["b0"], torch.float32),
+        _ptr(folded["w1"], torch.float32), _ptr(folded["b1"], torch.float32), _ptr(folded["ws0"], torch.float32),
+        _ptr(folded["bs0"], torch.float32), _ptr(folded["ws1"], torch.float32), _ptr(folded["bs1"], torch.float32),
+        pf.data_ptr(), sf.data_ptr(), _ptr(mask), _stream()), "hvpr_pillar_vfe_fwd_f32")
+    return pf, sf, mask
+
+
+# ------------------------------------------------------------------------------------------------ memory + scatter
+def memory_readout_fwd(f, bank, k, m_device=None, want_idx=False):
+    M, C = f.shape
+    out = torch.empty((M, C), dtype=torch.float32, device=f.device)
+    idx = torch.empty((M, k), dtype=torch.int32, device=f.device) if want_idx else None
+    check(lib().hvpr_memory_readout_fwd_f32(_ptr(f, torch.float32, "pillar_features"), M,
+                                            _ptr(m_device, torch.int32, "m_device"),
+                                            _ptr(bank, torch.float32, "memory.weight"), bank.shape[0], int(k),
+                                            out.data_ptr(), _ptr(idx), _stream()), "hvpr_memory_readout_fwd_f32")
+    return (out, idx) if want_idx else out
+
+
+def scatter_workspace(batch, nx, ny, device):
+    """Idle cell map (-1 everywhere); every call returns it to idle."""
+    n = lib().hvpr_scatter_workspace_bytes(batch, nx, ny) // 4
+    return torch.full((n,), -1, dtype=torch.int32, device=device)
+
+
+def scatter_bev_fwd(pillar, memory, scale, coords, batch, nx, ny, workspace, m_device=None):
+    """Returns spatial (B, Cp+Cm, ny, nx) and spatial_scale (B, Cs, ny, nx) in channels_last memory format."""
+    M, cp = pillar.shape
+    cm = 0 if memory is None else memory.shape[1]
+    cs = 0 if scale is None else scale.shape[1]
+    dev = pillar.device
+    spatial = torch.empty((batch, ny, nx, cp + cm), dtype=torch.float32, device=dev)
+    spatial_scale = torch.empty((batch, ny, nx, cs), dtype=torch.float32, device=dev) if cs else None
+    check(lib().hvpr_scatter_bev_fwd_f32(_ptr(pillar, torch.float32, "pillar_features"), cp, _ptr(memory, torch.float32),
+                                         cm, _ptr(scale, torch.float32), cs, _ptr(coords, torch.int32, "voxel_coords"),
+                                         M, _ptr(m_device, torch.int32), batch, nx, ny, spatial.data_ptr(),
+                                         _ptr(spatial_scale), workspace.data_ptr(), workspace.numel() * 4, _stream()),
+          "hvpr_scatter_bev_fwd_f32")
+    spatial = spatial.permute(0, 3, 1, 2)
+    if spatial_scale is not None:
+        spatial_scale = spatial_scale.permute(0, 3, 1, 2)
+    return spatial, spatial_scale

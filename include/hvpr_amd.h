@@ -1,0 +1,115 @@
+/*
+ * hvpr_amd — C-ABI of the MI355X (gfx950) hot path of HVPR's voxel-point encoding + BEV detection.
+ *
+ * Every entry point
+ *   - takes plain device pointers + sizes and a stream (hipStream_t passed as void*); no torch types;
+ *   - enqueues on that stream and returns without synchronising;
+ *   - never allocates, frees or retains memory: inputs, outputs and workspaces are the caller's
+ *     (sizes from the matching *_workspace_bytes function);
+ *   - returns 0 on success, a negative hvpr_status otherwise (see hvpr_status_string); nothing throws.
+ *   - data-dependent sizes (voxel counts, NMS keep counts) are written to device int32 words.
+ *
+ * Each function cites the reference interface it replaces (paths relative to the reference repo
+ * cvlab-yonsei/HVPR).  The reference's own native boundary for these was three pybind11 torch
+ * extensions built by setup.py:52-110 (iou3d_nms_cuda, pointnet2_batch_cuda, pointnet2_stack_cuda)
+ * plus the external spconv voxel generator; their sources are not part of the reference snapshot.
+ */
+#ifndef HVPR_AMD_H
+#define HVPR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *hvpr_stream_t; /* hipStream_t */
+
+enum hvpr_status {
+    HVPR_OK = 0,
+    HVPR_ERR_INVALID_ARG = -1,   /* null pointer, negative size, inconsistent dims            */
+    HVPR_ERR_UNSUPPORTED = -2,   /* a shape the kernels are not built for (documented per op) */
+    HVPR_ERR_WORKSPACE = -3,     /* workspace too small                                        */
+    HVPR_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after the launch           */
+};
+
+int hvpr_abi_version(void);
+const char *hvpr_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1  Voxelizer.  Replaces spconv.utils.VoxelGenerator[V2].generate as called from
+ *     pcdet/datasets/processor/data_processor.py:43-75 (CPU dataloader in the reference).
+ *     Bit-exact first-touch semantics: voxel id = order of first appearance in the point array,
+ *     first `max_points` points of a voxel kept in point order, coords = floor((p-lo)/vs) in fp32.
+ *
+ *     points        [n_points, point_stride] f32; xyz at columns xyz_col..xyz_col+2; the n_feat
+ *                   columns starting at xyz_col are copied into the voxels (n_feat >= 3).
+ *     frame_offsets [batch+1] i32 device; frame b owns points [frame_offsets[b], frame_offsets[b+1]).
+ *     cap_mode      0 = VoxelGeneratorV2 (`continue` once max_voxels is reached),
+ *                   1 = VoxelGenerator v1 / tools/vis.py:47-48 (`break`).
+ *     voxels        [capacity, max_points, n_feat] f32 out, zero padded.
+ *     coords        [capacity, 4] i32 out  [b, z, y, x]   (dataset.py:161-166 prepends b)
+ *     num_points    [capacity] i32 out
+ *     voxel_offsets [batch+1] i32 out; frame b produced rows [voxel_offsets[b], voxel_offsets[b+1]).
+ *     capacity      rows available in the three outputs; >= sum_b min(N_b, max_voxels) is always enough.
+ *     max_points <= 63.
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_voxelize_workspace_bytes(int batch, int n_points, int nx, int ny, int nz);
+/* one-time (and after any failed call): puts the workspace in its idle state */
+int hvpr_voxelize_workspace_reset(void *workspace, size_t workspace_bytes, int batch, int n_points, int nx, int ny,
+                                  int nz, hvpr_stream_t stream);
+int hvpr_voxelize_f32(const float *points, int n_points, int point_stride, int xyz_col, int n_feat,
+                      const int32_t *frame_offsets, int batch, float lo_x, float lo_y, float lo_z, float vs_x,
+                      float vs_y, float vs_z, int nx, int ny, int nz, int max_points, int max_voxels, int cap_mode,
+                      float *voxels, int32_t *coords, int32_t *num_points, int32_t *voxel_offsets, int capacity,
+                      void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a2  Pillar VFE, eval mode (BatchNorm folded by the caller).  Replaces
+ *     PillarVFE_Scale.forward, pcdet/models/backbones_3d/vfe/pillar_vfe.py:184-221 (+ PFNLayer :29-49)
+ *     for USE_ABSLOTE_XYZ=True, WITH_DISTANCE=False, NUM_FILTERS=[32,64], NUM_SCALE_FEATURES=[16,32],
+ *     4 raw point features.
+ *
+ *     voxels [M, P, 4] f32 zero padded (P <= 32), num_points [M] i32, coords [M,4] i32 [b,z,y,x].
+ *     w0 [16,10] b0 [16]: folded Linear(10->16)+BN;  w1 [64,32] b1 [64]: folded Linear(32->64)+BN;
+ *     ws0 [16,5] bs0 [16], ws1 [32,16] bs1 [32]: the folded scale-stream layers.
+ *     pillar_features [M,64], pillar_scale_features [M,32], pillar_mask [M,P] (may be NULL) f32 out.
+ *     m_device: optional device i32 holding the live row count (<= M); NULL means M rows.
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_pillar_vfe_fwd_f32(const float *voxels, const int32_t *num_points, const int32_t *coords, int M, int P,
+                            const int32_t *m_device, float vs_x, float vs_y, float vs_z, float off_x, float off_y,
+                            float off_z, const float *w0, const float *b0, const float *w1, const float *b1,
+                            const float *ws0, const float *bs0, const float *ws1, const float *bs1,
+                            float *pillar_features, float *pillar_scale_features, float *pillar_mask,
+                            hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3  Memory read-out, eval branch.  Replaces MemoryUnit_Agg.forward (eval),
+ *     pcdet/models/backbones_2d/map_to_bev/memory_module.py:60-77: logits = f.W^T, top-k items,
+ *     softmax over the k selected logits, weighted sum of the k items.
+ *     f [M,64], bank [n_items,64] -> out [M,64]; topk_idx [M,k] i32 (may be NULL; descending logit).
+ *     k <= 32, channels == 64.
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t *m_device, const float *bank, int n_items,
+                                int k, float *out, int32_t *topk_idx, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a4  Scatter to the dense BEV canvases.  Replaces the eval branch of
+ *     PointPillarScatter_Agg_Memory_1_scale.forward, map_to_bev/pointpillar_scatter.py:169-222
+ *     (and plain PointPillarScatter :5-37 when memory/scale inputs are NULL).
+ *     The canvases are written channels-last: spatial [B, ny, nx, c_pillar + c_mem],
+ *     spatial_scale [B, ny, nx, c_scale] — logically (B, C, ny, nx) tensors in torch's
+ *     channels_last memory format.  Every element is written exactly once (zeros included).
+ *     coords [M,4] i32 [b,z,y,x]; cell_map: workspace of B*ny*nx i32.
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_scatter_workspace_bytes(int batch, int nx, int ny);
+int hvpr_scatter_bev_fwd_f32(const float *pillar_features, int c_pillar, const float *memory_features, int c_mem,
+                             const float *scale_features, int c_scale, const int32_t *coords, int M,
+                             const int32_t *m_device, int batch, int nx, int ny, float *spatial,
+                             float *spatial_scale, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVPR_AMD_H */
