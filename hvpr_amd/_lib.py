@@ -27,6 +27,7 @@ SIGNATURES = {
     "hvpr_memory_readout_fwd_f32": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P]),
     "hvpr_scatter_workspace_bytes": (_Z, [_I, _I, _I]),
     "hvpr_scatter_bev_fwd_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "hvpr_conv2d_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

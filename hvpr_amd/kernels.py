@@ -126,3 +126,76 @@ def scatter_bev_fwd(pillar, memory, scale, coords, batch, nx, ny, workspace, m_d
     if spatial_scale is not None:
         spatial_scale = spatial_scale.permute(0, 3, 1, 2)
     return spatial, spatial_scale
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+class PackedConv:
+    """Weights of one conv layer in the kernel's layout [taps, Cin/8, cout_pad, 8] with BatchNorm folded."""
+
+    __slots__ = ("w", "bias", "taps", "stride", "cout", "cout_pad", "up", "cin", "relu", "tile_cfg")
+
+    def __init__(self, w, bias, taps, stride, cout, cout_pad, up, cin, relu, tile_cfg):
+        self.w, self.bias, self.taps, self.stride = w, bias, taps, stride
+        self.cout, self.cout_pad, self.up, self.cin, self.relu, self.tile_cfg = cout, cout_pad, up, cin, relu, tile_cfg
+
+
+def _tile_channels(tile_cfg):
+    return 128 if tile_cfg == 0 else 64
+
+
+def pack_conv(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=0):
+    """weight (Cout, Cin, k, k) with k in {1,3}; scale/shift: folded BatchNorm (per Cout) or None / conv bias."""
+    cout, cin, kh, kw = weight.shape
+    assert kh == kw and kh in (1, 3) and cin % 8 == 0
+    w = weight.detach().float()
+    if scale is not None:
+        w = w * scale.view(-1, 1, 1, 1)
+    tc = _tile_channels(tile_cfg)
+    cout_pad = (cout + tc - 1) // tc * tc
+    taps = kh * kw
+    # (Cout, Cin, kh, kw) -> (taps, Cin/8, Cout, 8)
+    p = w.permute(2, 3, 1, 0).reshape(taps, cin // 8, 8, cout).permute(0, 1, 3, 2)
+    wp = torch.zeros((taps, cin // 8, cout_pad, 8), dtype=torch.float32, device=w.device)
+    wp[:, :, :cout] = p
+    b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
+    if shift is not None:
+        b[:cout] = shift.detach().float()
+    return PackedConv(wp.contiguous(), b, taps, stride, cout, cout_pad, 1, cin, relu, tile_cfg)
+
+
+def pack_deconv(weight, scale, shift, relu=True, tile_cfg=0):
+    """ConvTranspose2d weight (Cin, Cout, s, s) with kernel == stride == s -> 1x1 GEMM with s*s*Cout columns."""
+    cin, cout, s, s2 = weight.shape
+    assert s == s2 and cin % 8 == 0
+    w = weight.detach().float() * scale.view(1, -1, 1, 1)
+    cols = s * s * cout
+    tc = _tile_channels(tile_cfg)
+    cout_pad = (cols + tc - 1) // tc * tc
+    # column = (ky*s + kx)*Cout + co
+    g = w.permute(0, 2, 3, 1).reshape(cin, cols)                       # (Cin, cols)
+    p = g.reshape(cin // 8, 8, cols).permute(0, 2, 1).unsqueeze(0)     # (1, Cin/8, cols, 8)
+    wp = torch.zeros((1, cin // 8, cout_pad, 8), dtype=torch.float32, device=w.device)
+    wp[:, :, :cols] = p
+    b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
+    b[:cols] = shift.detach().float().repeat(s * s)
+    return PackedConv(wp.contiguous(), b, 1, 1, cout, cout_pad, s, cin, relu, tile_cfg)
+
+
+def conv2d_nhwc(x, pc, out=None, out_coff=0, gate=None, resid=None):
+    """x (N,H,W,Cin) contiguous f32 -> (N,OH*up,OW*up,C) ; optional fused y = gate*y + resid (SFM step)."""
+    N, H, W, cin = x.shape
+    assert cin == pc.cin
+    if pc.taps == 9:
+        OH, OW = (H + 2 - 3) // pc.stride + 1, (W + 2 - 3) // pc.stride + 1
+    else:
+        OH, OW = H, W
+    if out is None:
+        out = torch.empty((N, OH * pc.up, OW * pc.up, pc.cout), dtype=torch.float32, device=x.device)
+    assert out.shape[:3] == (N, OH * pc.up, OW * pc.up) and out.is_contiguous()
+    check(lib().hvpr_conv2d_nhwc_f32(_ptr(x, torch.float32, "conv input"), N, H, W, cin, pc.w.data_ptr(),
+                                     pc.bias.data_ptr(), pc.taps, pc.stride, pc.cout, pc.cout_pad, pc.up,
+                                     1 if pc.relu else 0, _ptr(gate, torch.float32, "gate"),
+                                     _ptr(resid, torch.float32, "resid"), 0 if resid is None else resid.shape[-1],
+                                     out.data_ptr(), out.shape[-1], int(out_coff), pc.tile_cfg, _stream()),
+          "hvpr_conv2d_nhwc_f32")
+    return out

@@ -109,6 +109,28 @@ int hvpr_scatter_bev_fwd_f32(const float *pillar_features, int c_pillar, const f
                              const int32_t *m_device, int batch, int nx, int ny, float *spatial,
                              float *spatial_scale, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a5/a6  BEV backbone + head convolutions: implicit GEMM on the fp32 matrix cores, NHWC.
+ *     Replaces the cuDNN convolutions behind BaseBEVBackbone_Scale.forward (eval),
+ *     pcdet/models/backbones_2d/base_bev_backbone.py:280-315 — ZeroPad2d(1)+Conv3x3(s)+BN+ReLU (:154-169),
+ *     the shared SFM step x_att = gate*ReLU(BN(conv(x_att))) + x_att (:291-295), ConvTranspose2d(k=s)+BN+ReLU
+ *     (:177-188) written into its slice of the concat (:303-304) — and the three 1x1 head convolutions of
+ *     AnchorHeadSingle.forward, pcdet/models/dense_heads/anchor_head_single.py:112-121.
+ *
+ *     in        [N, H, W, Cin] f32 (Cin % 8 == 0)
+ *     w_packed  [taps, Cin/8, cout_pad, 8] f32, BatchNorm scale folded in; taps = 9 (3x3, pad 1) or 1 (1x1).
+ *               For up > 1 (ConvTranspose2d with kernel == stride == up) taps = 1 and the gemm column is
+ *               (ky*up + kx)*cout + co.
+ *     bias      [cout_pad] f32 by gemm column (folded BatchNorm shift or the conv bias)
+ *     gate/resid  both NULL, or gate [N, OH, OW] and resid [N, OH, OW, resid_cstride]: y = gate*y + resid
+ *     out       [N, OH*up, OW*up, out_cstride] f32, channels written at out_coff .. out_coff+cout
+ *     tile_cfg  0: 128 px x 128 ch   1: 64 px x 64 ch   2: 128 px x 64 ch   (cout_pad % tile channels == 0)
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_conv2d_nhwc_f32(const float *in, int N, int H, int W, int Cin, const float *w_packed, const float *bias,
+                         int taps, int stride, int cout, int cout_pad, int up, int relu, const float *gate,
+                         const float *resid, int resid_cstride, float *out, int out_cstride, int out_coff,
+                         int tile_cfg, hvpr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

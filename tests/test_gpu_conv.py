@@ -1,0 +1,74 @@
+"""GPU parity: implicit-GEMM fp32-MFMA convolution vs torch CPU conv (the oracle's F.conv2d) — 1e-3 rel (north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hvpr_amd import kernels
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(gen, *shape):
+    return torch.randn(*shape, generator=gen)
+
+
+def _close(got, ref, tol=1e-3):
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cin,cout,stride,H,W", [(16, 32, 1, 11, 19), (32, 128, 1, 16, 24), (64, 96, 2, 17, 23),
+                                                 (128, 256, 2, 24, 36), (8, 64, 1, 8, 16)])
+def test_conv3x3_bn_relu(cfg, cin, cout, stride, H, W):
+    g = torch.Generator().manual_seed(cin * 1000 + cout + cfg)
+    x = _rand(g, 2, cin, H, W)
+    w = _rand(g, cout, cin, 3, 3) / np.sqrt(cin * 9)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, _rand(g, cout) * 0.3
+    ref = F.relu(F.conv2d(x, w, stride=stride, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pc = kernels.pack_conv(w.to(DEV), scale.to(DEV), shift.to(DEV), stride=stride, relu=True, tile_cfg=cfg)
+    y = kernels.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), pc)
+    _close(y.permute(0, 3, 1, 2).cpu(), ref)
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_sfm_step_gate_residual(cfg):
+    g = torch.Generator().manual_seed(77 + cfg)
+    x = _rand(g, 1, 64, 13, 21)
+    w = _rand(g, 64, 64, 3, 3) / np.sqrt(64 * 9)
+    scale, shift = torch.rand(64, generator=g) + 0.5, _rand(g, 64) * 0.3
+    gate = torch.rand(1, 1, 13, 21, generator=g)
+    ref = gate * F.relu(F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) + x
+    pc = kernels.pack_conv(w.to(DEV), scale.to(DEV), shift.to(DEV), tile_cfg=cfg)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = kernels.conv2d_nhwc(xn, pc, gate=gate.reshape(1, 13, 21).contiguous().to(DEV), resid=xn)
+    _close(y.permute(0, 3, 1, 2).cpu(), ref)
+
+
+@pytest.mark.parametrize("s,cin,cout", [(1, 32, 16), (2, 64, 24), (4, 128, 128)])
+def test_deconv_into_concat_slice(s, cin, cout):
+    g = torch.Generator().manual_seed(900 + s)
+    x = _rand(g, 2, cin, 7, 9)
+    w = _rand(g, cin, cout, s, s) / np.sqrt(cin)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, _rand(g, cout) * 0.3
+    ref = F.relu(F.conv_transpose2d(x, w, stride=s) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pc = kernels.pack_deconv(w.to(DEV), scale.to(DEV), shift.to(DEV), tile_cfg=1)
+    out = torch.full((2, 7 * s, 9 * s, cout + 40), -7.0, device=DEV)
+    kernels.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), pc, out=out, out_coff=24)
+    o = out.cpu()
+    _close(o[..., 24:24 + cout].permute(0, 3, 1, 2), ref)
+    assert (o[..., :24] == -7).all() and (o[..., 24 + cout:] == -7).all()
+
+
+def test_head_1x1_with_bias():
+    g = torch.Generator().manual_seed(5)
+    x = _rand(g, 1, 384, 9, 14)
+    w = _rand(g, 20, 384, 1, 1) / np.sqrt(384)
+    b = _rand(g, 20)
+    ref = F.conv2d(x, w, b)
+    pc = kernels.pack_conv(w.to(DEV), None, b.to(DEV), relu=False, tile_cfg=2)
+    y = kernels.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), pc)
+    _close(y.permute(0, 3, 1, 2).cpu(), ref)
