@@ -27,6 +27,13 @@ SIGNATURES = {
     "hvpr_memory_readout_fwd_f32": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P]),
     "hvpr_scatter_workspace_bytes": (_Z, [_I, _I, _I]),
     "hvpr_scatter_bev_fwd_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "hvpr_spatial_gate_f32": (_I, [_P, _I, _I, _I, _I, _P, _F, _F, _F, _P, _P]),
+    "hvpr_head_decode_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "hvpr_score_topk_workspace_bytes": (_Z, [_I, _I]),
+    "hvpr_score_topk_f32": (_I, [_P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    "hvpr_nms_workspace_bytes": (_Z, [_I]),
+    "hvpr_nms_bev_f32": (_I, [_P, _I, _P, _P, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    "hvpr_boxes_pairwise_f32": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "hvpr_conv2d_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
 }
 

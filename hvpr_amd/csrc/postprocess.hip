@@ -1,0 +1,276 @@
+// a5 (gate) / a7 (anchors + box decode) / a8 (score filter + top-k) — the small kernels around the conv stack.
+//   k_spatial_gate   SpatialAttention gate, pcdet/models/backbones_2d/spatial_attention.py:47-62
+//   k_head_decode    AnchorHeadTemplate.generate_predicted_boxes, dense_heads/anchor_head_template.py:293-340,
+//                    ResidualCoder.decode_torch utils/box_coder_utils.py:45-77, limit_period utils/common_utils.py:20-23,
+//                    + the sigmoid / class max of Detector3DTemplate.post_processing (detector3d_template.py:206-207,241-246)
+//   k_score_compact / k_topk_select   score >= thresh mask and torch.topk of model_nms_utils.py:8-16, with the
+//                    build's deterministic order: descending score, ascending anchor id on ties.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ gate
+// gate[n,y,x] = sigmoid(s * (conv3x3_{2->1}(cat[max_c, mean_c])(y,x) + b) + t); zero padding of the pooled maps.
+constexpr int GT = 16;   // tile edge
+__global__ void __launch_bounds__(256) k_spatial_gate(const float *__restrict__ y, int N, int H, int W, int C,
+                                                      const float *__restrict__ w18, float conv_bias, float bn_scale,
+                                                      float bn_shift, float *__restrict__ gate) {
+    __shared__ float s_max[(GT + 2) * (GT + 2)], s_mean[(GT + 2) * (GT + 2)];
+    const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int grp = tid >> 3, sub = tid & 7;   // 8 lanes per pixel, float4 each
+    for (int p = grp; p < (GT + 2) * (GT + 2); p += 32) {
+        const int py = p / (GT + 2), px = p % (GT + 2);
+        const int iy = ty * GT + py - 1, ix = tx * GT + px - 1;
+        float mx = -INFINITY, sm = 0.f;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        if (in) {
+            const float4 *src = (const float4 *)(y + (((size_t)n * H + iy) * W + ix) * C);
+            for (int c = sub; c < C / 4; c += 8) {
+                const float4 v = src[c];
+                mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                sm += (v.x + v.y) + (v.z + v.w);
+            }
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); sm += __shfl_xor(sm, o, 64); }
+        if (sub == 0) { s_max[p] = in ? mx : 0.f; s_mean[p] = in ? sm / (float)C : 0.f; }
+    }
+    __syncthreads();
+    const int ly = tid / GT, lx = tid % GT;
+    const int oy = ty * GT + ly, ox = tx * GT + lx;
+    if (oy < H && ox < W) {
+        float a = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int p = (ly + ky) * (GT + 2) + lx + kx;
+                a = fmaf(w18[ky * 3 + kx], s_max[p], a);
+                a = fmaf(w18[9 + ky * 3 + kx], s_mean[p], a);
+            }
+        a = (a + conv_bias) * bn_scale + bn_shift;
+        gate[((size_t)n * H + oy) * W + ox] = 1.f / (1.f + expf(-a));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ head decode
+__global__ void __launch_bounds__(256) k_head_decode(const float *__restrict__ head, int N, int H, int W, int CH, int na,
+                                                     int nc, int nbins, const float *__restrict__ xs,
+                                                     const float *__restrict__ ys, const float *__restrict__ anc,
+                                                     float dir_offset, float dir_limit_offset, float period,
+                                                     float *__restrict__ cls_out, float *__restrict__ box_out,
+                                                     float *__restrict__ score_out, int *__restrict__ label_out) {
+    const long long A = (long long)H * W * na;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * A) return;
+    const int n = (int)(t / A);
+    const long long ai = t % A;
+    const int a = (int)(ai % na);
+    const long long pix = ai / na;
+    const int ix = (int)(pix % W), iy = (int)(pix / W);
+    const float *h = head + ((size_t)n * H * W + pix) * CH;
+    // class logits + sigmoid max  (post_processing :206-207, :241-246)
+    float best = -INFINITY;
+    int lab = 0;
+    for (int c = 0; c < nc; ++c) {
+        const float lg = h[a * nc + c];
+        if (cls_out) cls_out[(size_t)t * nc + c] = lg;
+        const float sg = 1.f / (1.f + expf(-lg));
+        if (sg > best) { best = sg; lab = c; }
+    }
+    if (score_out) score_out[t] = best;
+    if (label_out) label_out[t] = lab + 1;
+    // ResidualCoder.decode_torch
+    const float *bt = h + na * nc + a * 7;
+    const float *an = anc + a * 5;   // z centre, dx, dy, dz, rot
+    const float xa = xs[ix], ya = ys[iy], za = an[0], dxa = an[1], dya = an[2], dza = an[3], ra = an[4];
+    const float diag = sqrtf(dxa * dxa + dya * dya);
+    float *o = box_out + (size_t)t * 7;
+    o[0] = bt[0] * diag + xa;
+    o[1] = bt[1] * diag + ya;
+    o[2] = bt[2] * dza + za;
+    o[3] = expf(bt[3]) * dxa;
+    o[4] = expf(bt[4]) * dya;
+    o[5] = expf(bt[5]) * dza;
+    float rg = bt[6] + ra;
+    if (nbins > 0) {
+        const float *dp = h + na * nc + na * 7 + a * nbins;
+        int dl = 0;
+        float dm = dp[0];
+        for (int b = 1; b < nbins; ++b) if (dp[b] > dm) { dm = dp[b]; dl = b; }
+        const float v = rg - dir_offset;
+        const float rot = v - floorf(v / period + dir_limit_offset) * period;   // limit_period
+        rg = rot + dir_offset + period * (float)dl;
+    }
+    o[6] = rg;
+}
+
+// ------------------------------------------------------------------------------------------------ score filter + top-k
+__device__ __forceinline__ unsigned ord_bits(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unord_bits(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// key = (orderable score bits << 32) | ~id : descending key order = descending score, ascending id
+__global__ void __launch_bounds__(256) k_score_compact(const float *__restrict__ scores, int A, float thresh, int use_thresh,
+                                                       unsigned long long *__restrict__ keys, int *__restrict__ counts) {
+    const int n = blockIdx.y;
+    const float *s = scores + (size_t)n * A;
+    unsigned long long *k = keys + (size_t)n * A;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A; i += gridDim.x * blockDim.x) {
+        const float v = s[i];
+        const bool pass = use_thresh ? (v >= thresh) : !(v != v);
+        if (pass) {
+            const int pos = atomicAdd(&counts[n], 1);   // the compiler folds this into one atomic per wave
+            k[pos] = ((unsigned long long)ord_bits(v) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        }
+    }
+}
+
+constexpr int SORTCAP = 8192;
+constexpr int TK_THREADS = 1024;
+
+__device__ void lds_bitonic_desc(unsigned long long *s, int n_pow2) {
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n_pow2; i += TK_THREADS) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = s[i], b = s[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { s[i] = b; s[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ void __launch_bounds__(TK_THREADS) k_topk_select(const unsigned long long *__restrict__ keys, int A,
+                                                            const int *__restrict__ counts, int pre_max,
+                                                            int *__restrict__ order, float *__restrict__ sorted_scores,
+                                                            int *__restrict__ out_counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *s_keys = (unsigned long long *)smem;            // [SORTCAP]
+    unsigned *s_hist = (unsigned *)(s_keys + SORTCAP);                   // [2048]
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_remaining, s_fill;
+    const int n = blockIdx.x;
+    const unsigned long long *k = keys + (size_t)n * A;
+    const int cnt = min(counts[n], A);
+    const int take = min(cnt, pre_max);
+    int m = cnt;   // number of keys to sort in LDS
+    if (cnt > SORTCAP) {
+        // radix select of the take-th largest key (keys are unique), 11 bits per pass from the top
+        if (threadIdx.x == 0) { s_prefix = 0ull; s_remaining = (unsigned)take; }
+        __syncthreads();
+        for (int shift = 53; shift >= -2; shift -= 11) {
+            const int sh = shift < 0 ? 0 : shift;
+            const int bits = shift < 0 ? 11 + shift : 11;
+            const unsigned long long himask = (sh + bits >= 64) ? 0ull : (~0ull << (sh + bits));
+            for (int i = threadIdx.x; i < 2048; i += TK_THREADS) s_hist[i] = 0u;
+            __syncthreads();
+            const unsigned long long pre = s_prefix;
+            for (int i = threadIdx.x; i < cnt; i += TK_THREADS) {
+                const unsigned long long v = k[i];
+                if ((v & himask) == (pre & himask)) atomicAdd(&s_hist[(unsigned)(v >> sh) & ((1u << bits) - 1u)], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned rem = s_remaining;
+                int b = (1 << bits) - 1;
+                for (; b > 0; --b) {
+                    if (s_hist[b] >= rem) break;
+                    rem -= s_hist[b];
+                }
+                s_remaining = rem;
+                s_prefix = pre | ((unsigned long long)b << sh);
+            }
+            __syncthreads();
+        }
+        const unsigned long long kth = s_prefix;
+        if (threadIdx.x == 0) s_fill = 0u;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += TK_THREADS) {
+            const unsigned long long v = k[i];
+            if (v >= kth) { const unsigned p = atomicAdd(&s_fill, 1u); if (p < (unsigned)SORTCAP) s_keys[p] = v; }
+        }
+        __syncthreads();
+        m = take;
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += TK_THREADS) s_keys[i] = k[i];
+    }
+    int p2 = 1;
+    while (p2 < m) p2 <<= 1;
+    for (int i = m + threadIdx.x; i < p2; i += TK_THREADS) s_keys[i] = 0ull;
+    __syncthreads();
+    lds_bitonic_desc(s_keys, p2);
+    for (int i = threadIdx.x; i < take; i += TK_THREADS) {
+        const unsigned long long v = s_keys[i];
+        order[(size_t)n * pre_max + i] = (int)(0xffffffffu - (unsigned)(v & 0xffffffffull));
+        if (sorted_scores) sorted_scores[(size_t)n * pre_max + i] = unord_bits((unsigned)(v >> 32));
+    }
+    if (threadIdx.x == 0) out_counts[n] = take;
+}
+
+}  // namespace
+
+extern "C" int hvpr_spatial_gate_f32(const float *y, int N, int H, int W, int C, const float *w18, float conv_bias,
+                                     float bn_scale, float bn_shift, float *gate, hvpr_stream_t stream) {
+    if (!y || !w18 || !gate || N < 1 || H < 1 || W < 1 || C < 4) return HVPR_ERR_INVALID_ARG;
+    if (C % 4 != 0) return HVPR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_spatial_gate, dim3(hvpr_cdiv(W, GT), hvpr_cdiv(H, GT), N), dim3(256), 0, (hipStream_t)stream, y, N,
+                       H, W, C, w18, conv_bias, bn_scale, bn_shift, gate);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_head_decode_f32(const float *head, int N, int H, int W, int head_channels, int n_anchor, int n_class,
+                                    int n_dir_bins, const float *x_shifts, const float *y_shifts, const float *anchor_table,
+                                    float dir_offset, float dir_limit_offset, float period, float *batch_cls_preds,
+                                    float *batch_box_preds, float *scores, int32_t *labels, hvpr_stream_t stream) {
+    if (!head || !x_shifts || !y_shifts || !anchor_table || !batch_box_preds || N < 1 || H < 1 || W < 1 || n_anchor < 1 ||
+        n_class < 1 || n_dir_bins < 0)
+        return HVPR_ERR_INVALID_ARG;
+    if (head_channels != n_anchor * (n_class + 7 + n_dir_bins)) return HVPR_ERR_INVALID_ARG;
+    const long long total = (long long)N * H * W * n_anchor;
+    hipLaunchKernelGGL(k_head_decode, dim3(hvpr_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, head, N, H, W,
+                       head_channels, n_anchor, n_class, n_dir_bins, x_shifts, y_shifts, anchor_table, dir_offset,
+                       dir_limit_offset, period, batch_cls_preds, batch_box_preds, scores, labels);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" size_t hvpr_score_topk_workspace_bytes(int batch, int n_scores) {
+    if (batch < 1 || n_scores < 1) return 0;
+    return (size_t)batch * n_scores * sizeof(unsigned long long) + 256 + (size_t)batch * sizeof(int);
+}
+
+extern "C" int hvpr_score_topk_f32(const float *scores, int batch, int n_scores, float score_thresh, int use_thresh,
+                                   int pre_max, int32_t *order, float *sorted_scores, int32_t *counts, void *workspace,
+                                   size_t workspace_bytes, hvpr_stream_t stream) {
+    if (!scores || !order || !counts || !workspace || batch < 1 || n_scores < 1 || pre_max < 1) return HVPR_ERR_INVALID_ARG;
+    if (pre_max > SORTCAP) return HVPR_ERR_UNSUPPORTED;
+    if (workspace_bytes < hvpr_score_topk_workspace_bytes(batch, n_scores)) return HVPR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *keys = (unsigned long long *)workspace;
+    int *cnt = (int *)((char *)workspace + (((size_t)batch * n_scores * sizeof(unsigned long long) + 255) / 256) * 256);
+    if (hipMemsetAsync(cnt, 0, sizeof(int) * batch, s) != hipSuccess) return HVPR_ERR_LAUNCH;
+    int bx = hvpr_cdiv(n_scores, 256 * 4);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_score_compact, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, keys, cnt);
+    const size_t lds = (size_t)SORTCAP * 8 + 2048 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_topk_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return HVPR_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_topk_select, dim3(batch), dim3(TK_THREADS), lds, s, keys, n_scores, cnt, pre_max, order,
+                       sorted_scores, counts);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}

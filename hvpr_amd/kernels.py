@@ -199,3 +199,75 @@ def conv2d_nhwc(x, pc, out=None, out_coff=0, gate=None, resid=None):
                                      out.data_ptr(), out.shape[-1], int(out_coff), pc.tile_cfg, _stream()),
           "hvpr_conv2d_nhwc_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ gate / decode / top-k / NMS
+def spatial_gate(y_nhwc, w18, conv_bias, bn_scale, bn_shift):
+    N, H, W, C = y_nhwc.shape
+    gate = torch.empty((N, H, W), dtype=torch.float32, device=y_nhwc.device)
+    check(lib().hvpr_spatial_gate_f32(_ptr(y_nhwc, torch.float32, "scale features"), N, H, W, C,
+                                      _ptr(w18, torch.float32, "gate conv weight"), float(conv_bias), float(bn_scale),
+                                      float(bn_shift), gate.data_ptr(), _stream()), "hvpr_spatial_gate_f32")
+    return gate
+
+
+def head_decode(head_nhwc, n_anchor, n_class, n_dir_bins, x_shifts, y_shifts, anchor_table, dir_offset, dir_limit_offset,
+                period, want_cls=True, want_scores=True):
+    N, H, W, CH = head_nhwc.shape
+    A = H * W * n_anchor
+    dev = head_nhwc.device
+    cls = torch.empty((N, A, n_class), dtype=torch.float32, device=dev) if want_cls else None
+    box = torch.empty((N, A, 7), dtype=torch.float32, device=dev)
+    scores = torch.empty((N, A), dtype=torch.float32, device=dev) if want_scores else None
+    labels = torch.empty((N, A), dtype=torch.int32, device=dev) if want_scores else None
+    check(lib().hvpr_head_decode_f32(_ptr(head_nhwc, torch.float32, "head output"), N, H, W, CH, n_anchor, n_class,
+                                     n_dir_bins, _ptr(x_shifts, torch.float32), _ptr(y_shifts, torch.float32),
+                                     _ptr(anchor_table, torch.float32), float(dir_offset), float(dir_limit_offset),
+                                     float(period), _ptr(cls), box.data_ptr(), _ptr(scores), _ptr(labels), _stream()),
+          "hvpr_head_decode_f32")
+    return cls, box, scores, labels
+
+
+class PostWorkspace:
+    """Device scratch for score top-k + NMS of `batch` frames with `n_scores` anchors each."""
+
+    def __init__(self, batch, n_scores, pre_max, device):
+        self.batch, self.n_scores, self.pre_max = batch, n_scores, pre_max
+        self.topk = torch.empty(lib().hvpr_score_topk_workspace_bytes(batch, n_scores), dtype=torch.uint8, device=device)
+        self.nms = torch.empty(lib().hvpr_nms_workspace_bytes(pre_max), dtype=torch.uint8, device=device)
+
+
+def score_topk(scores, score_thresh, pre_max, ws, want_scores=True):
+    """scores (B, A) -> order (B, pre_max) i32, sorted scores (B, pre_max), counts (B,) i32."""
+    B, A = scores.shape
+    dev = scores.device
+    order = torch.empty((B, pre_max), dtype=torch.int32, device=dev)
+    ss = torch.empty((B, pre_max), dtype=torch.float32, device=dev) if want_scores else None
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    use = score_thresh is not None
+    check(lib().hvpr_score_topk_f32(_ptr(scores, torch.float32, "scores"), B, A, float(score_thresh) if use else 0.0,
+                                    1 if use else 0, int(pre_max), order.data_ptr(), _ptr(ss), counts.data_ptr(),
+                                    ws.topk.data_ptr(), ws.topk.numel(), _stream()), "hvpr_score_topk_f32")
+    return order, ss, counts
+
+
+def nms_bev(boxes, order, n_device, n_max, thresh, max_keep, ws_nms, map_through_order=True):
+    """boxes (R, >=7) f32; order (n_max,) i32 or None.  Returns keep (max_keep,) i32, keep_count (1,) i32."""
+    dev = boxes.device
+    keep = torch.empty((max(max_keep, 1),), dtype=torch.int32, device=dev)
+    kc = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib().hvpr_nms_bev_f32(_ptr(boxes, torch.float32, "boxes"), boxes.shape[1], _ptr(order, torch.int32),
+                                 _ptr(n_device, torch.int32), int(n_max), float(thresh), int(max_keep),
+                                 1 if map_through_order else 0, keep.data_ptr(), kc.data_ptr(), ws_nms.data_ptr(),
+                                 ws_nms.numel(), _stream()), "hvpr_nms_bev_f32")
+    return keep, kc
+
+
+def boxes_pairwise(a, b, mode):
+    """mode 0: BEV overlap area, 1: BEV IoU, 2: 3D IoU.  a (N,7), b (M,7) -> (N,M)."""
+    a = a[:, :7].contiguous()
+    b = b[:, :7].contiguous()
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(lib().hvpr_boxes_pairwise_f32(_ptr(a, torch.float32, "boxes_a"), a.shape[0], _ptr(b, torch.float32, "boxes_b"),
+                                        b.shape[0], int(mode), out.data_ptr(), _stream()), "hvpr_boxes_pairwise_f32")
+    return out

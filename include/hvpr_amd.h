@@ -131,6 +131,59 @@ int hvpr_conv2d_nhwc_f32(const float *in, int N, int H, int W, int Cin, const fl
                          const float *resid, int resid_cstride, float *out, int out_cstride, int out_coff,
                          int tile_cfg, hvpr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a5  SpatialAttention gate.  Replaces ChannelPool + ConvLayer(2->1, 3x3, bias) + BatchNorm + sigmoid of
+ *     pcdet/models/backbones_2d/spatial_attention.py:47-62.  y [N,H,W,C] NHWC -> gate [N,H,W].
+ *     w18: conv weight (1,2,3,3) flattened [max-channel 9 taps | mean-channel 9 taps]; bn_scale/bn_shift: folded BN.
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_spatial_gate_f32(const float *y, int N, int H, int W, int C, const float *w18, float conv_bias, float bn_scale,
+                          float bn_shift, float *gate, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a7  Anchors + box decode + direction fix + class sigmoid/max.  Replaces
+ *     AnchorHeadTemplate.generate_predicted_boxes (dense_heads/anchor_head_template.py:293-340),
+ *     ResidualCoder.decode_torch (utils/box_coder_utils.py:45-77), limit_period (utils/common_utils.py:20-23) and the
+ *     sigmoid + max over classes of Detector3DTemplate.post_processing (detectors/detector3d_template.py:206-207,241-246).
+ *     head [N,H,W, n_anchor*(n_class + 7 + n_dir_bins)] = [cls | box | dir] NHWC (output of the three 1x1 convs);
+ *     x_shifts [W], y_shifts [H]: anchor centres exactly as AnchorGenerator's arange (anchor_generator.py:34-39);
+ *     anchor_table [n_anchor,5] = z centre, dx, dy, dz, rotation.  Anchor id = (y*W + x)*n_anchor + a.
+ *     Outputs: batch_cls_preds [N,A,n_class] (may be NULL), batch_box_preds [N,A,7], scores [N,A] (may be NULL),
+ *     labels [N,A] i32, 1-based (may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_head_decode_f32(const float *head, int N, int H, int W, int head_channels, int n_anchor, int n_class,
+                         int n_dir_bins, const float *x_shifts, const float *y_shifts, const float *anchor_table,
+                         float dir_offset, float dir_limit_offset, float period, float *batch_cls_preds,
+                         float *batch_box_preds, float *scores, int32_t *labels, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a8  Score filter + top-k.  Replaces `scores >= thresh`, torch.topk and mask.nonzero() of
+ *     class_agnostic_nms, pcdet/models/model_utils/model_nms_utils.py:8-16,22-24.
+ *     scores [batch, n_scores]; order [batch, pre_max] i32 = ids sorted by (score desc, id asc);
+ *     sorted_scores [batch, pre_max] (may be NULL); counts [batch] i32 = min(#passing, pre_max).
+ *     use_thresh = 0 keeps every non-NaN score.  pre_max <= 8192.
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_score_topk_workspace_bytes(int batch, int n_scores);
+int hvpr_score_topk_f32(const float *scores, int batch, int n_scores, float score_thresh, int use_thresh, int pre_max,
+                        int32_t *order, float *sorted_scores, int32_t *counts, void *workspace, size_t workspace_bytes,
+                        hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a8  Rotated-BEV NMS and pairwise overlaps.  Replaces the absent pcdet/ops/iou3d_nms natives (setup.py:53-62):
+ *     nms_gpu (call site model_nms_utils.py:17-19), boxes_overlap_bev_gpu / boxes_iou_bev / boxes_iou3d_gpu
+ *     (detectors/detector3d_template.py:298,303).  Boxes [x,y,z,dx,dy,dz,heading], rows `box_stride` floats apart.
+ *     hvpr_nms_bev_f32: candidate i is boxes[order ? order[i] : i], candidates already in descending score;
+ *       n_device (may be NULL) holds the live count <= n_max (<= 16384); IoU > thresh suppresses (strict);
+ *       keep[0..keep_count) = kept candidate positions, or order[position] when map_through_order != 0;
+ *       at most max_keep are produced (NMS_POST_MAXSIZE).
+ *     hvpr_boxes_pairwise_f32: mode 0 BEV overlap area, 1 BEV IoU, 2 3D IoU; out [n, m]; rows 7 floats apart.
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_nms_workspace_bytes(int n_max);
+int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_t *order, const int32_t *n_device, int n_max,
+                     float thresh, int max_keep, int map_through_order, int32_t *keep, int32_t *keep_count,
+                     void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+int hvpr_boxes_pairwise_f32(const float *boxes_a, int n, const float *boxes_b, int m, int mode, float *out,
+                            hvpr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

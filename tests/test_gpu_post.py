@@ -1,0 +1,122 @@
+"""GPU parity: gate, head decode, score top-k (bit-exact order), rotated-BEV NMS (bit-exact survivors), pairwise IoU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hvpr_amd import kernels
+from oracle import hvpr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _boxes(rng, n, spread=40.0, clustered=True):
+    """Car-sized boxes; clustered so that many pairs overlap."""
+    if clustered:
+        centres = rng.uniform([0, -20], [spread, 20], (max(n // 6, 1), 2))
+        xy = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 0.8, (n, 2))
+    else:
+        xy = rng.uniform([0, -20], [spread, 20], (n, 2))
+    z = rng.normal(-1.0, 0.2, (n, 1))
+    size = np.array([3.9, 1.6, 1.56]) * rng.uniform(0.8, 1.2, (n, 3))
+    yaw = rng.uniform(-np.pi, np.pi, (n, 1))
+    return np.concatenate([xy, z, size, yaw], 1).astype(np.float32)
+
+
+def test_spatial_gate_vs_oracle():
+    g = torch.Generator().manual_seed(3)
+    for C, H, W in ((32, 19, 37), (64, 16, 16), (128, 5, 50)):
+        y = torch.randn(2, C, H, W, generator=g)
+        params = {"attention.spatial.conv.weight": torch.randn(1, 2, 3, 3, generator=g) * 0.5,
+                  "attention.spatial.conv.bias": torch.randn(1, generator=g),
+                  "attention.spatial.norm.weight": torch.rand(1, generator=g) + 0.5,
+                  "attention.spatial.norm.bias": torch.randn(1, generator=g) * 0.2,
+                  "attention.spatial.norm.running_mean": torch.randn(1, generator=g) * 0.2,
+                  "attention.spatial.norm.running_var": torch.rand(1, generator=g) + 0.5}
+        ref = O.spatial_gate(y, params)
+        s = params["attention.spatial.norm.weight"] / torch.sqrt(params["attention.spatial.norm.running_var"] + 1e-3)
+        t = params["attention.spatial.norm.bias"] - params["attention.spatial.norm.running_mean"] * s
+        gate = kernels.spatial_gate(y.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                    params["attention.spatial.conv.weight"].reshape(18).to(DEV),
+                                    params["attention.spatial.conv.bias"].item(), s.item(), t.item())
+        np.testing.assert_allclose(gate.cpu().numpy(), ref[:, 0].numpy(), rtol=1e-3, atol=1e-5)
+
+
+def test_head_decode_golden(golden_dir):
+    for stride in (1, 2):
+        z = np.load(os.path.join(golden_dir, f"g5_head_stride{stride}.npz"))
+        cls, box, dirp = (torch.from_numpy(z[k]) for k in ("cls_preds", "box_preds", "dir_cls_preds"))
+        head = torch.cat([cls, box, dirp], dim=-1).contiguous().to(DEV)
+        anc = torch.from_numpy(z["anchors"])                     # (1, H, W, 1, 2, 7)
+        xs, ys = anc[0, 0, :, 0, 0, 0].contiguous(), anc[0, :, 0, 0, 0, 1].contiguous()
+        table = anc[0, 0, 0, 0, :, [2, 3, 4, 5, 6]].contiguous()
+        c, b, s, lab = kernels.head_decode(head, 2, 1, 2, xs.to(DEV), ys.to(DEV), table.to(DEV), 0.78539, 0.0, np.pi)
+        np.testing.assert_array_equal(c.cpu().numpy(), z["batch_cls_preds"])
+        np.testing.assert_allclose(b.cpu().numpy(), z["batch_box_preds"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(s.cpu().numpy(), 1 / (1 + np.exp(-z["batch_cls_preds"][..., 0].astype(np.float64))), rtol=1e-5)
+        assert (lab.cpu().numpy() == 1).all()
+
+
+@pytest.mark.parametrize("A,thresh,pre", [(1000, 0.5, 4096), (146816, 0.9, 4096), (146816, 0.5, 4096), (146816, None, 4096),
+                                          (30000, 0.0, 512), (5, 2.0, 16)])
+def test_score_topk_exact_order(A, thresh, pre):
+    rng = np.random.default_rng(A + pre)
+    s = rng.uniform(0, 1, (2, A)).astype(np.float32)
+    s[0, : A // 3] = np.round(s[0, : A // 3], 2)     # heavy ties -> the id tie-break must be honoured
+    ws = kernels.PostWorkspace(2, A, pre, DEV)
+    order, ss, counts = kernels.score_topk(torch.from_numpy(s).to(DEV), thresh, pre, ws)
+    order, ss, counts = order.cpu().numpy(), ss.cpu().numpy(), counts.cpu().numpy()
+    for b in range(2):
+        passing = np.nonzero(s[b] >= np.float32(thresh))[0] if thresh is not None else np.arange(A)
+        ref = passing[O.stable_order_desc(s[b][passing])][:pre]
+        assert counts[b] == len(ref)
+        np.testing.assert_array_equal(order[b, : counts[b]], ref)
+        np.testing.assert_array_equal(ss[b, : counts[b]], s[b][ref])
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (63, 1), (64, 2), (65, 3), (700, 4), (4096, 5)])
+def test_nms_survivors_bit_exact(n, seed):
+    rng = np.random.default_rng(seed)
+    boxes = _boxes(rng, n)
+    scores = rng.uniform(0.1, 1, n).astype(np.float32)
+    ref = O.nms_bev(boxes, scores, 0.1)
+    ws = kernels.PostWorkspace(1, n, max(n, 1), DEV)
+    order, _, cnt = kernels.score_topk(torch.from_numpy(scores[None]).to(DEV), None, n, ws)
+    keep, kc = kernels.nms_bev(torch.from_numpy(boxes).to(DEV), order[0].contiguous(), cnt, n, 0.1, n, ws.nms)
+    got = keep.cpu().numpy()[: int(kc.item())]
+    np.testing.assert_array_equal(got, ref)
+    # properties: survivors mutually below the threshold, score-sorted, idempotent
+    iou = O.boxes_iou_bev(boxes[got], boxes[got])
+    assert (iou[np.triu_indices(len(got), 1)] <= 0.1).all()
+    assert (np.diff(scores[got]) <= 0).all()
+    keep2, kc2 = kernels.nms_bev(torch.from_numpy(boxes[got]).to(DEV), None, None, len(got), 0.1, len(got), ws.nms, False)
+    np.testing.assert_array_equal(keep2.cpu().numpy()[: int(kc2.item())], np.arange(len(got)))
+
+
+def test_nms_post_max_and_thresholds():
+    rng = np.random.default_rng(11)
+    boxes = _boxes(rng, 2000, clustered=False)
+    scores = rng.uniform(0, 1, 2000).astype(np.float32)
+    ws = kernels.PostWorkspace(1, 2000, 2000, DEV)
+    order, _, cnt = kernels.score_topk(torch.from_numpy(scores[None]).to(DEV), None, 2000, ws)
+    for thr in (0.01, 0.1, 0.7):
+        ref = O.nms_bev(boxes, scores, thr)[:500]
+        keep, kc = kernels.nms_bev(torch.from_numpy(boxes).to(DEV), order[0].contiguous(), cnt, 2000, thr, 500, ws.nms)
+        np.testing.assert_array_equal(keep.cpu().numpy()[: int(kc.item())], ref)
+
+
+def test_pairwise_overlap_and_iou():
+    rng = np.random.default_rng(5)
+    a, b = _boxes(rng, 150), _boxes(rng, 90)
+    ta, tb = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)
+    for mode, fn in ((0, O.boxes_overlap_bev), (1, O.boxes_iou_bev), (2, O.boxes_iou3d)):
+        got = kernels.boxes_pairwise(ta, tb, mode).cpu().numpy()
+        ref = fn(a, b)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
+    # identical boxes -> IoU 1 (within polygon round-off); disjoint -> exactly 0
+    same = kernels.boxes_pairwise(ta[:10], ta[:10], 1).cpu().numpy()
+    np.testing.assert_allclose(np.diag(same), 1.0, atol=1e-3)
+    far = a.copy(); far[:, 0] += 500
+    assert (kernels.boxes_pairwise(ta, torch.from_numpy(far).to(DEV), 0).cpu().numpy() == 0).all()
