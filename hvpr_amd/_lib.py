@@ -21,7 +21,7 @@ SIGNATURES = {
     "hvpr_voxelize_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "hvpr_voxelize_workspace_reset": (_I, [_P, _Z, _I, _I, _I, _I, _I, _P]),
     "hvpr_voxelize_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I,
-                               _P, _P, _P, _P, _I, _P, _Z, _P]),
+                               _P, _P, _P, _P, _I, _P, _Z, _I, _I, _P]),
     "hvpr_pillar_vfe_fwd_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P]),
     "hvpr_memory_readout_fwd_f32": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P]),

@@ -1,0 +1,166 @@
+"""2-D BEV backbone with the reference's plugin interface (pcdet/models/backbones_2d/base_bev_backbone.py,
+spatial_attention.py): same registry key, ctor kwargs and state-dict names.  The eval forward runs every convolution
+on the fp32 matrix cores through hvpr_conv2d_nhwc_f32 with BatchNorm / ReLU / gate / residual fused in the epilogue,
+activations kept NHWC end to end, the gate computed ONCE per level (it depends only on the scale stream,
+base_bev_backbone.py:289-293) and each deconv writing straight into its slice of the 384-channel concat."""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import kernels
+from .folding import FoldCache, bn_scale_shift
+
+
+class ConvLayer(nn.Module):
+    """spatial_attention.py:9-45 — conv (+bias) + BatchNorm2d, no activation here."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, use_norm=True, activation=False):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+        self.norm = nn.BatchNorm2d(out_channels, eps=1e-3, momentum=0.01) if use_norm else None
+        self.relu = nn.ReLU() if activation else None
+
+
+class SpatialAttention(nn.Module):
+    """CBAM-style spatial gate — spatial_attention.py:51-63.  forward(x, w) = sigmoid(BN(conv(pool(w)))) * x."""
+
+    def __init__(self):
+        super().__init__()
+        self.spatial = ConvLayer(2, 1, 3, stride=1, padding=1, use_norm=True, activation=False)
+
+    def gate_params(self):
+        s, t = bn_scale_shift(self.spatial.norm)
+        return (self.spatial.conv.weight.detach().float().reshape(18).contiguous(), float(self.spatial.conv.bias.detach()),
+                float(s), float(t))
+
+
+def _conv_bn_relu(cin, cout, stride=1, zero_pad=False):
+    if zero_pad:   # nn.ZeroPad2d(1) + conv(padding=0) — the form the reference uses for strided entries (:154-160)
+        return [nn.ZeroPad2d(1), nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=0, bias=False),
+                nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01), nn.ReLU()]
+    return [nn.Conv2d(cin, cout, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01), nn.ReLU()]
+
+
+def _tile_cfg(h, w, cout_cols):
+    """Pick the workgroup tile so that the launch fills 256 CUs: big tiles on big maps, 64x64 on small ones."""
+    forced = os.environ.get("HVPR_CONV_TILE")
+    if forced is not None:
+        return int(forced)
+    px = h * w
+    if cout_cols < 128:
+        return 2 if px >= 128 * 256 else 1
+    n128 = ((px + 127) // 128) * ((cout_cols + 127) // 128)
+    if n128 >= 512:
+        return 0
+    n_128x64 = ((px + 127) // 128) * ((cout_cols + 63) // 64)
+    return 2 if n_128x64 >= 512 else 1
+
+
+class BaseBEVBackbone_Scale(nn.Module):
+    """base_bev_backbone.py:116-315."""
+
+    def __init__(self, model_cfg, input_channels):
+        super().__init__()
+        self.model_cfg = model_cfg
+        layer_nums, strides, filters = list(model_cfg.LAYER_NUMS), list(model_cfg.LAYER_STRIDES), list(model_cfg.NUM_FILTERS)
+        assert len(layer_nums) == len(strides) == len(filters)
+        self.sfm_layer_nums = list(model_cfg.SFM_LAYER_NUMS)
+        up_strides, up_filters = list(model_cfg.UPSAMPLE_STRIDES), list(model_cfg.NUM_UPSAMPLE_FILTERS)
+        assert len(up_strides) == len(up_filters) == len(layer_nums), "HIP path: one deblock per level"
+        scale_filters = list(model_cfg.NUM_SCALE_FILTERS)
+        assert len(scale_filters) == len(strides)
+        cin = [input_channels] + filters[:-1]
+        cin_s = [input_channels // 4] + scale_filters[:-1]
+        self.layer_strides, self.layer_nums, self.upsample_strides = strides, layer_nums, up_strides
+        self.sfmblocks_down, self.sfmblocks_up = nn.ModuleList(), nn.ModuleList()
+        self.scale_layers, self.blocks, self.deblocks = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for i in range(len(layer_nums)):
+            layers = _conv_bn_relu(cin[i], filters[i], strides[i], zero_pad=True)
+            for _ in range(layer_nums[i]):
+                layers += _conv_bn_relu(filters[i], filters[i])
+            self.blocks.append(nn.Sequential(*layers))
+            self.sfmblocks_down.append(nn.Sequential(*_conv_bn_relu(filters[i], filters[i])))
+            s = up_strides[i]
+            assert s >= 1 and int(s) == s, "HIP path: integer upsample strides (ConvTranspose2d with kernel == stride)"
+            self.deblocks.append(nn.Sequential(
+                nn.ConvTranspose2d(filters[i], up_filters[i], int(s), stride=int(s), bias=False),
+                nn.BatchNorm2d(up_filters[i], eps=1e-3, momentum=0.01), nn.ReLU()))
+            self.scale_layers.append(nn.Sequential(*_conv_bn_relu(cin_s[i], scale_filters[i], strides[i], zero_pad=True)))
+        self.up_filters = up_filters
+        self.num_bev_features = sum(up_filters)
+        self.attention = SpatialAttention()
+        self._fold = FoldCache()
+        self._shape_key = None
+
+    def train(self, mode=True):
+        self._fold.invalidate()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._fold.invalidate()
+        return super()._load_from_state_dict(*a, **k)
+
+    def _build_packed(self, H, W):
+        packed = {"levels": [], "gate": self.attention.gate_params()}
+        h, w = H, W
+        for i in range(len(self.blocks)):
+            s = self.layer_strides[i]
+            h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+            blk = self.blocks[i]
+            cout = blk[1].weight.shape[0]
+            cfg = _tile_cfg(h, w, cout)
+            lv = {"convs": []}
+            sc, sh = bn_scale_shift(blk[2])
+            lv["convs"].append(kernels.pack_conv(blk[1].weight, sc, sh, stride=s, tile_cfg=cfg))
+            for k in range(self.layer_nums[i]):
+                sc, sh = bn_scale_shift(blk[5 + 3 * k])
+                lv["convs"].append(kernels.pack_conv(blk[4 + 3 * k].weight, sc, sh, tile_cfg=cfg))
+            sc, sh = bn_scale_shift(self.sfmblocks_down[i][1])
+            lv["sfm"] = kernels.pack_conv(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=cfg)
+            sl = self.scale_layers[i]
+            sc, sh = bn_scale_shift(sl[2])
+            lv["scale"] = kernels.pack_conv(sl[1].weight, sc, sh, stride=s, tile_cfg=_tile_cfg(h, w, sl[1].weight.shape[0]))
+            de = self.deblocks[i]
+            sc, sh = bn_scale_shift(de[1])
+            us = int(self.upsample_strides[i])
+            lv["deconv"] = kernels.pack_deconv(de[0].weight, sc, sh, tile_cfg=_tile_cfg(h, w, us * us * de[0].weight.shape[1]))
+            packed["levels"].append(lv)
+        return packed
+
+    def forward(self, data_dict):
+        if self.training:
+            raise NotImplementedError("hvpr_amd: the training forward of BaseBEVBackbone_Scale is not built yet")
+        sp, sc = data_dict["spatial_features"], data_dict["spatial_scale_features"]
+        x = sp.permute(0, 2, 3, 1).contiguous()       # no copy when the scatter produced channels_last
+        y = sc.permute(0, 2, 3, 1).contiguous()
+        B, H, W, _ = x.shape
+        if self._shape_key != (H, W):
+            self._fold.invalidate()
+            self._shape_key = (H, W)
+        P = self._fold.get(x.device, lambda: self._build_packed(H, W))
+        gw, gb, gs, gt = P["gate"]
+        gw = gw.to(x.device)
+        out = None
+        coff = 0
+        for i, lv in enumerate(P["levels"]):
+            for pc in lv["convs"]:
+                x = kernels.conv2d_nhwc(x, pc)
+            y = kernels.conv2d_nhwc(y, lv["scale"])
+            gate = kernels.spatial_gate(y, gw, gb, gs, gt)
+            x_att = x
+            for _ in range(self.sfm_layer_nums[i]):
+                x_att = kernels.conv2d_nhwc(x_att, lv["sfm"], gate=gate, resid=x_att)
+            us = int(self.upsample_strides[i])
+            if out is None:
+                out = torch.empty((B, x_att.shape[1] * us, x_att.shape[2] * us, self.num_bev_features), dtype=torch.float32,
+                                  device=x.device)
+            kernels.conv2d_nhwc(x_att, lv["deconv"], out=out, out_coff=coff)
+            coff += self.up_filters[i]
+        data_dict["spatial_features_2d"] = out.permute(0, 3, 1, 2)   # (B, 384, H, W), channels_last
+        return data_dict
+
+
+__all__ = {
+    "BaseBEVBackbone_Scale": BaseBEVBackbone_Scale,
+}

@@ -305,7 +305,7 @@ extern "C" int hvpr_voxelize_f32(const float *points, int n_points, int point_st
                                  float vs_y, float vs_z, int nx, int ny, int nz, int max_points, int max_voxels,
                                  int cap_mode, float *voxels, int32_t *coords, int32_t *num_points,
                                  int32_t *voxel_offsets, int capacity, void *workspace, size_t workspace_bytes,
-                                 hvpr_stream_t stream) {
+                                 int ws_max_batch, int ws_max_points, hvpr_stream_t stream) {
     if (!points || !frame_offsets || !voxels || !coords || !num_points || !voxel_offsets || !workspace)
         return HVPR_ERR_INVALID_ARG;
     if (batch < 1 || n_points < 0 || n_feat < 3 || xyz_col < 0 || point_stride < xyz_col + n_feat || nx < 1 || ny < 1 ||
@@ -313,14 +313,15 @@ extern "C" int hvpr_voxelize_f32(const float *points, int n_points, int point_st
         return HVPR_ERR_INVALID_ARG;
     if (max_points > 63 || (long long)batch * nx * ny * nz > 0x7ffffff0ll) return HVPR_ERR_UNSUPPORTED;
     const long long ncell = (long long)nx * ny * nz;
-    const int n_alloc = n_points > 0 ? n_points : 1;
-    if (workspace_bytes < ws_bytes(batch, n_alloc, ncell)) return HVPR_ERR_WORKSPACE;
+    // the workspace is carved with the dimensions it was sized and reset for, not with this call's
+    if (ws_max_batch < batch || ws_max_points < n_points || ws_max_points < 1) return HVPR_ERR_WORKSPACE;
+    if (workspace_bytes < ws_bytes(ws_max_batch, ws_max_points, ncell)) return HVPR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (n_points == 0) {
         if (hipMemsetAsync(voxel_offsets, 0, sizeof(int) * (batch + 1), s) != hipSuccess) return HVPR_ERR_LAUNCH;
         return HVPR_OK;
     }
-    VoxWs w = carve(workspace, batch, n_alloc, ncell);
+    VoxWs w = carve(workspace, ws_max_batch, ws_max_points, ncell);
     const int tiles = hvpr_cdiv(n_points, kScanTile);
     const int pblocks = hvpr_cdiv(n_points, 256);
     hipLaunchKernelGGL(k1_keys, dim3(pblocks), dim3(256), 0, s, points, n_points, point_stride, xyz_col, frame_offsets,

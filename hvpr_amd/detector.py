@@ -1,0 +1,337 @@
+"""Detector layer with the reference's model API (pcdet/models/detectors/, pcdet/models/__init__.py [absent upstream file],
+pcdet/models/model_utils/model_nms_utils.py): module registries keyed by the yaml NAME, the constructor-kwarg contract of
+Detector3DTemplate.build_*, ordered module_list, forward(batch_dict) -> batch_dict, post_processing -> pred_dicts."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import anchor_head, bev_backbone, iou3d_nms_utils, kernels, map_to_bev, vfe
+from .voxel_generator import VoxelGenerator
+
+backbones_3d_all = {}          # PointNet2MSG (training-only point stream) registers here once built
+REGISTRY = {
+    "backbone_3d": backbones_3d_all,
+    "vfe": vfe.__all__,
+    "map_to_bev": map_to_bev.__all__,
+    "backbone_2d": bev_backbone.__all__,
+    "dense_head": anchor_head.__all__,
+}
+
+
+# ---------------------------------------------------------------------------------------------- model_nms_utils
+def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
+    """model_nms_utils.py:6-25, same arguments and return value (selected ids into box_scores, their scores)."""
+    n = box_scores.shape[0]
+    dev = box_scores.device
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.long, device=dev), box_scores[:0]
+    pre = min(int(nms_config.NMS_PRE_MAXSIZE), n)
+    ws = kernels.PostWorkspace(1, n, pre, dev)
+    order, _, cnt = kernels.score_topk(box_scores.float().reshape(1, n).contiguous(), score_thresh, pre, ws, want_scores=False)
+    keep, kc = kernels.nms_bev(box_preds.float().contiguous(), order[0].contiguous(), cnt, pre, float(nms_config.NMS_THRESH),
+                               int(nms_config.NMS_POST_MAXSIZE), ws.nms)
+    selected = keep[: int(kc.item())].long()
+    return selected, box_scores[selected]
+
+
+# ---------------------------------------------------------------------------------------------- detectors
+class Detector3DTemplate(nn.Module):
+    """detectors/detector3d_template.py:13-132 (construction), :168-318 (post-processing, recall)."""
+
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.dataset = dataset
+        self.class_names = dataset.class_names
+        self.register_buffer("global_step", torch.LongTensor(1).zero_())
+        self.module_topology = ["backbone_3d", "vfe", "map_to_bev_module", "pfe", "backbone_2d", "dense_head",
+                                "point_head", "roi_head"]
+        self._post_ws = None
+
+    @property
+    def mode(self):
+        return "TRAIN" if self.training else "TEST"
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def build_networks(self):
+        info = {
+            "module_list": [],
+            "num_rawpoint_features": self.dataset.point_feature_encoder.num_point_features,
+            "num_point_features": self.dataset.point_feature_encoder.num_point_features,
+            "grid_size": self.dataset.grid_size,
+            "point_cloud_range": self.dataset.point_cloud_range,
+            "voxel_size": self.dataset.voxel_size,
+        }
+        for name in self.module_topology:
+            module, info = getattr(self, "build_%s" % name)(model_info_dict=info)
+            self.add_module(name, module)
+        return info["module_list"]
+
+    def build_backbone_3d(self, model_info_dict):
+        cfg = self.model_cfg.get("BACKBONE_3D", None)
+        if cfg is None or cfg.NAME not in backbones_3d_all:
+            # the point stream only exists in training (MixAnchor_Memory skips it in eval, pointpillar.py:54)
+            return None, model_info_dict
+        m = backbones_3d_all[cfg.NAME](model_cfg=cfg, input_channels=model_info_dict["num_point_features"],
+                                       grid_size=model_info_dict["grid_size"], voxel_size=model_info_dict["voxel_size"],
+                                       point_cloud_range=model_info_dict["point_cloud_range"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_point_features"] = m.num_point_features
+        return m, model_info_dict
+
+    def build_vfe(self, model_info_dict):
+        cfg = self.model_cfg.get("VFE", None)
+        if cfg is None:
+            return None, model_info_dict
+        m = vfe.__all__[cfg.NAME](model_cfg=cfg, num_point_features=model_info_dict["num_rawpoint_features"],
+                                  point_cloud_range=model_info_dict["point_cloud_range"], voxel_size=model_info_dict["voxel_size"])
+        model_info_dict["num_point_features"] = m.get_output_feature_dim()
+        model_info_dict["module_list"].append(m)
+        return m, model_info_dict
+
+    def build_map_to_bev_module(self, model_info_dict):
+        cfg = self.model_cfg.get("MAP_TO_BEV", None)
+        if cfg is None:
+            return None, model_info_dict
+        m = map_to_bev.__all__[cfg.NAME](model_cfg=cfg, grid_size=model_info_dict["grid_size"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_bev_features"] = m.num_bev_features
+        return m, model_info_dict
+
+    def build_backbone_2d(self, model_info_dict):
+        cfg = self.model_cfg.get("BACKBONE_2D", None)
+        if cfg is None:
+            return None, model_info_dict
+        m = bev_backbone.__all__[cfg.NAME](model_cfg=cfg, input_channels=model_info_dict["num_bev_features"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_bev_features"] = m.num_bev_features
+        return m, model_info_dict
+
+    def build_dense_head(self, model_info_dict):
+        cfg = self.model_cfg.get("DENSE_HEAD", None)
+        if cfg is None:
+            return None, model_info_dict
+        m = anchor_head.__all__[cfg.NAME](
+            model_cfg=cfg, input_channels=model_info_dict["num_bev_features"],
+            num_class=self.num_class if not cfg.CLASS_AGNOSTIC else 1, class_names=self.class_names,
+            grid_size=model_info_dict["grid_size"], point_cloud_range=model_info_dict["point_cloud_range"],
+            predict_boxes_when_training=self.model_cfg.get("ROI_HEAD", False))
+        model_info_dict["module_list"].append(m)
+        return m, model_info_dict
+
+    def _absent(self, key, model_info_dict):
+        assert self.model_cfg.get(key, None) is None, f"{key} is outside the hvpr hot path"
+        return None, model_info_dict
+
+    def build_pfe(self, model_info_dict):
+        return self._absent("PFE", model_info_dict)
+
+    def build_point_head(self, model_info_dict):
+        return self._absent("POINT_HEAD", model_info_dict)
+
+    def build_roi_head(self, model_info_dict):
+        return self._absent("ROI_HEAD", model_info_dict)
+
+    def forward(self, **kwargs):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------------------------------ post-processing
+    def post_processing(self, batch_dict, sync=True):
+        """detector3d_template.py:168-274, class-agnostic single-head branch, all on device.
+
+        sync=True  -> the reference's return: pred_dicts[i] = {pred_boxes (n,7), pred_scores (n,), pred_labels (n,)}.
+        sync=False -> no host read-back: every tensor is padded to NMS_POST_MAXSIZE rows and pred_count (device i32)
+                      says how many are live (rows past it are copies of anchor 0 and must be ignored).
+        """
+        cfg = self.model_cfg.POST_PROCESSING
+        ncfg = cfg.NMS_CONFIG
+        assert not ncfg.MULTI_CLASSES_NMS, "hvpr path: class-agnostic NMS (hvpr.yaml:144)"
+        B = batch_dict["batch_size"]
+        boxes_all = batch_dict["batch_box_preds"]
+        assert boxes_all.dim() == 3 and boxes_all.shape[0] == B
+        cls_all = batch_dict["batch_cls_preds"]
+        assert cls_all.shape[2] in (1, self.num_class)
+        if "batch_max_scores" in batch_dict:
+            scores, labels = batch_dict["batch_max_scores"], batch_dict["batch_max_labels"]
+        else:
+            c = cls_all if batch_dict["cls_preds_normalized"] else torch.sigmoid(cls_all)
+            scores, lab = torch.max(c, dim=-1)
+            labels = (lab + 1).to(torch.int32)
+        A = scores.shape[1]
+        pre, post = min(int(ncfg.NMS_PRE_MAXSIZE), A), int(ncfg.NMS_POST_MAXSIZE)
+        dev = scores.device
+        if self._post_ws is None or (self._post_ws.batch, self._post_ws.n_scores, self._post_ws.pre_max) != (B, A, pre) \
+                or self._post_ws.topk.device != dev:
+            self._post_ws = kernels.PostWorkspace(B, A, pre, dev)
+        order, _, counts = kernels.score_topk(scores.contiguous(), cfg.SCORE_THRESH, pre, self._post_ws, want_scores=False)
+        pred_dicts, recall_dict = [], {}
+        for b in range(B):
+            keep, kc = kernels.nms_bev(boxes_all[b], order[b], counts[b:b + 1], pre, float(ncfg.NMS_THRESH), post,
+                                       self._post_ws.nms)
+            sel = keep.long()
+            rec = {"pred_boxes": boxes_all[b].index_select(0, sel), "pred_labels": labels[b].index_select(0, sel).long(),
+                   "pred_scores": (cls_all[b].max(dim=-1)[0] if cfg.OUTPUT_RAW_SCORE else scores[b]).index_select(0, sel),
+                   "selected": sel, "pred_count": kc}
+            if sync:
+                n = int(kc.item())
+                rec = {k: (v[:n] if k != "pred_count" else v) for k, v in rec.items()}
+                recall_dict = self.generate_recall_record(rec["pred_boxes"], recall_dict, b, batch_dict, cfg.RECALL_THRESH_LIST)
+            pred_dicts.append(rec)
+        return pred_dicts, recall_dict, batch_dict
+
+    @staticmethod
+    def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+        """detector3d_template.py:276-318 (no ROI head on this path)."""
+        if "gt_boxes" not in data_dict:
+            return recall_dict
+        gt = data_dict["gt_boxes"][batch_index]
+        if len(recall_dict) == 0:
+            recall_dict = {"gt": 0}
+            for t in thresh_list:
+                recall_dict["roi_%s" % str(t)] = 0
+                recall_dict["rcnn_%s" % str(t)] = 0
+        k = len(gt) - 1
+        while k > 0 and gt[k].sum() == 0:
+            k -= 1
+        gt = gt[:k + 1]
+        if gt.shape[0] > 0:
+            iou = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7], gt[:, 0:7]) if box_preds.shape[0] > 0 else \
+                torch.zeros((0, gt.shape[0]), device=gt.device)
+            for t in thresh_list:
+                if iou.shape[0] > 0:
+                    recall_dict["rcnn_%s" % str(t)] += int((iou.max(dim=0)[0] > t).sum().item())
+            recall_dict["gt"] += gt.shape[0]
+        return recall_dict
+
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def load_params_from_file(self, filename, logger=None, to_cpu=False):
+        """detector3d_template.py:320-346: load by key + shape match."""
+        ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None)
+        disk = ckpt["model_state"]
+        state = self.state_dict()
+        update = {k: v for k, v in disk.items() if k in state and state[k].shape == v.shape}
+        state.update(update)
+        self.load_state_dict(state)
+        if logger is not None:
+            for k in state:
+                if k not in update:
+                    logger.info("Not updated weight %s: %s" % (k, str(state[k].shape)))
+            logger.info("==> Done (loaded %d/%d)" % (len(update), len(state)))
+        return len(update), len(state)
+
+
+class _VoxelizingDetector(Detector3DTemplate):
+    """Adds the step the north_star moves on-device: when batch_dict carries raw `points` (N,5) [b,x,y,z,r] and no
+    `voxels`, voxelize on the GPU (replaces the CPU dataloader step data_processor.py:43-75)."""
+
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+        self._voxgen = None
+
+    def _voxel_cfg(self):
+        for p in self.dataset.dataset_cfg.DATA_PROCESSOR:
+            if p.NAME == "transform_points_to_voxels":
+                return p
+        raise KeyError("transform_points_to_voxels")
+
+    def voxelize_on_device(self, batch_dict):
+        pts = batch_dict["points"]
+        B = batch_dict["batch_size"]
+        if self._voxgen is None:
+            vc = self._voxel_cfg()
+            self._voxgen = VoxelGenerator(vc.VOXEL_SIZE, self.dataset.point_cloud_range, vc.MAX_POINTS_PER_VOXEL,
+                                          vc.MAX_NUMBER_OF_VOXELS["train" if self.training else "test"], device=pts.device)
+        offs = batch_dict.get("point_frame_offsets")
+        if offs is None:   # frames are contiguous and ordered (dataset.py:161-166); count per frame on device
+            offs = torch.searchsorted(pts[:, 0].contiguous(), torch.arange(B + 1, device=pts.device, dtype=pts.dtype)).to(torch.int32)
+        v, c, n, vo = self._voxgen.generate_batch(pts, offs, B, xyz_col=1, n_feat=pts.shape[1] - 1)
+        batch_dict["voxels"], batch_dict["voxel_coords"], batch_dict["voxel_num_points"] = v, c, n
+        batch_dict["voxel_offsets"] = vo
+        batch_dict["voxel_count_device"] = vo[B:B + 1]     # live row count, read on device by the next kernels
+        return batch_dict
+
+
+class MixAnchor_Memory(_VoxelizingDetector):
+    """detectors/pointpillar.py:36-68."""
+
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+        self.module_list = self.build_networks()
+
+    def forward(self, batch_dict, sync=True):
+        if self.training:
+            raise NotImplementedError("hvpr_amd: the training step (SURVEY.md §8 a9-a15) is not built yet")
+        if "voxels" not in batch_dict:
+            batch_dict = self.voxelize_on_device(batch_dict)
+        # eval skips the point stream: module_list[1:] in the reference (pointpillar.py:54); here the point stream is
+        # only put in module_list when it exists, so skip it by type
+        for m in self.module_list:
+            if m is getattr(self, "backbone_3d", None):
+                continue
+            batch_dict = m(batch_dict)
+        return self.post_processing(batch_dict, sync=sync)
+
+
+class PointPillar(_VoxelizingDetector):
+    """detectors/pointpillar.py:4-34."""
+
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+        self.module_list = self.build_networks()
+
+    def forward(self, batch_dict, sync=True):
+        if self.training:
+            raise NotImplementedError("hvpr_amd: the training step is not built yet")
+        if "voxels" not in batch_dict:
+            batch_dict = self.voxelize_on_device(batch_dict)
+        for m in self.module_list:
+            batch_dict = m(batch_dict)
+        return self.post_processing(batch_dict, sync=sync)
+
+
+__all__ = {
+    "Detector3DTemplate": Detector3DTemplate,
+    "PointPillar": PointPillar,
+    "MixAnchor_Memory": MixAnchor_Memory,
+}
+
+
+def build_detector(model_cfg, num_class, dataset):
+    """detectors/__init__.py:11-16."""
+    return __all__[model_cfg.NAME](model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+
+
+# ---------------------------------------------------------------------------------------------- pcdet/models/__init__.py
+def build_network(model_cfg, num_class, dataset):
+    return build_detector(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+
+
+def load_data_to_gpu(batch_dict):
+    """Every ndarray except the host-object keys becomes a float32 device tensor."""
+    for k, v in batch_dict.items():
+        if not isinstance(v, np.ndarray) or k in ("frame_id", "metadata", "calib", "image_shape"):
+            continue
+        batch_dict[k] = torch.from_numpy(v).float().cuda()
+
+
+class SyntheticDataset:
+    """The slice of DatasetTemplate the model constructors read (dataset.py:17-40): class names, range, voxel/grid size,
+    point feature count.  Used by tests and bench.py, which have no KITTI files."""
+
+    class _Encoder:
+        def __init__(self, n):
+            self.num_point_features = n
+
+    def __init__(self, cfg, training=False):
+        from .voxel_generator import grid_size_of
+        self.dataset_cfg = cfg.DATA_CONFIG
+        self.class_names = list(cfg.CLASS_NAMES)
+        self.training = training
+        self.point_cloud_range = np.array(self.dataset_cfg.POINT_CLOUD_RANGE, dtype=np.float32)
+        self.point_feature_encoder = self._Encoder(len(self.dataset_cfg.POINT_FEATURE_ENCODING.used_feature_list))
+        vc = [p for p in self.dataset_cfg.DATA_PROCESSOR if p.NAME == "transform_points_to_voxels"][0]
+        self.voxel_size = vc.VOXEL_SIZE
+        self.grid_size = grid_size_of(self.point_cloud_range, self.voxel_size)

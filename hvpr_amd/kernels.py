@@ -26,7 +26,8 @@ def _ptr(t, dtype=None, name="tensor"):
 
 # ------------------------------------------------------------------------------------------------ voxelizer
 class VoxelizeWorkspace:
-    """Persistent device workspace of the voxelizer (two cell maps + per-point scratch)."""
+    """Persistent device workspace of the voxelizer (two cell maps + per-point scratch), sized for up to `batch`
+    frames / `n_points` points per call."""
 
     def __init__(self, batch, n_points, grid, device):
         self.key = (int(batch), int(n_points), tuple(int(g) for g in grid), torch.device(device))
@@ -60,13 +61,14 @@ def voxelize(points, frame_offsets, batch, point_cloud_range, voxel_size, grid, 
     nx, ny, nz = [int(g) for g in grid]
     lo = [float(torch.tensor(v, dtype=torch.float32)) for v in point_cloud_range[:3]]
     vs = [float(torch.tensor(v, dtype=torch.float32)) for v in voxel_size]
-    if (batch, n) != workspace.key[:2] and (workspace.key[0] < batch or workspace.key[1] < n):
+    if workspace.key[0] < batch or workspace.key[1] < n:
         raise ValueError("voxelize workspace too small for this call")
     check(lib().hvpr_voxelize_f32(_ptr(points, torch.float32, "points"), n, stride, xyz_col, n_feat,
                                   _ptr(frame_offsets, torch.int32, "frame_offsets"), batch, lo[0], lo[1], lo[2],
                                   vs[0], vs[1], vs[2], nx, ny, nz, int(max_points), int(max_voxels), int(cap_mode),
                                   voxels.data_ptr(), coords.data_ptr(), num.data_ptr(), offs.data_ptr(), capacity,
-                                  workspace.buf.data_ptr(), workspace.buf.numel(), _stream()), "hvpr_voxelize_f32")
+                                  workspace.buf.data_ptr(), workspace.buf.numel(), workspace.key[0], workspace.key[1],
+                                  _stream()), "hvpr_voxelize_f32")
     return voxels, coords, num, offs
 
 
@@ -254,7 +256,7 @@ def score_topk(scores, score_thresh, pre_max, ws, want_scores=True):
 def nms_bev(boxes, order, n_device, n_max, thresh, max_keep, ws_nms, map_through_order=True):
     """boxes (R, >=7) f32; order (n_max,) i32 or None.  Returns keep (max_keep,) i32, keep_count (1,) i32."""
     dev = boxes.device
-    keep = torch.empty((max(max_keep, 1),), dtype=torch.int32, device=dev)
+    keep = torch.zeros((max(max_keep, 1),), dtype=torch.int32, device=dev)   # rows past keep_count stay valid ids
     kc = torch.empty((1,), dtype=torch.int32, device=dev)
     check(lib().hvpr_nms_bev_f32(_ptr(boxes, torch.float32, "boxes"), boxes.shape[1], _ptr(order, torch.int32),
                                  _ptr(n_device, torch.int32), int(n_max), float(thresh), int(max_keep),

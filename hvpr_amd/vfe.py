@@ -1,0 +1,99 @@
+"""Voxel feature encoders with the reference's plugin interface (pcdet/models/backbones_3d/vfe/):
+same registry keys, constructor kwargs, state-dict names and batch_dict keys; the eval forward is ONE HIP launch
+(hvpr_pillar_vfe_fwd_f32) instead of the reference's chain of PyTorch ops."""
+import torch
+import torch.nn as nn
+
+from . import kernels
+from .folding import FoldCache, bn_scale_shift
+
+
+class VFETemplate(nn.Module):
+    """pcdet/models/backbones_3d/vfe/vfe_template.py:4-22."""
+
+    def __init__(self, model_cfg, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+
+    def get_output_feature_dim(self):
+        raise NotImplementedError
+
+    def forward(self, **kwargs):
+        raise NotImplementedError
+
+
+class PFNLayer(nn.Module):
+    """Parameter holder of one pillar-feature layer (pillar_vfe.py:8-27): `linear` (no bias) + `norm` (eps 1e-3, mom 0.01)."""
+
+    def __init__(self, in_channels, out_channels, use_norm=True, last_layer=False):
+        super().__init__()
+        assert use_norm, "the HIP path is built for USE_NORM: True"
+        self.last_vfe = last_layer
+        width = out_channels if last_layer else out_channels // 2
+        self.linear = nn.Linear(in_channels, width, bias=False)
+        self.norm = nn.BatchNorm1d(width, eps=1e-3, momentum=0.01)
+
+
+def _as_i32(t):
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+class PillarVFE_Scale(VFETemplate):
+    """Pillar encoder + scale stream — pillar_vfe.py:127-221."""
+
+    def __init__(self, model_cfg, num_point_features, voxel_size, point_cloud_range):
+        super().__init__(model_cfg=model_cfg)
+        assert model_cfg.USE_ABSLOTE_XYZ and not model_cfg.WITH_DISTANCE, "HIP VFE: USE_ABSLOTE_XYZ=True, WITH_DISTANCE=False"
+        self.num_filters = list(model_cfg.NUM_FILTERS)
+        self.num_scale_features = list(model_cfg.NUM_SCALE_FEATURES)
+        widths = [num_point_features + 6] + self.num_filters
+        self.pfn_layers = nn.ModuleList(
+            PFNLayer(widths[i], widths[i + 1], model_cfg.USE_NORM, last_layer=(i >= len(widths) - 2))
+            for i in range(len(widths) - 1))
+        sw = [5] + self.num_scale_features
+        self.pfn_scale_layers = nn.ModuleList(
+            nn.Sequential(nn.Linear(sw[i], sw[i + 1], bias=False), nn.BatchNorm1d(sw[i + 1], eps=1e-3, momentum=0.01), nn.ReLU())
+            for i in range(len(sw) - 1))
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.offsets = [self.voxel_size[i] / 2 + float(point_cloud_range[i]) for i in range(3)]
+        self._fold = FoldCache()
+
+    def get_output_feature_dim(self):
+        return self.num_filters[-1]
+
+    def train(self, mode=True):
+        self._fold.invalidate()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._fold.invalidate()
+        return super()._load_from_state_dict(*a, **k)
+
+    def _build_folded(self):
+        f = {}
+        for key, lin, bn in (("0", self.pfn_layers[0].linear, self.pfn_layers[0].norm),
+                             ("1", self.pfn_layers[1].linear, self.pfn_layers[1].norm),
+                             ("s0", self.pfn_scale_layers[0][0], self.pfn_scale_layers[0][1]),
+                             ("s1", self.pfn_scale_layers[1][0], self.pfn_scale_layers[1][1])):
+            s, t = bn_scale_shift(bn)
+            f["w" + key] = (lin.weight.detach().float() * s[:, None]).contiguous()
+            f["b" + key] = t.contiguous()
+        return f
+
+    def forward(self, batch_dict, **kwargs):
+        if self.training:
+            raise NotImplementedError("hvpr_amd: the training forward of PillarVFE_Scale is not built yet (SURVEY.md §8 a9-a15)")
+        voxels, num, coords = batch_dict["voxels"], batch_dict["voxel_num_points"], batch_dict["voxel_coords"]
+        folded = self._fold.get(voxels.device, self._build_folded)
+        pf, sf, mask = kernels.pillar_vfe_fwd(voxels.contiguous(), _as_i32(num), _as_i32(coords).contiguous(), folded,
+                                              self.voxel_size, self.offsets, m_device=batch_dict.get("voxel_count_device"))
+        batch_dict["pillar_features"] = pf
+        batch_dict["pillar_scale_features"] = sf
+        batch_dict["pillar_mask"] = mask
+        return batch_dict
+
+
+__all__ = {
+    "VFETemplate": VFETemplate,
+    "PillarVFE_Scale": PillarVFE_Scale,
+}

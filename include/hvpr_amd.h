@@ -55,15 +55,18 @@ const char *hvpr_status_string(int status);
  *     capacity      rows available in the three outputs; >= sum_b min(N_b, max_voxels) is always enough.
  *     max_points <= 63.
  * ------------------------------------------------------------------------------------------- */
-size_t hvpr_voxelize_workspace_bytes(int batch, int n_points, int nx, int ny, int nz);
-/* one-time (and after any failed call): puts the workspace in its idle state */
-int hvpr_voxelize_workspace_reset(void *workspace, size_t workspace_bytes, int batch, int n_points, int nx, int ny,
+size_t hvpr_voxelize_workspace_bytes(int max_batch, int max_points, int nx, int ny, int nz);
+/* one-time (and after any failed call): puts the workspace in its idle state.  A workspace sized and reset for
+ * (max_batch, max_points) serves every call with batch <= max_batch and n_points <= max_points on the same grid;
+ * each call returns it to idle. */
+int hvpr_voxelize_workspace_reset(void *workspace, size_t workspace_bytes, int max_batch, int max_points, int nx, int ny,
                                   int nz, hvpr_stream_t stream);
 int hvpr_voxelize_f32(const float *points, int n_points, int point_stride, int xyz_col, int n_feat,
                       const int32_t *frame_offsets, int batch, float lo_x, float lo_y, float lo_z, float vs_x,
                       float vs_y, float vs_z, int nx, int ny, int nz, int max_points, int max_voxels, int cap_mode,
                       float *voxels, int32_t *coords, int32_t *num_points, int32_t *voxel_offsets, int capacity,
-                      void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+                      void *workspace, size_t workspace_bytes, int ws_max_batch, int ws_max_points,
+                      hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a2  Pillar VFE, eval mode (BatchNorm folded by the caller).  Replaces

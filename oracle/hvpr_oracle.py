@@ -438,3 +438,79 @@ def post_process_frame(cls_logits, boxes, score_thresh, nms_thresh, pre_maxsize,
     sel, sc = class_agnostic_nms(score.numpy(), np.asarray(boxes), score_thresh, nms_thresh, pre_maxsize, post_maxsize)
     return {"pred_boxes": np.asarray(boxes)[sel], "pred_scores": sc, "pred_labels": (label.numpy()[sel] + 1),
             "selected": sel}
+
+
+# ----------------------------------------------------------------------------------------
+# whole forward path a1 -> a8 for one batch (CPU).  `params` uses the detector's state-dict names
+# (vfe.*, map_to_bev_module.memory.weight, backbone_2d.*, dense_head.*).
+# ----------------------------------------------------------------------------------------
+def _sub(params, prefix):
+    n = len(prefix)
+    return {k[n:]: torch.as_tensor(v, dtype=torch.float32) for k, v in params.items() if k.startswith(prefix)}
+
+
+def forward_frames(frames, params, cfg, stages=None, timings=None):
+    """frames: list of (N_i, 4) float32 arrays.  cfg: dict with point_cloud_range, voxel_size, max_points, max_voxels,
+    k, layer_nums, layer_strides, sfm_layer_nums, upsample_strides, anchor_sizes, anchor_rotations,
+    anchor_bottom_heights, feature_map_stride, dir_offset, dir_limit_offset, num_dir_bins, score_thresh, nms_thresh,
+    nms_pre, nms_post.  Returns (pred_dicts, intermediates)."""
+    import time
+    t0 = time.perf_counter()
+
+    def lap(name):
+        nonlocal t0
+        if timings is not None:
+            t1 = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (t1 - t0)
+            t0 = t1
+
+    rng, vs = cfg["point_cloud_range"], cfg["voxel_size"]
+    grid = grid_size_of(rng, vs)
+    nx, ny = int(grid[0]), int(grid[1])
+    vox, coords, num = [], [], []
+    for b, f in enumerate(frames):
+        v, c, n = voxelize(f, vs, rng, cfg["max_points"], cfg["max_voxels"])
+        vox.append(v); num.append(n)
+        coords.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], axis=1))
+    vox, coords, num = np.concatenate(vox), np.concatenate(coords), np.concatenate(num)
+    lap("voxelize")
+    inter = {"voxels": vox, "voxel_coords": coords, "voxel_num_points": num}
+    pf, sf, _ = pillar_vfe_scale(vox, num.astype(np.float32), coords.astype(np.float32), _sub(params, "vfe."), vs, rng)
+    lap("vfe")
+    inter.update(pillar_features=pf, pillar_scale_features=sf)
+    mem, _, _ = memory_readout_eval(pf, params["map_to_bev_module.memory.weight"], cfg["k"])
+    sp, sc = scatter_eval(pf, mem, sf, coords.astype(np.float32), len(frames), nx, ny)
+    lap("memory_scatter")
+    inter.update(memory_features=mem, spatial_features=sp, spatial_scale_features=sc)
+    f2d = bev_backbone_eval(sp, sc, _sub(params, "backbone_2d."), cfg["layer_nums"], cfg["layer_strides"],
+                            cfg["sfm_layer_nums"], cfg["upsample_strides"])
+    lap("backbone")
+    inter["spatial_features_2d"] = f2d
+    cls, box, dirp = head_forward(f2d, _sub(params, "dense_head."))
+    stride = cfg["feature_map_stride"]
+    anchors = generate_anchors(rng, (nx // stride, ny // stride), cfg["anchor_sizes"], cfg["anchor_rotations"],
+                               cfg["anchor_bottom_heights"])
+    bc, bb = generate_predicted_boxes(cls, box, dirp, anchors, cfg["dir_offset"], cfg["dir_limit_offset"], cfg["num_dir_bins"])
+    lap("head_decode")
+    inter.update(batch_cls_preds=bc, batch_box_preds=bb)
+    preds = [post_process_frame(bc[b].numpy(), bb[b].numpy(), cfg["score_thresh"], cfg["nms_thresh"], cfg["nms_pre"],
+                                cfg["nms_post"]) for b in range(len(frames))]
+    lap("post")
+    return preds, inter
+
+
+def cfg_from_model_cfg(cfg):
+    """Flatten an hvpr yaml (hvpr_amd.config AttrDict) into the dict forward_frames takes."""
+    dp = [p for p in cfg.DATA_CONFIG.DATA_PROCESSOR if p.NAME == "transform_points_to_voxels"][0]
+    m = cfg.MODEL
+    ag = m.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG[0]
+    return dict(point_cloud_range=list(cfg.DATA_CONFIG.POINT_CLOUD_RANGE), voxel_size=list(dp.VOXEL_SIZE),
+                max_points=dp.MAX_POINTS_PER_VOXEL, max_voxels=dp.MAX_NUMBER_OF_VOXELS["test"], k=m.MAP_TO_BEV.NUM_K,
+                layer_nums=list(m.BACKBONE_2D.LAYER_NUMS), layer_strides=list(m.BACKBONE_2D.LAYER_STRIDES),
+                sfm_layer_nums=list(m.BACKBONE_2D.SFM_LAYER_NUMS), upsample_strides=list(m.BACKBONE_2D.UPSAMPLE_STRIDES),
+                anchor_sizes=ag["anchor_sizes"], anchor_rotations=ag["anchor_rotations"],
+                anchor_bottom_heights=ag["anchor_bottom_heights"], feature_map_stride=ag["feature_map_stride"],
+                dir_offset=m.DENSE_HEAD.DIR_OFFSET, dir_limit_offset=m.DENSE_HEAD.DIR_LIMIT_OFFSET,
+                num_dir_bins=m.DENSE_HEAD.NUM_DIR_BINS, score_thresh=m.POST_PROCESSING.SCORE_THRESH,
+                nms_thresh=m.POST_PROCESSING.NMS_CONFIG.NMS_THRESH, nms_pre=m.POST_PROCESSING.NMS_CONFIG.NMS_PRE_MAXSIZE,
+                nms_post=m.POST_PROCESSING.NMS_CONFIG.NMS_POST_MAXSIZE)
