@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the HVPR forward hot path on MI355X (BASELINE.json metric: KITTI frames/sec/GPU, fwd, ~20k pts;
+VFE+scatter achieved HBM GB/s vs peak).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the path a1..a8 (voxelize -> pillar VFE -> memory read-out + scatter -> BEV backbone -> head +
+decode -> score top-k + rotated NMS) over one batch of ONE synthetic frame (tools/cfgs hvpr_car.yaml, batch=1 forward —
+BASELINE.json configs[1]) whose points are already resident in HBM.  Multi-GPU = replicas only: frames are sharded over
+ranks, no data-path collective; value = frames of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with `roofline` (VFE+scatter kernel group, HBM bound — the group BASELINE.json's metric
+names), `roofline_mfma` (BEV backbone + head, fp32 matrix-core bound) and `cpu_baseline` (the CPU oracle timed on this
+box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hvpr_amd import detector, synthetic, synthetic_weights  # noqa: E402
+from hvpr_amd.config import hvpr_car_cfg  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32, exact fp32
+N_POOL = 8                      # distinct frames per rank, cycled
+
+
+def make_batch(frame, device):
+    pts = np.concatenate([np.zeros((len(frame), 1), np.float32), frame], axis=1)
+    return {"points": torch.from_numpy(pts).to(device),
+            "point_frame_offsets": torch.tensor([0, len(frame)], dtype=torch.int32, device=device),
+            "batch_size": 1}
+
+
+def conv_flops(model, H, W):
+    """2*MACs of BaseBEVBackbone_Scale (eval) + the three 1x1 heads (BN / ReLU / gate not counted)."""
+    bb = model.backbone_2d
+    fl = 0
+    h, w = H, W
+    for i, blk in enumerate(bb.blocks):
+        s = bb.layer_strides[i]
+        h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        convs = [m for m in blk if isinstance(m, torch.nn.Conv2d)]
+        for c in convs:
+            fl += 2 * c.in_channels * c.out_channels * 9 * h * w
+        sf = bb.sfmblocks_down[i][0]
+        fl += bb.sfm_layer_nums[i] * 2 * sf.in_channels * sf.out_channels * 9 * h * w
+        sc = bb.scale_layers[i][1]
+        fl += 2 * sc.in_channels * sc.out_channels * 9 * h * w
+        de = bb.deblocks[i][0]
+        fl += 2 * de.in_channels * de.out_channels * (h * w) * int(bb.upsample_strides[i]) ** 2
+    head = model.dense_head
+    for c in (head.conv_cls, head.conv_box, head.conv_dir_cls):
+        fl += 2 * c.in_channels * c.out_channels * H * W
+    return fl
+
+
+def staged_forward(model, bd, ev):
+    """The same forward as MixAnchor_Memory.forward(sync=False) with HIP events between the stage groups (recorded on
+    the stream the kernels are launched on — torch's current stream)."""
+    ev[0].record()
+    bd = model.voxelize_on_device(bd)
+    bd = model.vfe(bd)
+    bd = model.map_to_bev_module(bd)
+    ev[1].record()
+    bd = model.backbone_2d(bd)
+    bd = model.dense_head.forward(bd)
+    ev[2].record()
+    out = model.post_processing(bd, sync=False)
+    ev[3].record()
+    return out
+
+
+def host_cores():
+    """Cores this process may really use: the cgroup CPU quota when there is one (the GPU box shows 256 logical CPUs
+    behind a 16-CPU quota; running 256 torch threads against it is 60x slower than 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(cfg, params, n_timed=5):
+    from oracle import hvpr_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ocfg = O.cfg_from_model_cfg(cfg)
+    frames = [synthetic.hvpr_frame(1000 + i) for i in range(n_timed + 1)]
+    O.forward_frames(frames[:1], params, ocfg)          # warm-up (allocators, oneDNN primitives)
+    timings = {}
+    t0 = time.perf_counter()
+    for f in frames[1:]:
+        O.forward_frames([f], params, ocfg, timings=timings)
+    dt = time.perf_counter() - t0
+    return {"value": n_timed / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_timed} synthetic hvpr_car frames (batch=1, a1..a8) after 1 warm-up frame; torch CPU fp32, "
+                      f"{cores} threads; C voxelizer/NMS",
+            "stage_ms": {k: round(1e3 * v / n_timed, 2) for k, v in timings.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-steps", type=int, default=30, help="extra untimed steps with per-stage HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" IS RCCL on ROCm
+
+    cfg = hvpr_car_cfg()
+    ds = detector.SyntheticDataset(cfg)
+    model = detector.build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    # cls bias -2.0: a few thousand anchors pass SCORE_THRESH so that top-k and NMS do real work (random init with the
+    # reference's -4.6 prior bias would let nothing through)
+    params = synthetic_weights.load_synthetic(model, seed=0, cls_bias=-2.0)
+    model = model.to(device).eval()
+
+    frames = [synthetic.hvpr_frame(rank * 1000 + i) for i in range(N_POOL)]
+    raw_pts = int(np.mean([len(synthetic.kitti_like_frame(rank * 1000 + i)) for i in range(2)]))
+    batches = [make_batch(f, device) for f in frames]
+    n_pts = len(frames[0])
+    nx, ny = int(ds.grid_size[0]), int(ds.grid_size[1])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            model(dict(batches[i % N_POOL]), sync=False)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            model(dict(batches[i % N_POOL]), sync=False)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+
+        # ---- per-stage probe (untimed): HIP events on the launch stream ----
+        stage = np.zeros(3)
+        n_pillars = 0
+        for i in range(args.probe_steps):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            out = staged_forward(model, dict(batches[i % N_POOL]), ev)
+            torch.cuda.synchronize()
+            stage += [ev[k].elapsed_time(ev[k + 1]) for k in range(3)]
+            n_pillars += int(out[2]["voxel_offsets"][-1].item())
+        stage /= max(args.probe_steps, 1)
+        n_pillars /= max(args.probe_steps, 1)
+        kept = int(out[0][0]["pred_count"].item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    fps = world * args.steps / dt
+    # algorithmic bytes of the VFE+scatter group per frame (SURVEY.md §8d / BASELINE.md §6): raw points read once +
+    # dense canvases written once (zeros included) + VFE weights and memory bank read once
+    w_bytes = 4 * (16 * 10 + 16 + 64 * 32 + 64 + 16 * 5 + 16 + 32 * 16 + 32) + 2000 * 64 * 4
+    group_bytes = 16 * n_pts + 4 * (128 + 32) * nx * ny + w_bytes
+    group_s = stage[0] * 1e-3
+    flops = conv_flops(model, ny, nx)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))
+    res = {
+        "metric": "KITTI frames/sec/GPU (fwd, ~20k pts); VFE+scatter achieved HBM GB/s vs peak",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "hvpr_car.yaml batch=1 forward-only, a1..a8 (on-GPU voxelize, pillar VFE, memory read-out + "
+                               "scatter, BEV backbone, head + decode, score top-k + rotated-BEV NMS); frames sharded "
+                               "over ranks, replicas only",
+                   "frame": f"synthetic 64-beam LiDAR, ~{raw_pts} raw points -> range mask -> {n_pts} sampled points, "
+                            f"~{int(n_pillars)} pillars, grid {nx}x{ny}x1", "global_batch": world,
+                   "weights": "deterministic synthetic (seed 0), BN stats randomised, cls bias -2.0",
+                   "nms_candidates_kept": kept},
+        "stage_ms": {"voxelize+vfe+memory+scatter": round(float(stage[0]), 4), "backbone+head+decode": round(float(stage[1]), 4),
+                     "topk+nms": round(float(stage[2]), 4)},
+        "roofline": {"kernel": "VFE+scatter group (4 voxelize launches, pillar VFE, memory read-out, cell map, scatter)",
+                     "bound": "hbm", "achieved": round(group_bytes / group_s / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(group_bytes / group_s / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": group_bytes,
+                     "avg_duration_us": round(group_s * 1e6, 2),
+                     "traffic": None if traffic is None else traffic.get("vfe_scatter_group_bytes")},
+        "roofline_mfma": {"kernel": "BEV backbone + head convolutions (hvpr_conv2d_nhwc_f32, v_mfma_f32_32x32x2_f32)",
+                          "bound": "mfma", "achieved": round(flops / (stage[1] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": round(flops / (stage[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                          "algorithmic_flops": flops, "avg_duration_us": round(float(stage[1]) * 1e3, 1),
+                          "traffic": None if traffic is None else traffic.get("conv_stack_bytes")},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, params)
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

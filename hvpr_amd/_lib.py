@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhvpr_amd.so")
+LIB_PATH = os.environ.get("HVPR_AMD_LIB", os.path.join(_HERE, "libhvpr_amd.so"))   # override: kernel experiments only
 
 _c = ctypes
 _P = _c.c_void_p

@@ -181,7 +181,7 @@ class AnchorHeadSingle(AnchorHeadTemplate):
         w = torch.cat([c.weight.detach().float() for c in convs], dim=0)
         b = torch.cat([c.bias.detach().float() for c in convs], dim=0)
         x, y, table = self._decode_tables(device)
-        return {"pc": kernels.pack_conv(w, None, b, relu=False, tile_cfg=2), "xs": x, "ys": y, "table": table}
+        return {"pc": kernels.pack_conv(w, None, b, relu=False, tile_cfg=1), "xs": x, "ys": y, "table": table}
 
     def forward(self, data_dict):
         if self.training:

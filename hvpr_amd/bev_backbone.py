@@ -43,18 +43,11 @@ def _conv_bn_relu(cin, cout, stride=1, zero_pad=False):
 
 
 def _tile_cfg(h, w, cout_cols):
-    """Pick the workgroup tile so that the launch fills 256 CUs: big tiles on big maps, 64x64 on small ones."""
+    """Workgroup tile of hvpr_conv2d_nhwc_f32.  Measured on MI355X at batch 1 (tools/bench_conv.py): the 64 px x 64 ch
+    tile wins on every hvpr_car layer — the persistent launch balances best with many small tiles; HVPR_CONV_TILE
+    overrides it for experiments."""
     forced = os.environ.get("HVPR_CONV_TILE")
-    if forced is not None:
-        return int(forced)
-    px = h * w
-    if cout_cols < 128:
-        return 2 if px >= 128 * 256 else 1
-    n128 = ((px + 127) // 128) * ((cout_cols + 127) // 128)
-    if n128 >= 512:
-        return 0
-    n_128x64 = ((px + 127) // 128) * ((cout_cols + 63) // 64)
-    return 2 if n_128x64 >= 512 else 1
+    return int(forced) if forced is not None else 1
 
 
 class BaseBEVBackbone_Scale(nn.Module):

@@ -12,10 +12,11 @@
 //
 // Workgroup = 4 waves (2 x 2), tile = (TH x TW) pixels x BN channels; each wave owns MB x NB blocks of 32 x 32.
 // K is walked in chunks of 8 input channels: the (halo) input patch and all taps of the weight slab for the
-// chunk are staged in LDS, the next chunk is prefetched into registers while the current one is multiplied
-// (issue-early / write-late), one LDS buffer.  Operand trick: lane half h reads channels 4h..4h+3 of the chunk
+// chunk are streamed into one of two LDS stages by LDS-DMA while the other stage is multiplied; one barrier per chunk.  Operand trick: lane half h reads channels 4h..4h+3 of the chunk
 // as ONE ds_read_b128 for A and for B and feeds them to four consecutive MFMAs — the MFMA k index is a free
 // permutation as long as A and B agree.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -23,9 +24,29 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC = 8;   // input channels per K chunk
 
+// One LDS-DMA piece: 16 B per lane, global (per-lane address) -> LDS (M0 = wave-uniform base, + lane * 16).
+// Issued through inline asm on purpose: hipcc would otherwise put s_waitcnt vmcnt(0) in front of the next ds_read (it
+// must assume the DMA write aliases it), which serialises the stream behind the multiply.  The wait is placed by hand
+// in front of the per-chunk barrier instead (cdna_hip_programming.md §5.7 recipe).
+// Address form: SGPR base + 32-bit VGPR byte offset.  Everything that changes from chunk to chunk lives in the SGPR base
+// and in M0, so the steady-state loop issues NO vector-ALU instruction: measured on this chip, v_mfma_f32_32x32x2_f32
+// runs on the f32 vector lanes (it is rated at the vector FMA rate), and a co-resident wave that needs VALU slots for
+// address arithmetic is starved for as long as its neighbour multiplies.
+__device__ __forceinline__ void lds_dma16(const void *sbase_uniform, unsigned voff_bytes, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(sbase_uniform), "s"(lds_dst_uniform)
+                 : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+
 struct ConvArgs {
     const float *in;      // [N, H, W, Cin]
-    const float *wpk;     // [TAPS, Cin/8, CoutPad, 8]   (BN scale folded)
+    const float *wpk;     // [TAPS, Cin/8, 2, CoutPad, 4]   (BN scale folded; channel halves split)
     const float *bias;    // [CoutPad]  (gemm column index)
     float *out;           // [N, OH*up, OW*up, out_cstride]
     const float *gate;    // [N, OH, OW] or null
@@ -49,19 +70,31 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     static_assert(MB >= 1 && NB >= 1, "wave tile must hold at least one 32x32 block");
     constexpr int HALO = TAPS == 9 ? 2 : 0;
     constexpr int PH = (TH - 1) * S + 1 + HALO, PW = (TW - 1) * S + 1 + HALO;
-    constexpr int PATCH_V4 = PH * PW * 2;          // float4 per chunk
+    // LDS images (float4 units), both split into two channel-half planes so that a half-wave (32 lanes, same half)
+    // reads 32 consecutive float4 = conflict-free ds_read_b128:
+    //   patch   [half][PPAD]       pixel-major inside a plane
+    //   weights [tap][half][BN]
+    constexpr int PPAD = (PH * PW + 63) / 64 * 64;
+    constexpr int PATCH_V4 = 2 * PPAD;
     constexpr int W_V4 = TAPS * BN * 2;
     constexpr int NLD_P = (PATCH_V4 + 255) / 256, NLD_W = (W_V4 + 255) / 256;
 
-    __shared__ __attribute__((aligned(16))) float4 s_patch[PATCH_V4];
-    __shared__ __attribute__((aligned(16))) float4 s_w[W_V4];
+    // two LDS stages per operand, filled by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass);
+    // padded to whole 1-KiB pieces because a piece always lands wave-uniform base + lane * 16
+    constexpr int PATCH_PAD = NLD_P * 256, W_PAD = NLD_W * 256;
+    __shared__ __attribute__((aligned(16))) float4 s_patch[2][PATCH_PAD];
+    __shared__ __attribute__((aligned(16))) float4 s_w[2][W_PAD];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned wave_s = __builtin_amdgcn_readfirstlane((unsigned)(threadIdx.x >> 6));
     const int wm = wid >> 1, wn = wid & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
-    // workgroup -> (cout tile, pixel tile): cout tile fastest so that an XCD (block id % 8) keeps one weight slab in its L2
-    const int bid = blockIdx.x;
+    // Persistent workgroups: the grid is (resident workgroups per CU) x 256 and workgroup w walks tiles w, w+G, w+2G ...
+    // so that every CU ends up with the same number of tiles (+-1) whatever the dispatcher does after the first wave.
+    // tile -> (cout tile, pixel tile): cout tile fastest, so concurrently running workgroups share input patches.
+    const int total_tiles = a.n_ct * a.tiles_x * a.tiles_y * a.N;
+    for (int bid = blockIdx.x; bid < total_tiles; bid += gridDim.x) {
     const int ct = bid % a.n_ct;
     int pt = bid / a.n_ct;
     const int tx = pt % a.tiles_x; pt /= a.tiles_x;
@@ -72,44 +105,48 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     const int co0 = ct * BN;
 
     // ---- global -> register staging descriptors (constant over the K loop) ----
-    const float *pin[NLD_P];
+    unsigned poff[NLD_P];    // byte offset of this lane's 16 B inside image n (without the chunk term)
     bool pok[NLD_P];
 #pragma unroll
     for (int i = 0; i < NLD_P; ++i) {
         const int v = tid + i * 256;
-        const int pix = v >> 1, part = v & 1;
+        const int part = v / PPAD, pix = v % PPAD;
         const int py = pix / PW, px = pix % PW;
         const int iy = iy0 + py, ix = ix0 + px;
-        pok[i] = v < PATCH_V4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        pin[i] = a.in + (((size_t)n * a.H + (pok[i] ? iy : 0)) * a.W + (pok[i] ? ix : 0)) * a.Cin + part * 4;
+        pok[i] = v < PATCH_V4 && pix < PH * PW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        poff[i] = pok[i] ? (unsigned)((((size_t)iy * a.W + ix) * a.Cin + part * 4) * sizeof(float)) : 0u;
     }
-    const float *pw[NLD_W];
+    unsigned woff[NLD_W];    // byte offset inside the packed weights (without the chunk term)
     bool wok[NLD_W];
     const size_t w_chunk_stride = (size_t)a.cout_pad * KC;                 // floats between cin chunks
     const size_t w_tap_stride = (size_t)(a.Cin / KC) * w_chunk_stride;     // floats between taps
 #pragma unroll
     for (int i = 0; i < NLD_W; ++i) {
-        const int v = tid + i * 256;
+        const int v = tid + i * 256;                                       // = (tap*2 + half)*BN + co_local
         wok[i] = v < W_V4;
-        const int tap = v / (BN * 2), rem = v % (BN * 2);                  // rem = co_local*2 + part
-        pw[i] = a.wpk + (size_t)(wok[i] ? tap : 0) * w_tap_stride + (size_t)co0 * KC + rem * 4;
+        const int th = v / BN, co_l = v % BN;
+        const int tap = th >> 1, hf = th & 1;
+        woff[i] = wok[i] ? (unsigned)(((size_t)tap * w_tap_stride + ((size_t)hf * a.cout_pad + co0 + co_l) * 4) * sizeof(float)) : 0u;
     }
+    const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * a.Cin);   // uniform
+    const unsigned lds_patch0 = lds_addr_of(&s_patch[0][0]) + wave_s * 1024u;    // uniform (wave_s is an SGPR value)
+    const unsigned lds_w0 = lds_addr_of(&s_w[0][0]) + wave_s * 1024u;
 
-    float4 rp[NLD_P], rw[NLD_W];
-    auto issue = [&](int chunk) {
+    auto stage = [&](int chunk, int buf) {
+        const char *pbase = in_n + (size_t)chunk * (KC * sizeof(float));
+        const char *wbase = (const char *)a.wpk + (size_t)chunk * w_chunk_stride * sizeof(float);
 #pragma unroll
         for (int i = 0; i < NLD_P; ++i)
-            rp[i] = pok[i] ? *(const float4 *)(pin[i] + chunk * KC) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * 256) * 16u);
 #pragma unroll
         for (int i = 0; i < NLD_W; ++i)
-            rw[i] = wok[i] ? *(const float4 *)(pw[i] + (size_t)chunk * w_chunk_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wok[i]) lds_dma16(wbase, woff[i], lds_w0 + (unsigned)(buf * W_PAD + i * 256) * 16u);
     };
-    auto commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < NLD_P; ++i) if (tid + i * 256 < PATCH_V4) s_patch[tid + i * 256] = rp[i];
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < NLD_W; ++i) if (tid + i * 256 < W_V4) s_w[tid + i * 256] = rw[i];
-    };
+        for (int i = 0; i < NLD_P; ++i) s_patch[b][tid + i * 256] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
 
     // ---- per-lane LDS read offsets (float4 units) ----
     int a_off[MB];
@@ -117,11 +154,11 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     for (int mb = 0; mb < MB; ++mb) {
         const int q = mb * 32 + l31;
         const int py = wm * (TH / 2) + q / TW, px = q % TW;
-        a_off[mb] = ((py * S) * PW + px * S) * 2 + half;
+        a_off[mb] = half * PPAD + (py * S) * PW + px * S;
     }
     int b_off[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b_off[nb] = (wn * WN + nb * 32 + l31) * 2 + half;
+    for (int nb = 0; nb < NB; ++nb) b_off[nb] = half * BN + wn * WN + nb * 32 + l31;
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -132,35 +169,53 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
     const int n_chunks = a.Cin / KC;
-    issue(0);
-    commit();
-    __syncthreads();
-    for (int c = 0; c < n_chunks; ++c) {
-        if (c + 1 < n_chunks) issue(c + 1);
+    // one chunk: wait for it, let the next one stream into the other stage, multiply.  `buf` is a compile-time constant in
+    // both call sites (the loop is unrolled by two) so that every LDS address is an immediate offset.
+    auto chunk_step = [&](int c, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        // chunk c has landed: this wave's DMA is waited for by hand, the barrier covers the other waves' and also
+        // says that every wave is done reading the other stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
+        const float4 *sp = s_patch[BUF];
+        const float4 *sw = s_w[BUF];
+        // operand ring: LDS reads run PF taps ahead of the MFMAs that consume them (a dependent-accumulator
+        // MFMA chain cannot hide a ds_read issued right before its wait)
+        constexpr int PF = TAPS >= 3 ? 2 : 0;
+        float4 av[PF + 1][MB], bv[PF + 1][NB];
+        auto lds_load = [&](int tap, int slot) {
+            const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[slot][mb] = sp[a_off[mb] + ky * PW + kx];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[slot][nb] = sw[b_off[nb] + tap * BN * 2];
+        };
+#pragma unroll
+        for (int t = 0; t < PF; ++t) lds_load(t, t);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
-            float4 av[MB], bv[NB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[mb] = s_patch[a_off[mb] + (ky * PW + kx) * 2];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bv[nb] = s_w[b_off[nb] + tap * BN * 2];
+            if (tap + PF < TAPS || PF == 0) lds_load(tap + PF < TAPS ? tap + PF : tap, (tap + PF) % (PF + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            const int cur = tap % (PF + 1);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb].x, bv[nb].x, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb].y, bv[nb].y, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb].z, bv[nb].z, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb].w, bv[nb].w, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mb].x, bv[cur][nb].x, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mb].y, bv[cur][nb].y, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mb].z, bv[cur][nb].z, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mb].w, bv[cur][nb].w, acc[mb][nb], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
-        if (c + 1 < n_chunks) {
-            commit();
-            __syncthreads();
-        }
+    };
+    stage(0, 0);
+    for (int c = 0; c + 1 < n_chunks; c += 2) {        // straight-line body: no accumulator shuffling at a join
+        chunk_step(c, std::integral_constant<int, 0>{});
+        chunk_step(c + 1, std::integral_constant<int, 1>{});
     }
+    if (n_chunks & 1) chunk_step(n_chunks - 1, std::integral_constant<int, 0>{});
 
     // ---- epilogue: bias (+ReLU) (+gate * y + residual), NHWC store; C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5) ----
 #pragma unroll
@@ -188,6 +243,8 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
             }
         }
     }
+    __syncthreads();   // the next tile re-zeroes and refills the LDS stages
+    }
 }
 
 template <int TH, int TW, int BN, int S, int TAPS>
@@ -195,7 +252,17 @@ int launch(ConvArgs a, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
     a.n_ct = a.cout_pad / BN;
-    const long long blocks = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
+    const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
+    static int resident = 0;   // workgroups of this instantiation that fit the chip at once
+    if (resident == 0) {
+        int per_cu = 0, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv<TH, TW, BN, S, TAPS>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        resident = per_cu * cus;
+    }
+    const long long blocks = tiles < resident ? tiles : resident;
     hipLaunchKernelGGL((k_conv<TH, TW, BN, S, TAPS>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return 0;
 }

@@ -132,7 +132,7 @@ def scatter_bev_fwd(pillar, memory, scale, coords, batch, nx, ny, workspace, m_d
 
 # ------------------------------------------------------------------------------------------------ convolutions
 class PackedConv:
-    """Weights of one conv layer in the kernel's layout [taps, Cin/8, cout_pad, 8] with BatchNorm folded."""
+    """Weights of one conv layer in the kernel's layout [taps, Cin/8, 2, cout_pad, 4] with BatchNorm folded."""
 
     __slots__ = ("w", "bias", "taps", "stride", "cout", "cout_pad", "up", "cin", "relu", "tile_cfg")
 
@@ -155,10 +155,10 @@ def pack_conv(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=0):
     tc = _tile_channels(tile_cfg)
     cout_pad = (cout + tc - 1) // tc * tc
     taps = kh * kw
-    # (Cout, Cin, kh, kw) -> (taps, Cin/8, Cout, 8)
-    p = w.permute(2, 3, 1, 0).reshape(taps, cin // 8, 8, cout).permute(0, 1, 3, 2)
-    wp = torch.zeros((taps, cin // 8, cout_pad, 8), dtype=torch.float32, device=w.device)
-    wp[:, :, :cout] = p
+    # (Cout, Cin, kh, kw) -> (taps, Cin/8, 2 halves, Cout, 4)
+    p = w.permute(2, 3, 1, 0).reshape(taps, cin // 8, 2, 4, cout).permute(0, 1, 2, 4, 3)
+    wp = torch.zeros((taps, cin // 8, 2, cout_pad, 4), dtype=torch.float32, device=w.device)
+    wp[:, :, :, :cout] = p
     b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
     if shift is not None:
         b[:cout] = shift.detach().float()
@@ -175,9 +175,9 @@ def pack_deconv(weight, scale, shift, relu=True, tile_cfg=0):
     cout_pad = (cols + tc - 1) // tc * tc
     # column = (ky*s + kx)*Cout + co
     g = w.permute(0, 2, 3, 1).reshape(cin, cols)                       # (Cin, cols)
-    p = g.reshape(cin // 8, 8, cols).permute(0, 2, 1).unsqueeze(0)     # (1, Cin/8, cols, 8)
-    wp = torch.zeros((1, cin // 8, cout_pad, 8), dtype=torch.float32, device=w.device)
-    wp[:, :, :cols] = p
+    p = g.reshape(cin // 8, 2, 4, cols).permute(0, 1, 3, 2).unsqueeze(0)     # (1, Cin/8, 2, cols, 4)
+    wp = torch.zeros((1, cin // 8, 2, cout_pad, 4), dtype=torch.float32, device=w.device)
+    wp[:, :, :, :cols] = p
     b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
     b[:cols] = shift.detach().float().repeat(s * s)
     return PackedConv(wp.contiguous(), b, 1, 1, cout, cout_pad, s, cin, relu, tile_cfg)

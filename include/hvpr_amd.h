@@ -121,7 +121,8 @@ int hvpr_scatter_bev_fwd_f32(const float *pillar_features, int c_pillar, const f
  *     AnchorHeadSingle.forward, pcdet/models/dense_heads/anchor_head_single.py:112-121.
  *
  *     in        [N, H, W, Cin] f32 (Cin % 8 == 0)
- *     w_packed  [taps, Cin/8, cout_pad, 8] f32, BatchNorm scale folded in; taps = 9 (3x3, pad 1) or 1 (1x1).
+ *     w_packed  [taps, Cin/8, 2, cout_pad, 4] f32 (input channel = 8*chunk + 4*half + i), BatchNorm scale folded in;
+ *               taps = 9 (3x3, pad 1) or 1 (1x1).
  *               For up > 1 (ConvTranspose2d with kernel == stride == up) taps = 1 and the gemm column is
  *               (ky*up + kx)*cout + co.
  *     bias      [cout_pad] f32 by gemm column (folded BatchNorm shift or the conv bias)
