@@ -82,48 +82,63 @@ __device__ __forceinline__ bool far_apart(const Box &A, const Box &B) {
     return ddx * ddx + ddy * ddy > lim * lim * 1.0001f;
 }
 
-__device__ float box_overlap(const Box &A, const Box &B) {
+// Per-lane polygon scratch in LDS: up to 24 candidate vertices (16 edge crossings + 8 corners), lane-minor so that
+// dynamic indexing is a conflict-free ds access.  (As a private array this spills to scratch memory: 300 B/lane and
+// an order of magnitude slower.)
+struct PolyStore {
+    float x[24][64], y[24][64], a[24][64];
+};
+
+__device__ float box_overlap(const Box &A, const Box &B, PolyStore &ps, int ln) {
     if (far_apart(A, B)) return 0.0f;
-    P2 v[24];
     int cnt = 0;
     P2 ctr = {0.0f, 0.0f};
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
             P2 o;
             if (seg_intersect(A.c[i + 1], A.c[i], B.c[j + 1], B.c[j], o)) {
-                v[cnt] = o; ctr.x += o.x; ctr.y += o.y; ++cnt;
+                ps.x[cnt][ln] = o.x; ps.y[cnt][ln] = o.y; ctr.x += o.x; ctr.y += o.y; ++cnt;
             }
         }
     for (int k = 0; k < 4; ++k) {
-        if (in_box(A, B.c[k])) { ctr.x += B.c[k].x; ctr.y += B.c[k].y; v[cnt++] = B.c[k]; }
-        if (in_box(B, A.c[k])) { ctr.x += A.c[k].x; ctr.y += A.c[k].y; v[cnt++] = A.c[k]; }
+        if (in_box(A, B.c[k])) { ctr.x += B.c[k].x; ctr.y += B.c[k].y; ps.x[cnt][ln] = B.c[k].x; ps.y[cnt][ln] = B.c[k].y; ++cnt; }
+        if (in_box(B, A.c[k])) { ctr.x += A.c[k].x; ctr.y += A.c[k].y; ps.x[cnt][ln] = A.c[k].x; ps.y[cnt][ln] = A.c[k].y; ++cnt; }
     }
     if (cnt == 0) return 0.0f;
     ctr.x /= (float)cnt; ctr.y /= (float)cnt;
+    // bubble sort by polar angle: the angle of a vertex does not change while it is moved around, so it is computed
+    // once per vertex instead of twice per comparison (identical comparisons, identical order)
+    for (int i = 0; i < cnt; ++i) ps.a[i][ln] = atan2f(ps.y[i][ln] - ctr.y, ps.x[i][ln] - ctr.x);
     for (int j = 0; j < cnt - 1; ++j)
         for (int i = 0; i < cnt - j - 1; ++i) {
-            const float ai = atan2f(v[i].y - ctr.y, v[i].x - ctr.x);
-            const float an = atan2f(v[i + 1].y - ctr.y, v[i + 1].x - ctr.x);
-            if (ai > an) { const P2 t = v[i]; v[i] = v[i + 1]; v[i + 1] = t; }
+            const float a0 = ps.a[i][ln], a1 = ps.a[i + 1][ln];
+            if (a0 > a1) {
+                const float tx = ps.x[i][ln], ty = ps.y[i][ln];
+                ps.x[i][ln] = ps.x[i + 1][ln]; ps.y[i][ln] = ps.y[i + 1][ln]; ps.a[i][ln] = a1;
+                ps.x[i + 1][ln] = tx; ps.y[i + 1][ln] = ty; ps.a[i + 1][ln] = a0;
+            }
         }
     float area = 0.0f;
+    const float x0 = ps.x[0][ln], y0 = ps.y[0][ln];
     for (int k = 0; k < cnt - 1; ++k) {
-        const float ux = v[k].x - v[0].x, uy = v[k].y - v[0].y;
-        const float wx = v[k + 1].x - v[0].x, wy = v[k + 1].y - v[0].y;
+        const float ux = ps.x[k][ln] - x0, uy = ps.y[k][ln] - y0;
+        const float wx = ps.x[k + 1][ln] - x0, wy = ps.y[k + 1][ln] - y0;
         area += ux * wy - uy * wx;
     }
     return fabsf(area) / 2.0f;
 }
 
-__device__ __forceinline__ float iou_bev(const Box &A, const Box &B) {
+__device__ __forceinline__ float iou_bev(const Box &A, const Box &B, PolyStore &ps, int ln) {
     const float sa = A.dx * A.dy, sb = B.dx * B.dy;
-    const float so = box_overlap(A, B);
+    const float so = box_overlap(A, B, ps, ln);
     return so / fmaxf(sa + sb - so, kEps);
 }
 
 // ---- pairwise (N,M) kernels: mode 0 overlap, 1 bev iou, 2 3d iou -----------------------------------------
-__global__ void __launch_bounds__(256) k_pairwise(const float *__restrict__ a, int n, const float *__restrict__ b, int m,
-                                                  int mode, float *__restrict__ out) {
+__global__ void __launch_bounds__(64) k_pairwise(const float *__restrict__ a, int n, const float *__restrict__ b, int m,
+                                                 int mode, float *__restrict__ out) {
+    __shared__ PolyStore ps;
+    const int ln = threadIdx.x;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n * m) return;
     const int i = (int)(t / m), j = (int)(t % m);
@@ -132,13 +147,13 @@ __global__ void __launch_bounds__(256) k_pairwise(const float *__restrict__ a, i
     make_box(pa, A);
     make_box(pb, B);
     float r;
-    if (mode == 0) r = box_overlap(A, B);
-    else if (mode == 1) r = iou_bev(A, B);
+    if (mode == 0) r = box_overlap(A, B, ps, ln);
+    else if (mode == 1) r = iou_bev(A, B, ps, ln);
     else {
         const float a_top = pa[2] + pa[5] / 2, a_bot = pa[2] - pa[5] / 2;
         const float b_top = pb[2] + pb[5] / 2, b_bot = pb[2] - pb[5] / 2;
         const float va = pa[3] * pa[4] * pa[5], vb = pb[3] * pb[4] * pb[5];
-        const float ob = box_overlap(A, B);
+        const float ob = box_overlap(A, B, ps, ln);
         const float oh = fmaxf(fminf(a_top, b_top) - fmaxf(a_bot, b_bot), 0.0f);
         const float o3 = ob * oh;
         r = o3 / fmaxf(va + vb - o3, 1e-6f);
@@ -147,9 +162,22 @@ __global__ void __launch_bounds__(256) k_pairwise(const float *__restrict__ a, i
 }
 
 // ---- NMS: bit-mask tiles -------------------------------------------------------------------------------
-// boxes are addressed through `order` (sorted candidate ids, descending score) when it is non-null.
-__global__ void __launch_bounds__(64) k_nms_mask(const float *__restrict__ boxes, int box_stride,
-                                                 const int *__restrict__ order, const int *__restrict__ n_device, int n_max,
+// k_nms_prep: candidate i = boxes[order ? order[i] : i] -> Box (corners + sin/cos computed once per box, not once per tile)
+__global__ void __launch_bounds__(256) k_nms_prep(const float *__restrict__ boxes, int box_stride, const int *__restrict__ order,
+                                                  const int *__restrict__ n_device, int n_max, Box *__restrict__ prepared) {
+    const int n = n_device ? min(*n_device, n_max) : n_max;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Box B;
+    make_box(boxes + (size_t)(order ? order[i] : i) * box_stride, B);
+    prepared[i] = B;
+}
+
+// One wave per 64 x 64 tile.  Phase 1: every lane tests its row box against the 64 column boxes with the exact
+// circum-circle reject only (a few flops).  Phase 2: the surviving (row, col) pairs of the whole tile are compacted into
+// LDS and dealt out to the lanes round-robin, so the expensive polygon clip runs on densely packed lanes instead of
+// 64 divergent column iterations.  Results are identical to testing every pair (the reject is exact).
+__global__ void __launch_bounds__(64) k_nms_mask(const Box *__restrict__ prepared, const int *__restrict__ n_device, int n_max,
                                                  float thresh, unsigned long long *__restrict__ mask, int nb) {
     const int n = n_device ? min(*n_device, n_max) : n_max;
     const int rb = blockIdx.y, cb = blockIdx.x;
@@ -160,18 +188,43 @@ __global__ void __launch_bounds__(64) k_nms_mask(const float *__restrict__ boxes
         if (row < n) mask[(size_t)row * nb + cb] = 0ull;
         return;
     }
-    __shared__ Box s_col[64];
+    __shared__ Box s_row[64], s_col[64];
+    __shared__ unsigned long long s_bits[64];
+    __shared__ unsigned short s_pairs[64 * 64];
+    __shared__ PolyStore ps;
     const int col = cb * 64 + t;
-    if (col < n) make_box(boxes + (size_t)(order ? order[col] : col) * box_stride, s_col[t]);
+    if (row < n) s_row[t] = prepared[row];
+    if (col < n) s_col[t] = prepared[col];
+    s_bits[t] = 0ull;
     __syncthreads();
-    if (row >= n) return;
-    Box R;
-    make_box(boxes + (size_t)(order ? order[row] : row) * box_stride, R);
     const int ncol = min(64, n - cb * 64);
-    unsigned long long bits = 0ull;
-    for (int i = (rb == cb) ? t + 1 : 0; i < ncol; ++i)
-        if (iou_bev(R, s_col[i]) > thresh) bits |= 1ull << i;
-    mask[(size_t)row * nb + cb] = bits;
+    unsigned long long near = 0ull;
+    if (row < n)
+        for (int i = (rb == cb) ? t + 1 : 0; i < ncol; ++i)
+            if (!far_apart(s_row[t], s_col[i])) near |= 1ull << i;
+    // exclusive prefix of the per-lane pair counts
+    const int cnt = __popcll(near);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o, 64);
+        if (t >= o) incl += u;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int pos = incl - cnt;
+    while (near) {
+        const int i = __ffsll((long long)near) - 1;
+        near &= near - 1;
+        s_pairs[pos++] = (unsigned short)((t << 6) | i);
+    }
+    __syncthreads();
+    for (int k = t; k < total; k += 64) {
+        const int pr = s_pairs[k];
+        const int r = pr >> 6, c = pr & 63;
+        if (iou_bev(s_row[r], s_col[c], ps, t) > thresh) atomicOr(&s_bits[r], 1ull << c);
+    }
+    __syncthreads();
+    if (row < n) mask[(size_t)row * nb + cb] = s_bits[t];
 }
 
 // ---- NMS: sequential sweep, one wave ----------------------------------------------------------------------
@@ -246,7 +299,7 @@ extern "C" int hvpr_boxes_pairwise_f32(const float *boxes_a, int n, const float 
     if (n < 0 || m < 0 || mode < 0 || mode > 2) return HVPR_ERR_INVALID_ARG;
     if (n == 0 || m == 0) return HVPR_OK;
     if (!boxes_a || !boxes_b || !out) return HVPR_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_pairwise, dim3(hvpr_cdiv((long long)n * m, 256)), dim3(256), 0, (hipStream_t)stream, boxes_a, n,
+    hipLaunchKernelGGL(k_pairwise, dim3(hvpr_cdiv((long long)n * m, 64)), dim3(64), 0, (hipStream_t)stream, boxes_a, n,
                        boxes_b, m, mode, out);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
@@ -255,7 +308,7 @@ extern "C" int hvpr_boxes_pairwise_f32(const float *boxes_a, int n, const float 
 extern "C" size_t hvpr_nms_workspace_bytes(int n_max) {
     if (n_max < 1) return 0;
     const size_t nb = (n_max + 63) / 64;
-    return (size_t)n_max * nb * sizeof(unsigned long long);
+    return (size_t)n_max * nb * sizeof(unsigned long long) + (size_t)n_max * sizeof(Box) + 256;
 }
 
 extern "C" int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_t *order, const int32_t *n_device,
@@ -272,7 +325,9 @@ extern "C" int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_
     if (workspace_bytes < hvpr_nms_workspace_bytes(n_max)) return HVPR_ERR_WORKSPACE;
     const int nb = (n_max + 63) / 64;
     unsigned long long *mask = (unsigned long long *)workspace;
-    hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, s, boxes, box_stride, order, n_device, n_max, thresh, mask, nb);
+    Box *prepared = (Box *)((char *)workspace + (((size_t)n_max * nb * sizeof(unsigned long long) + 255) / 256) * 256);
+    hipLaunchKernelGGL(k_nms_prep, dim3(hvpr_cdiv(n_max, 256)), dim3(256), 0, s, boxes, box_stride, order, n_device, n_max, prepared);
+    hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, s, prepared, n_device, n_max, thresh, mask, nb);
     hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, nb, n_device, n_max, order, map_through_order, max_keep,
                        keep, keep_count);
     HVPR_CHECK_LAUNCH();

@@ -131,6 +131,62 @@ __global__ void __launch_bounds__(256) k_score_compact(const float *__restrict__
     }
 }
 
+// Pre-selection for large inputs: 16-bit histogram of the orderable score bits (sign + exponent + 7 mantissa bits), then
+// the bin that holds the pre_max-th largest score; only scores in that bin or above are compacted and sorted.
+constexpr int HBINS = 65536;
+__global__ void __launch_bounds__(256) k_score_hist(const float *__restrict__ scores, int A, float thresh, int use_thresh,
+                                                    unsigned *__restrict__ hist) {
+    const int n = blockIdx.y;
+    const float *s = scores + (size_t)n * A;
+    unsigned *h = hist + (size_t)n * HBINS;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A; i += gridDim.x * blockDim.x) {
+        const float v = s[i];
+        const bool pass = use_thresh ? (v >= thresh) : !(v != v);
+        if (pass) atomicAdd(&h[ord_bits(v) >> 16], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_hist_find(const unsigned *__restrict__ hist, int pre_max, unsigned *__restrict__ tbin) {
+    __shared__ unsigned s_sum[1024];
+    const int n = blockIdx.x, t = threadIdx.x;
+    const unsigned *h = hist + (size_t)n * HBINS;
+    unsigned loc = 0;
+    for (int k = 0; k < 64; ++k) loc += h[t * 64 + k];
+    s_sum[t] = loc;
+    __syncthreads();
+    if (t == 0) {
+        unsigned acc = 0;
+        int chunk = 1023;
+        for (; chunk > 0; --chunk) {
+            if (acc + s_sum[chunk] >= (unsigned)pre_max) break;
+            acc += s_sum[chunk];
+        }
+        int b = chunk * 64 + 63;
+        for (; b > chunk * 64; --b) {
+            if (acc + h[b] >= (unsigned)pre_max) break;
+            acc += h[b];
+        }
+        tbin[n] = (unsigned)b;   // every score with bin >= b is a candidate (all of them when fewer than pre_max pass)
+    }
+}
+
+__global__ void __launch_bounds__(256) k_score_compact_bin(const float *__restrict__ scores, int A, float thresh, int use_thresh,
+                                                           const unsigned *__restrict__ tbin, unsigned long long *__restrict__ keys,
+                                                           int *__restrict__ counts) {
+    const int n = blockIdx.y;
+    const float *s = scores + (size_t)n * A;
+    unsigned long long *k = keys + (size_t)n * A;
+    const unsigned tb = tbin[n];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A; i += gridDim.x * blockDim.x) {
+        const float v = s[i];
+        const bool pass = (use_thresh ? (v >= thresh) : !(v != v)) && (ord_bits(v) >> 16) >= tb;
+        if (pass) {
+            const int pos = atomicAdd(&counts[n], 1);
+            k[pos] = ((unsigned long long)ord_bits(v) << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        }
+    }
+}
+
 constexpr int SORTCAP = 8192;
 constexpr int TK_THREADS = 1024;
 
@@ -246,7 +302,8 @@ extern "C" int hvpr_head_decode_f32(const float *head, int N, int H, int W, int 
 
 extern "C" size_t hvpr_score_topk_workspace_bytes(int batch, int n_scores) {
     if (batch < 1 || n_scores < 1) return 0;
-    return (size_t)batch * n_scores * sizeof(unsigned long long) + 256 + (size_t)batch * sizeof(int);
+    return (size_t)batch * n_scores * sizeof(unsigned long long) + 256 + (size_t)batch * (2 * sizeof(int) + 256) +
+           (size_t)batch * HBINS * sizeof(unsigned);
 }
 
 extern "C" int hvpr_score_topk_f32(const float *scores, int batch, int n_scores, float score_thresh, int use_thresh,
@@ -257,11 +314,22 @@ extern "C" int hvpr_score_topk_f32(const float *scores, int batch, int n_scores,
     if (workspace_bytes < hvpr_score_topk_workspace_bytes(batch, n_scores)) return HVPR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *keys = (unsigned long long *)workspace;
-    int *cnt = (int *)((char *)workspace + (((size_t)batch * n_scores * sizeof(unsigned long long) + 255) / 256) * 256);
-    if (hipMemsetAsync(cnt, 0, sizeof(int) * batch, s) != hipSuccess) return HVPR_ERR_LAUNCH;
+    char *tail = (char *)workspace + (((size_t)batch * n_scores * sizeof(unsigned long long) + 255) / 256) * 256;
+    int *cnt = (int *)tail;                                              // [batch]
+    unsigned *tbin = (unsigned *)(tail + ((batch * sizeof(int) + 255) / 256) * 256);   // [batch]
+    unsigned *hist = (unsigned *)((char *)tbin + ((batch * sizeof(unsigned) + 255) / 256) * 256);   // [batch][HBINS], adjacent to cnt/tbin
     int bx = hvpr_cdiv(n_scores, 256 * 4);
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_score_compact, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, keys, cnt);
+    if (n_scores > SORTCAP) {
+        // one memset clears cnt, tbin and the histograms
+        if (hipMemsetAsync(cnt, 0, (size_t)((char *)(hist + (size_t)batch * HBINS) - (char *)cnt), s) != hipSuccess) return HVPR_ERR_LAUNCH;
+        hipLaunchKernelGGL(k_score_hist, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, hist);
+        hipLaunchKernelGGL(k_hist_find, dim3(batch), dim3(1024), 0, s, hist, pre_max, tbin);
+        hipLaunchKernelGGL(k_score_compact_bin, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, tbin, keys, cnt);
+    } else {
+        if (hipMemsetAsync(cnt, 0, sizeof(int) * batch, s) != hipSuccess) return HVPR_ERR_LAUNCH;
+        hipLaunchKernelGGL(k_score_compact, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, keys, cnt);
+    }
     const size_t lds = (size_t)SORTCAP * 8 + 2048 * 4;
     static bool attr_set = false;
     if (!attr_set) {
