@@ -26,7 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hvpr_amd import detector, synthetic, synthetic_weights  # noqa: E402
+from hvpr_amd import detector, distributed, synthetic, synthetic_weights  # noqa: E402
 from hvpr_amd.config import hvpr_car_cfg  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
@@ -121,17 +121,12 @@ def main():
     ap.add_argument("--cls-bias", type=float, default=-4.59511985013459, help="conv_cls.bias of the synthetic weights")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local_rank, world = distributed.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" IS RCCL on ROCm
+    distributed.init("nccl", device)   # "nccl" IS RCCL on ROCm; a no-op at world size 1
 
     cfg = hvpr_car_cfg()
     ds = detector.SyntheticDataset(cfg)
@@ -149,10 +144,7 @@ def main():
     nx, ny = int(ds.grid_size[0]), int(ds.grid_size[1])
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        distributed.barrier(device)
 
     with torch.no_grad():
         for i in range(args.warmup):
@@ -162,11 +154,7 @@ def main():
         for i in range(args.steps):
             model(dict(batches[i % N_POOL]), sync=False)
         barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = distributed.max_over_ranks(time.perf_counter() - t0, device)
 
         # ---- per-stage probe (untimed): HIP events on the launch stream ----
         stage = np.zeros(3)
@@ -183,8 +171,7 @@ def main():
         kept = int(out[0][0]["pred_count"].item()) if args.probe_steps > 0 else -1
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        distributed.finalize()
         return
 
     fps = world * args.steps / dt
@@ -228,8 +215,7 @@ def main():
     else:
         res["cpu_baseline"] = None
     print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    distributed.finalize()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,62 @@
+"""Multi-GPU harness of the inference path: whole frames are sharded over ranks, replicas only — no data-path collective
+(the reference's eval sampler does the same, pcdet/datasets/__init__.py:18-38).  The process group is used
+for the start/stop barriers, the max-over-ranks time and the host-side merge of results (reference: pickle files + two
+barriers, pcdet/utils/common_utils.py:174-195).  Backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None, device=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them)."""
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def shard_frames(n_frames, rank, world):
+    """Frame ids of this rank: rank, rank+world, ... (every frame exactly once over the ranks)."""
+    return list(range(rank, n_frames, world))
+
+
+def barrier(device=None):
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value, device):
+    """Max of a python float over the ranks (the timed region of the slowest rank)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_results(local, rank, world):
+    """Merge per-frame results {frame_id: obj} of all ranks on every rank (host objects)."""
+    if not dist.is_initialized():
+        return dict(local)
+    out = [None] * world
+    dist.all_gather_object(out, local)
+    merged = {}
+    for d in out:
+        merged.update(d)
+    return merged
+
+
+def finalize():
+    if dist.is_initialized():
+        dist.destroy_process_group()
