@@ -146,14 +146,15 @@ __global__ void __launch_bounds__(256) k_score_hist(const float *__restrict__ sc
     }
 }
 
-__global__ void __launch_bounds__(1024) k_hist_find(const unsigned *__restrict__ hist, int pre_max, unsigned *__restrict__ tbin) {
+__global__ void __launch_bounds__(1024) k_hist_find(unsigned *__restrict__ hist, int pre_max, unsigned *__restrict__ tbin) {
     __shared__ unsigned s_sum[1024];
     const int n = blockIdx.x, t = threadIdx.x;
-    const unsigned *h = hist + (size_t)n * HBINS;
+    unsigned *h = hist + (size_t)n * HBINS;
     unsigned loc = 0;
     for (int k = 0; k < 64; ++k) loc += h[t * 64 + k];
     s_sum[t] = loc;
     __syncthreads();
+
     if (t == 0) {
         unsigned acc = 0;
         int chunk = 1023;
@@ -168,6 +169,9 @@ __global__ void __launch_bounds__(1024) k_hist_find(const unsigned *__restrict__
         }
         tbin[n] = (unsigned)b;   // every score with bin >= b is a candidate (all of them when fewer than pre_max pass)
     }
+    __syncthreads();
+    // idle state: the histogram is all-zero between calls (no memset node per frame)
+    for (int k = 0; k < 64; ++k) h[t * 64 + k] = 0u;
 }
 
 __global__ void __launch_bounds__(256) k_score_compact_bin(const float *__restrict__ scores, int A, float thresh, int use_thresh,
@@ -206,7 +210,7 @@ __device__ void lds_bitonic_desc(unsigned long long *s, int n_pow2) {
 }
 
 __global__ void __launch_bounds__(TK_THREADS) k_topk_select(const unsigned long long *__restrict__ keys, int A,
-                                                            const int *__restrict__ counts, int pre_max,
+                                                            int *__restrict__ counts, int pre_max,
                                                             int *__restrict__ order, float *__restrict__ sorted_scores,
                                                             int *__restrict__ out_counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -269,7 +273,10 @@ __global__ void __launch_bounds__(TK_THREADS) k_topk_select(const unsigned long 
         order[(size_t)n * pre_max + i] = (int)(0xffffffffu - (unsigned)(v & 0xffffffffull));
         if (sorted_scores) sorted_scores[(size_t)n * pre_max + i] = unord_bits((unsigned)(v >> 32));
     }
-    if (threadIdx.x == 0) out_counts[n] = take;
+    if (threadIdx.x == 0) {
+        out_counts[n] = take;
+        counts[n] = 0;   // idle state: the candidate counter is zero between calls
+    }
 }
 
 }  // namespace
@@ -320,14 +327,12 @@ extern "C" int hvpr_score_topk_f32(const float *scores, int batch, int n_scores,
     unsigned *hist = (unsigned *)((char *)tbin + ((batch * sizeof(unsigned) + 255) / 256) * 256);   // [batch][HBINS], adjacent to cnt/tbin
     int bx = hvpr_cdiv(n_scores, 256 * 4);
     if (bx > 1024) bx = 1024;
+    // cnt and hist are zero on entry (workspace contract) and are returned to zero by k_hist_find / k_topk_select
     if (n_scores > SORTCAP) {
-        // one memset clears cnt, tbin and the histograms
-        if (hipMemsetAsync(cnt, 0, (size_t)((char *)(hist + (size_t)batch * HBINS) - (char *)cnt), s) != hipSuccess) return HVPR_ERR_LAUNCH;
         hipLaunchKernelGGL(k_score_hist, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, hist);
         hipLaunchKernelGGL(k_hist_find, dim3(batch), dim3(1024), 0, s, hist, pre_max, tbin);
         hipLaunchKernelGGL(k_score_compact_bin, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, tbin, keys, cnt);
     } else {
-        if (hipMemsetAsync(cnt, 0, sizeof(int) * batch, s) != hipSuccess) return HVPR_ERR_LAUNCH;
         hipLaunchKernelGGL(k_score_compact, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, keys, cnt);
     }
     const size_t lds = (size_t)SORTCAP * 8 + 2048 * 4;

@@ -235,7 +235,8 @@ class PostWorkspace:
 
     def __init__(self, batch, n_scores, pre_max, device):
         self.batch, self.n_scores, self.pre_max = batch, n_scores, pre_max
-        self.topk = torch.empty(lib().hvpr_score_topk_workspace_bytes(batch, n_scores), dtype=torch.uint8, device=device)
+        # zero-filled once: every hvpr_score_topk_f32 call leaves its counters and histogram zeroed again
+        self.topk = torch.zeros(lib().hvpr_score_topk_workspace_bytes(batch, n_scores), dtype=torch.uint8, device=device)
         self.nms = torch.empty(lib().hvpr_nms_workspace_bytes(pre_max), dtype=torch.uint8, device=device)
 
 

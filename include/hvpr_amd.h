@@ -165,6 +165,7 @@ int hvpr_head_decode_f32(const float *head, int N, int H, int W, int head_channe
  *     scores [batch, n_scores]; order [batch, pre_max] i32 = ids sorted by (score desc, id asc);
  *     sorted_scores [batch, pre_max] (may be NULL); counts [batch] i32 = min(#passing, pre_max).
  *     use_thresh = 0 keeps every non-NaN score.  pre_max <= 8192.
+ *     workspace: zero-filled by the caller ONCE; every call returns it zero-filled (no per-call memset).
  * ------------------------------------------------------------------------------------------- */
 size_t hvpr_score_topk_workspace_bytes(int batch, int n_scores);
 int hvpr_score_topk_f32(const float *scores, int batch, int n_scores, float score_thresh, int use_thresh, int pre_max,
