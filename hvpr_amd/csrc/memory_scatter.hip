@@ -6,7 +6,7 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// a3  memory read-out.  One workgroup = kPillars pillars; the kPillars x n_items logit rows live in LDS
+// a3  memory read-out.  One workgroup = kPillars pillars; the kPillars x n_items logit rows (fp32 MFMA) live in LDS
 // (never in HBM: the reference materialises M x 2000 floats twice).  Selection per pillar (one wave):
 //   lane-local max of the lane's 32 logits -> 64-lane bitonic sort -> tau = k-th largest lane max, a
 //   lower bound of the k-th largest logit -> the expected ~23 logits >= tau are compacted and sorted
@@ -16,11 +16,33 @@ namespace {
 constexpr int kC = 64;          // feature channels
 constexpr int kPillars = 16;    // pillars per workgroup
 constexpr int kItemsPad = 2048; // logits row length in LDS
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;  // 16 waves: one pillar per wave in the selection phase, 4 waves per SIMD hide the bank stream latency
 
 __device__ __forceinline__ unsigned ord_bits(float v) {
     const unsigned b = __float_as_uint(v);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// k-th largest (k >= 1) of one key per lane: the largest v with count(key >= v) >= k, found bit by bit with ballots —
+// compares and scalar popcounts only, no cross-lane data movement (a 64-lane bitonic sort costs 42 dependent
+// ds_bpermute round trips).  Lanes that do not take part pass key 0.
+__device__ __forceinline__ unsigned wave_kth_largest_u32(unsigned key, int k) {
+    unsigned prefix = 0u;
+#pragma unroll
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        if (__popcll(__ballot(key >= cand)) >= k) prefix = cand;
+    }
+    return prefix;
+}
+__device__ __forceinline__ unsigned long long wave_kth_largest_u64(unsigned long long key, int k) {
+    unsigned long long prefix = 0ull;
+#pragma unroll
+    for (int bit = 63; bit >= 0; --bit) {
+        const unsigned long long cand = prefix | (1ull << bit);
+        if (__popcll(__ballot(key >= cand)) >= k) prefix = cand;
+    }
+    return prefix;
 }
 
 // sort 64 keys descending across the wave
@@ -54,37 +76,85 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
     if (p0 >= M) return;
     const int np = min(kPillars, M - p0);
 
+#ifdef HVPR_EXP_TIMING
+    const long long tt0 = __builtin_readcyclecounter();
+#endif
     for (int i = tid; i < kPillars * kC; i += kThreads) {
         const int p = i / kC;
         s_f[i] = p < np ? f[(size_t)(p0 + p) * kC + (i % kC)] : 0.f;
     }
     __syncthreads();
 
-    // ---- phase 1: logits[p][j] = f[p] . bank[j]  (thread = item, 16 pillars per pass over the row) ----
-    for (int j = tid; j < kItemsPad; j += kThreads) {
-        if (j < n_items) {
-            float4 w[kC / 4];
-            const float4 *row = (const float4 *)(bank + (size_t)j * kC);
+    // ---- phase 1: logits[p][j] = f[p] . bank[j] on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) ----
+    // D (16 items x 16 pillars) = A (items x K) . B (K x pillars), K = 64 channels.  Lane quarter q feeds channels
+    // 16g+4q .. 16g+4q+3 of group g to four consecutive MFMAs from ONE 16-byte load per operand (the MFMA k index is a
+    // free permutation as long as A and B agree).  B (the 16 pillars) stays in registers for the whole kernel; A (the
+    // bank, 512 KB, L2 resident) is streamed 16 items at a time, next tile prefetched while the current one multiplies.
+    {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int l15 = lane & 15, q = lane >> 4;
+        float4 bf[4];
 #pragma unroll
-            for (int c = 0; c < kC / 4; ++c) w[c] = row[c];
-#pragma unroll 4
-            for (int p = 0; p < kPillars; ++p) {
-                const float4 *fp = (const float4 *)(s_f + p * kC);
-                float a = 0.f;
+        for (int g = 0; g < 4; ++g) bf[g] = *(const float4 *)(s_f + l15 * kC + 16 * g + 4 * q);
+        constexpr int kTiles = kItemsPad / 16;
+        constexpr int TI = 2;                       // item tiles in flight per wave: independent accumulator chains
+        constexpr int kWaves = kThreads / 64;
+        auto load_a = [&](int tile, float4 (&a)[4]) {
+            const int item = min(tile * 16 + l15, n_items - 1);
+            const float4 *row = (const float4 *)(bank + (size_t)item * kC + 4 * q);
 #pragma unroll
-                for (int c = 0; c < kC / 4; ++c) {
-                    const float4 x = fp[c];
-                    a = fmaf(w[c].x, x.x, a); a = fmaf(w[c].y, x.y, a);
-                    a = fmaf(w[c].z, x.z, a); a = fmaf(w[c].w, x.w, a);
-                }
-                s_logit[p * kItemsPad + j] = a;
+            for (int g = 0; g < 4; ++g) a[g] = row[4 * g];
+        };
+        // wave w owns super-tiles w, w + kWaves, ...; a super-tile is TI consecutive item tiles
+        float4 a_cur[TI][4], a_nxt[TI][4];
+        // every workgroup streams the whole bank: rotate the start by the workgroup id so that the 200+ workgroups do
+        // not all hit the same L2 channel at the same moment
+        constexpr int kSuper = kTiles / TI;
+        const int rot = (blockIdx.x * 7) % kSuper;
+#pragma unroll
+        for (int u = 0; u < TI; ++u) load_a(((wid + rot) % kSuper) * TI + u, a_cur[u]);
+        for (int sti = wid; sti < kSuper; sti += kWaves) {
+            const int st = (sti + rot) % kSuper;
+            const int nst = (sti + kWaves + rot) % kSuper;
+            if (sti + kWaves < kSuper) {
+#pragma unroll
+                for (int u = 0; u < TI; ++u) load_a(nst * TI + u, a_nxt[u]);
             }
-        } else {
-#pragma unroll 4
-            for (int p = 0; p < kPillars; ++p) s_logit[p * kItemsPad + j] = -INFINITY;
+            f32x4 acc[TI];
+#pragma unroll
+            for (int u = 0; u < TI; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int u = 0; u < TI; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][g].x, bf[g].x, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < TI; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][g].y, bf[g].y, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < TI; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][g].z, bf[g].z, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < TI; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][g].w, bf[g].w, acc[u], 0, 0, 0);
+            }
+            // C/D map of 16x16x4: column (pillar) = lane & 15, row (item) = 4 * (lane >> 4) + reg
+#pragma unroll
+            for (int u = 0; u < TI; ++u) {
+                const int item0 = (st * TI + u) * 16 + 4 * q;
+                float4 o;
+                o.x = item0 + 0 < n_items ? acc[u][0] : -INFINITY;
+                o.y = item0 + 1 < n_items ? acc[u][1] : -INFINITY;
+                o.z = item0 + 2 < n_items ? acc[u][2] : -INFINITY;
+                o.w = item0 + 3 < n_items ? acc[u][3] : -INFINITY;
+                *(float4 *)(s_logit + l15 * kItemsPad + item0) = o;
+            }
+#pragma unroll
+            for (int u = 0; u < TI; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a_cur[u][g] = a_nxt[u][g];
         }
     }
     __syncthreads();
+#ifdef HVPR_EXP_TIMING
+    const long long tt1 = __builtin_readcyclecounter();
+#endif
 
     // ---- phase 2/3: one wave per pillar ----
     unsigned long long *cand = s_cand + wid * 64;
@@ -94,9 +164,8 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         float lmax = -INFINITY;
 #pragma unroll
         for (int t = 0; t < kItemsPad / 64; ++t) { v[t] = row[lane + 64 * t]; lmax = fmaxf(lmax, v[t]); }
-        // tau = k-th largest of the 64 lane maxima
-        const unsigned long long sorted = bitonic64_desc_u64(((unsigned long long)ord_bits(lmax) << 32) | (unsigned)lane, lane);
-        const unsigned tau_bits = __shfl((unsigned)(sorted >> 32), k - 1, 64);
+        // tau = k-th largest of the 64 lane maxima: a lower bound of the k-th largest logit
+        const unsigned tau_bits = wave_kth_largest_u32(ord_bits(lmax), k);
         // compact the candidates (>= tau) into LDS, wave-uniform counter
         int cnt = 0;
 #pragma unroll
@@ -110,13 +179,15 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                 cnt += __popcll(m);
             }
         }
-        unsigned long long key;
+        // the k largest keys (value desc, index asc; keys are unique) end up in lanes [0,k), in no particular order
+        unsigned long long key = 0ull;
+        bool sel;
         if (cnt <= 64) {
             key = lane < cnt ? cand[lane] : 0ull;
-            key = bitonic64_desc_u64(key, lane);
+            const unsigned long long kth = wave_kth_largest_u64(key, min(k, cnt));
+            sel = key != 0ull && key >= kth;
         } else {
             // exact slow path (mass ties): k rounds of wave arg-max with (value desc, index asc) order
-            key = 0ull;
             unsigned long long prev = ~0ull;
             for (int r = 0; r < k; ++r) {
                 unsigned long long best = 0ull;
@@ -136,24 +207,43 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                 if (lane == r) key = best;
                 prev = best;
             }
+            sel = lane < k && key != 0ull;
         }
-        // lanes [0,k): selected (logit, index), descending
-        const bool sel = lane < k && key != 0ull;
+        // move the selected keys to lanes [0, #selected)
+        {
+            const unsigned long long m = __ballot(sel);
+            const int dst = __popcll(m & ((1ull << lane) - 1ull));
+            if (sel) cand[dst] = key;
+            const int nsel = __popcll(m);
+            key = lane < nsel ? cand[lane] : 0ull;
+            sel = lane < nsel;
+        }
         const unsigned ub = (unsigned)(key >> 32);
         const float logit = sel ? __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub) : -INFINITY;
         const int idx = sel ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0;
-        const float mx = hvpr_reduce_max<64>(logit);
+        // softmax over the selected logits, every lane redundantly from readlane broadcasts (no LDS round trips)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(logit), r)));
         const float e = sel ? __expf(logit - mx) : 0.f;
-        const float a = e / hvpr_reduce_sum<64>(e);
+        float esum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) esum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r));
+        const float a = e / esum;
         if (topk_idx && lane < k) topk_idx[(size_t)(p0 + p) * k + lane] = idx;
-        float acc = 0.f;   // lane = channel
-        for (int r = 0; r < k; ++r) {
-            const float ar = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), r));
-            const int ir = __builtin_amdgcn_readlane(idx, r);
-            acc = fmaf(ar, bank[(size_t)ir * kC + lane], acc);
-        }
+        // lane = channel.  All 32 candidate rows are requested before the first is used (lanes >= k carry weight 0 and
+        // row 0), so the gather costs one L2 round trip instead of k dependent ones.
+        float rows[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(idx, r) * kC + lane];
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), r)), rows[r], acc);
         out[(size_t)(p0 + p) * kC + lane] = acc;
     }
+#ifdef HVPR_EXP_TIMING
+    if (blockIdx.x == 3 && lane == 0) printf("readout wave %d: mfma phase %lld cycles, select+gather %lld cycles\n", wid, tt1 - tt0, (long long)__builtin_readcyclecounter() - tt1);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

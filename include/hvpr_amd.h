@@ -91,7 +91,7 @@ int hvpr_pillar_vfe_fwd_f32(const float *voxels, const int32_t *num_points, cons
  * a3  Memory read-out, eval branch.  Replaces MemoryUnit_Agg.forward (eval),
  *     pcdet/models/backbones_2d/map_to_bev/memory_module.py:60-77: logits = f.W^T, top-k items,
  *     softmax over the k selected logits, weighted sum of the k items.
- *     f [M,64], bank [n_items,64] -> out [M,64]; topk_idx [M,k] i32 (may be NULL; descending logit).
+ *     f [M,64], bank [n_items,64] -> out [M,64]; topk_idx [M,k] i32 (may be NULL; the k selected ids, order unspecified).
  *     k <= 32, channels == 64.
  * ------------------------------------------------------------------------------------------- */
 int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t *m_device, const float *bank, int n_items,
