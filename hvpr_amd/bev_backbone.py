@@ -3,6 +3,7 @@ spatial_attention.py): same registry key, ctor kwargs and state-dict names.  The
 on the fp32 matrix cores through hvpr_conv2d_nhwc_f32 with BatchNorm / ReLU / gate / residual fused in the epilogue,
 activations kept NHWC end to end, the gate computed ONCE per level (it depends only on the scale stream,
 base_bev_backbone.py:289-293) and each deconv writing straight into its slice of the 384-channel concat."""
+import contextlib
 import os
 
 import torch
@@ -85,6 +86,13 @@ class BaseBEVBackbone_Scale(nn.Module):
         self.attention = SpatialAttention()
         self._fold = FoldCache()
         self._shape_key = None
+        self._side = None
+        self.overlap_branches = os.environ.get("HVPR_BEV_STREAMS", "2") != "1"
+
+    def _side_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def train(self, mode=True):
         self._fold.invalidate()
@@ -134,22 +142,40 @@ class BaseBEVBackbone_Scale(nn.Module):
         P = self._fold.get(x.device, lambda: self._build_packed(H, W))
         gw, gb, gs, gt = P["gate"]
         gw = gw.to(x.device)
-        out = None
+        us_all = [int(u) for u in self.upsample_strides]
+        # output size of the concat: level-0 resolution after its own stride, times its upsample stride
+        h0 = (H + 2 - 3) // self.layer_strides[0] + 1
+        w0 = (W + 2 - 3) // self.layer_strides[0] + 1
+        out = torch.empty((B, h0 * us_all[0], w0 * us_all[0], self.num_bev_features), dtype=torch.float32, device=x.device)
+        # Two HIP streams: the trunk (blocks of level i+1) does not depend on the attentive branch of level i (scale conv,
+        # gate, the three weight-shared SFM steps and the deconv), so the branch runs on a side stream and fills the
+        # tail of the trunk's launches (at batch 1 the upper levels have fewer tiles than the chip has workgroup slots).
+        main = torch.cuda.current_stream()
+        side = self._side_stream(x.device)
+        two_streams = self.overlap_branches
         coff = 0
+        capturing = torch.cuda.is_current_stream_capturing()
         for i, lv in enumerate(P["levels"]):
             for pc in lv["convs"]:
                 x = kernels.conv2d_nhwc(x, pc)
-            y = kernels.conv2d_nhwc(y, lv["scale"])
-            gate = kernels.spatial_gate(y, gw, gb, gs, gt)
-            x_att = x
-            for _ in range(self.sfm_layer_nums[i]):
-                x_att = kernels.conv2d_nhwc(x_att, lv["sfm"], gate=gate, resid=x_att)
-            us = int(self.upsample_strides[i])
-            if out is None:
-                out = torch.empty((B, x_att.shape[1] * us, x_att.shape[2] * us, self.num_bev_features), dtype=torch.float32,
-                                  device=x.device)
-            kernels.conv2d_nhwc(x_att, lv["deconv"], out=out, out_coff=coff)
+            if two_streams:
+                side.wait_stream(main)          # x (and y of the previous level) are ready for the branch
+                ctx = torch.cuda.stream(side)
+            else:
+                ctx = contextlib.nullcontext()
+            with ctx:
+                y = kernels.conv2d_nhwc(y, lv["scale"])
+                gate = kernels.spatial_gate(y, gw, gb, gs, gt)
+                x_att = x
+                for _ in range(self.sfm_layer_nums[i]):
+                    x_att = kernels.conv2d_nhwc(x_att, lv["sfm"], gate=gate, resid=x_att)
+                kernels.conv2d_nhwc(x_att, lv["deconv"], out=out, out_coff=coff)
+                if two_streams and not capturing:     # eager mode: keep the caching allocator from recycling early
+                    for t in (x, out):
+                        t.record_stream(side)
             coff += self.up_filters[i]
+        if two_streams:
+            main.wait_stream(side)
         data_dict["spatial_features_2d"] = out.permute(0, 3, 1, 2)   # (B, 384, H, W), channels_last
         return data_dict
 

@@ -1,7 +1,8 @@
 """Deterministic synthetic weights for tests and bench.py (no checkpoints can be downloaded here): every parameter and
 BatchNorm statistic is drawn from a numpy Generator keyed by (seed, crc32(parameter name)), so that the GPU model and
 the CPU oracle can be given bit-identical weights without storing 15 M floats.  BatchNorm statistics are non-trivial
-(mean ~ N(0, .5), var ~ U(.5, 2)) so that folding is exercised."""
+(mean ~ N(0, .5), var ~ U(.5, 2)) so that folding is exercised.  The head follows the reference's init_weights():
+conv_box.weight ~ N(0, 0.001) and (by default in bench.py) conv_cls.bias = -log(99)."""
 import zlib
 
 import numpy as np
@@ -17,6 +18,10 @@ def det_tensor(name, shape, seed):
         return rng.normal(0.0, 0.5, shape).astype(np.float32)
     if name.endswith("memory.weight"):
         return rng.uniform(-0.125, 0.125, shape).astype(np.float32)
+    if name.endswith("conv_box.weight"):
+        # the reference's own head initialisation: nn.init.normal_(conv_box.weight, 0, 0.001)
+        # (pcdet/models/dense_heads/anchor_head_single.py:35-38) — decoded boxes stay anchor-sized
+        return rng.normal(0.0, 0.001, shape).astype(np.float32)
     if len(shape) == 1:
         if name.endswith("bias"):
             return rng.normal(0.0, 0.3, shape).astype(np.float32)
