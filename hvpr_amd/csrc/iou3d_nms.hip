@@ -240,9 +240,24 @@ __global__ void __launch_bounds__(64) k_nms_sweep(const unsigned long long *__re
     // remv words: lane w owns word w of chunk (w / 64); n_max <= 64*64*? -> up to NW words per lane
     constexpr int NW = 4;   // supports n <= 64 * 64 * NW = 16384
     unsigned long long remv[NW] = {0ull, 0ull, 0ull, 0ull};
+    // diagonal words of the first 64 blocks are fetched up front (64 independent loads per lane), so the per-block
+    // critical path is the resolve loop plus ONE batch of row loads
+    constexpr int NPRE = 64;
+    unsigned long long dpre[NPRE];
+#pragma unroll
+    for (int b = 0; b < NPRE; ++b) {
+        const int row = b * 64 + lane;
+        dpre[b] = (b < nb && row < n) ? mask[(size_t)row * nb_stride + b] : 0ull;
+    }
     for (int b = 0; b < nb && kept < max_keep; ++b) {
         const int row = b * 64 + lane;
-        const unsigned long long diag = row < n ? mask[(size_t)row * nb_stride + b] : 0ull;
+        unsigned long long diag = 0ull;
+        if (b < NPRE) {
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) if (q == b) diag = dpre[q];
+        } else {
+            diag = row < n ? mask[(size_t)row * nb_stride + b] : 0ull;
+        }
         // remv word of this block (uniform)
         unsigned long long rw = 0ull;
 #pragma unroll
@@ -260,31 +275,35 @@ __global__ void __launch_bounds__(64) k_nms_sweep(const unsigned long long *__re
                 const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffull), i);
                 const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), i);
                 rw |= ((unsigned long long)hi << 32) | lo;
-                if (lane == 0) {
-                    const int pos = b * 64 + i;
-                    keep[kept] = (order && map_through_order) ? order[pos] : pos;
-                }
                 ++kept;
             }
         }
-        // OR the rows of the kept boxes into the later words: four independent coalesced row loads in flight
+        // kept positions of this block -> keep[] (lane i writes its own entry)
+        {
+            const int base = kept - __popcll(kbits);
+            if ((kbits >> lane) & 1ull) {
+                const int pos = b * 64 + lane;
+                keep[base + __popcll(kbits & ((1ull << lane) - 1ull))] = (order && map_through_order) ? order[pos] : pos;
+            }
+        }
+        // OR the rows of the kept boxes into the later words: eight independent coalesced row loads in flight
         unsigned long long kb = kbits;
         while (kb) {
-            int idx4[4];
+            int idx8[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                idx4[u] = kb ? __ffsll((long long)kb) - 1 : -1;
+            for (int u = 0; u < 8; ++u) {
+                idx8[u] = kb ? __ffsll((long long)kb) - 1 : -1;
                 kb &= kb - 1;
             }
 #pragma unroll
             for (int q = 0; q < NW; ++q) {
                 const int w = q * 64 + lane;
                 if (q * 64 < nb && w > b && w < nb) {
-                    unsigned long long t4[4];
+                    unsigned long long t8[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        t4[u] = idx4[u] >= 0 ? mask[(size_t)(b * 64 + idx4[u]) * nb_stride + w] : 0ull;
-                    remv[q] |= (t4[0] | t4[1]) | (t4[2] | t4[3]);
+                    for (int u = 0; u < 8; ++u)
+                        t8[u] = idx8[u] >= 0 ? mask[(size_t)(b * 64 + idx8[u]) * nb_stride + w] : 0ull;
+                    remv[q] |= ((t8[0] | t8[1]) | (t8[2] | t8[3])) | ((t8[4] | t8[5]) | (t8[6] | t8[7]));
                 }
             }
         }

@@ -147,30 +147,43 @@ __global__ void __launch_bounds__(256) k_score_hist(const float *__restrict__ sc
 }
 
 __global__ void __launch_bounds__(1024) k_hist_find(unsigned *__restrict__ hist, int pre_max, unsigned *__restrict__ tbin) {
-    __shared__ unsigned s_sum[1024];
-    const int n = blockIdx.x, t = threadIdx.x;
+    // thread t owns bins [64t, 64t+64); suffix sums over threads (wave shuffles + 16 wave totals) find the owner of the
+    // pre_max-th largest score, which then walks its own 64 bins
+    __shared__ unsigned s_wave[16];
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     unsigned *h = hist + (size_t)n * HBINS;
+    unsigned hv[64];
     unsigned loc = 0;
-    for (int k = 0; k < 64; ++k) loc += h[t * 64 + k];
-    s_sum[t] = loc;
-    __syncthreads();
-
-    if (t == 0) {
-        unsigned acc = 0;
-        int chunk = 1023;
-        for (; chunk > 0; --chunk) {
-            if (acc + s_sum[chunk] >= (unsigned)pre_max) break;
-            acc += s_sum[chunk];
-        }
-        int b = chunk * 64 + 63;
-        for (; b > chunk * 64; --b) {
-            if (acc + h[b] >= (unsigned)pre_max) break;
-            acc += h[b];
-        }
-        tbin[n] = (unsigned)b;   // every score with bin >= b is a candidate (all of them when fewer than pre_max pass)
+#pragma unroll
+    for (int k = 0; k < 64; ++k) { hv[k] = h[t * 64 + k]; loc += hv[k]; }
+    // inclusive suffix sum inside the wave (towards higher lanes)
+    unsigned suf = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += u;
     }
+    if (lane == 0) s_wave[wid] = suf;
     __syncthreads();
+    unsigned above_waves = 0;
+    for (int w = wid + 1; w < 16; ++w) above_waves += s_wave[w];
+    const unsigned incl = suf + above_waves;          // scores in bins >= 64t
+    const unsigned excl = incl - loc;                 // scores in bins >= 64(t+1)
+    unsigned total = 0;
+    for (int w = 0; w < 16; ++w) total += s_wave[w];
+    if (total < (unsigned)pre_max) {
+        if (t == 0) tbin[n] = 0u;                     // fewer than pre_max pass: everything is a candidate
+    } else if (excl < (unsigned)pre_max && incl >= (unsigned)pre_max) {
+        unsigned acc = excl;
+        int b = 63;
+        for (; b > 0; --b) {
+            if (acc + hv[b] >= (unsigned)pre_max) break;
+            acc += hv[b];
+        }
+        tbin[n] = (unsigned)(t * 64 + b);
+    }
     // idle state: the histogram is all-zero between calls (no memset node per frame)
+#pragma unroll
     for (int k = 0; k < 64; ++k) h[t * 64 + k] = 0u;
 }
 
