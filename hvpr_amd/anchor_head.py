@@ -108,6 +108,7 @@ class AnchorHeadTemplate(nn.Module):
         anchors, self.num_anchors_per_location = self.anchor_generator.generate_anchors(self.feature_map_sizes)
         dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")   # reference: `.cuda()` at build
         self.anchors = [a.to(dev) for a in anchors]
+        self.target_assigner = None
         self.forward_ret_dict = {}
 
     def _decode_tables(self, device):
@@ -126,10 +127,32 @@ class AnchorHeadTemplate(nn.Module):
         return x.to(device), y.to(device), torch.tensor(rows, dtype=torch.float32, device=device)
 
     def assign_targets(self, gt_boxes):
-        raise NotImplementedError("hvpr_amd: target assignment (training) is not built yet (SURVEY.md §8 a12)")
+        """anchor_head_template.py:89-99 -> AxisAlignedTargetAssigner (device, no host syncs)."""
+        if self.target_assigner is None:
+            from .target_assigner import AxisAlignedTargetAssigner
+            assert self.model_cfg.TARGET_ASSIGNER_CONFIG.NAME == "AxisAlignedTargetAssigner"
+            self.target_assigner = AxisAlignedTargetAssigner(self.model_cfg, self.class_names, self.box_coder,
+                                                             self.model_cfg.TARGET_ASSIGNER_CONFIG.MATCH_HEIGHT)
+        return self.target_assigner.assign_targets([a.to(gt_boxes.device) for a in self.anchors], gt_boxes)
 
     def get_loss(self):
-        raise NotImplementedError("hvpr_amd: losses (training) are not built yet (SURVEY.md §8 a13)")
+        """anchor_head_template.py:277-291: (rpn_loss, rpn_loss_point, mem_loss, tb_dict, memory items).  tb_dict holds
+        device scalars (the reference calls .item() on each: ~10 host syncs per step)."""
+        from . import losses
+        fr = self.forward_ret_dict
+        w = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        anchors = torch.cat(self.anchors, dim=-3).reshape(-1, 7).to(fr["box_preds"].device)
+        common = dict(labels=fr["box_cls_labels"], reg_targets=fr["box_reg_targets"], anchors=anchors, num_class=self.num_class,
+                      num_anchors_per_loc=self.num_anchors_per_location, cfg_weights=w, dir_offset=self.model_cfg.DIR_OFFSET,
+                      num_dir_bins=self.model_cfg.NUM_DIR_BINS)
+        cls, box, parts = losses.rpn_losses(fr["cls_preds"], fr["box_preds"], fr.get("dir_cls_preds"), **common)
+        cls_p, box_p, parts_p = losses.rpn_losses(fr["cls_preds_point"], fr["box_preds_point"], fr.get("dir_cls_preds_point"), **common)
+        mem = losses.memory_loss(fr["pos_memory_feas"], fr["pos_point_feas"], w["mem_weight"])
+        tb = {"rpn_loss_cls": parts["cls"], "rpn_loss_loc": parts["loc"], "rpn_loss_cls_pt": parts_p["cls"],
+              "rpn_loss_loc_pt": parts_p["loc"], "mem_loss": mem, "rpn_loss": cls + box, "rpn_loss_point": cls_p + box_p}
+        if "dir" in parts:
+            tb["rpn_loss_dir"], tb["rpn_loss_dir_pt"] = parts["dir"], parts_p["dir"]
+        return cls + box, cls_p + box_p, mem, {k: v.detach() for k, v in tb.items()}, fr["memory_items"]
 
     def generate_predicted_boxes(self, batch_size, cls_preds, box_preds, dir_cls_preds=None):
         """torch form of anchor_head_template.py:293-340, kept for callers that hold separate NHWC head outputs."""
@@ -183,9 +206,29 @@ class AnchorHeadSingle(AnchorHeadTemplate):
         x, y, table = self._decode_tables(device)
         return {"pc": kernels.pack_conv(w, None, b, relu=False, tile_cfg=1), "xs": x, "ys": y, "table": table}
 
+    def _forward_train(self, data_dict):
+        """Training forward, anchor_head_single.py:41-108: both streams through the same three 1x1 convs (torch, autograd),
+        targets assigned once."""
+        fr = self.forward_ret_dict
+        for key, suffix in (("spatial_features_2d", ""), ("spatial_features_point_2d", "_point")):
+            f = data_dict[key]
+            fr["cls_preds" + suffix] = self.conv_cls(f).permute(0, 2, 3, 1).contiguous()
+            fr["box_preds" + suffix] = self.conv_box(f).permute(0, 2, 3, 1).contiguous()
+            if self.conv_dir_cls is not None:
+                fr["dir_cls_preds" + suffix] = self.conv_dir_cls(f).permute(0, 2, 3, 1).contiguous()
+        fr["pos_point_feas"] = data_dict["point_positive_features"]
+        fr["pos_memory_feas"] = data_dict["memory_positive_features"]
+        fr["memory_items"] = data_dict["memory_items"]
+        fr.update(self.assign_targets(gt_boxes=data_dict["gt_boxes"]))
+        if self.predict_boxes_when_training:
+            data_dict["batch_cls_preds"], data_dict["batch_box_preds"] = self.generate_predicted_boxes(
+                data_dict["batch_size"], fr["cls_preds"], fr["box_preds"], fr.get("dir_cls_preds"))
+            data_dict["cls_preds_normalized"] = False
+        return data_dict
+
     def forward(self, data_dict):
         if self.training:
-            raise NotImplementedError("hvpr_amd: the training forward of AnchorHeadSingle is not built yet")
+            return self._forward_train(data_dict)
         f2d = data_dict["spatial_features_2d"]
         x = f2d.permute(0, 2, 3, 1).contiguous()
         P = self._fold.get(x.device, lambda: self._build_packed(x.device))

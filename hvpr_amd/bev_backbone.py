@@ -30,6 +30,11 @@ class SpatialAttention(nn.Module):
         super().__init__()
         self.spatial = ConvLayer(2, 1, 3, stride=1, padding=1, use_norm=True, activation=False)
 
+    def forward(self, x, w):
+        """Torch form used by the training forward: gate from the scale stream w, applied to x (spatial_attention.py:57-63)."""
+        pooled = torch.cat((w.max(dim=1, keepdim=True)[0], w.mean(dim=1, keepdim=True)), dim=1)
+        return torch.sigmoid(self.spatial.norm(self.spatial.conv(pooled))) * x
+
     def gate_params(self):
         s, t = bn_scale_shift(self.spatial.norm)
         return (self.spatial.conv.weight.detach().float().reshape(18).contiguous(), float(self.spatial.conv.bias.detach()),
@@ -129,9 +134,27 @@ class BaseBEVBackbone_Scale(nn.Module):
             packed["levels"].append(lv)
         return packed
 
+    def _forward_train(self, data_dict):
+        """Training forward, base_bev_backbone.py:228-279: the memory-fed and the point-fed canvases go through the SAME
+        weights (two streams, shared scale stream); BatchNorm uses batch statistics and every call of a shared BN layer
+        updates its running statistics.  Dense math through torch (MIOpen) with autograd."""
+        x, xp, y = data_dict["spatial_features"], data_dict["spatial_features_point"], data_dict["spatial_scale_features"]
+        ups, ups_p = [], []
+        for i in range(len(self.blocks)):
+            x, xp, y = self.blocks[i](x), self.blocks[i](xp), self.scale_layers[i](y)
+            xa, xpa = x, xp
+            for _ in range(self.sfm_layer_nums[i]):
+                xa = self.attention(self.sfmblocks_down[i](xa), y) + xa
+                xpa = self.attention(self.sfmblocks_down[i](xpa), y) + xpa
+            ups.append(self.deblocks[i](xa))
+            ups_p.append(self.deblocks[i](xpa))
+        data_dict["spatial_features_2d"] = torch.cat(ups, dim=1)
+        data_dict["spatial_features_point_2d"] = torch.cat(ups_p, dim=1)
+        return data_dict
+
     def forward(self, data_dict):
         if self.training:
-            raise NotImplementedError("hvpr_amd: the training forward of BaseBEVBackbone_Scale is not built yet")
+            return self._forward_train(data_dict)
         sp, sc = data_dict["spatial_features"], data_dict["spatial_scale_features"]
         x = sp.permute(0, 2, 3, 1).contiguous()       # no copy when the scatter produced channels_last
         y = sc.permute(0, 2, 3, 1).contiguous()

@@ -5,10 +5,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import anchor_head, bev_backbone, iou3d_nms_utils, kernels, map_to_bev, vfe
+from . import anchor_head, bev_backbone, iou3d_nms_utils, kernels, map_to_bev, pointnet2, vfe
 from .voxel_generator import VoxelGenerator
 
-backbones_3d_all = {}          # PointNet2MSG (training-only point stream) registers here once built
+backbones_3d_all = pointnet2.__all__   # PointNet2MSG: the training-only point stream
 REGISTRY = {
     "backbone_3d": backbones_3d_all,
     "vfe": vfe.__all__,
@@ -261,11 +261,21 @@ class MixAnchor_Memory(_VoxelizingDetector):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
         self.module_list = self.build_networks()
 
+    def get_training_loss(self):
+        """detectors/pointpillar.py:59-68 with the arity decision of SURVEY.md T2: loss = rpn + rpn_point + mem."""
+        rpn, rpn_point, mem, tb_dict, items = self.dense_head.get_loss()
+        loss = rpn + rpn_point + mem
+        tb_dict = {"loss_rpn": rpn.detach(), **tb_dict}
+        return loss, tb_dict, {"items": items}
+
     def forward(self, batch_dict, sync=True):
-        if self.training:
-            raise NotImplementedError("hvpr_amd: the training step (SURVEY.md §8 a9-a15) is not built yet")
         if "voxels" not in batch_dict:
             batch_dict = self.voxelize_on_device(batch_dict)
+        if self.training:
+            for m in self.module_list:            # point stream first (module_topology), then the pillar stream
+                batch_dict = m(batch_dict)
+            loss, tb_dict, disp_dict = self.get_training_loss()
+            return {"loss": loss}, tb_dict, disp_dict
         # eval skips the point stream: module_list[1:] in the reference (pointpillar.py:54); here the point stream is
         # only put in module_list when it exists, so skip it by type
         for m in self.module_list:

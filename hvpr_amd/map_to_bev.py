@@ -7,6 +7,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import kernels
 
@@ -22,13 +23,55 @@ class MemoryUnit_Agg(nn.Module):
         self.weight.data.uniform_(-stdv, stdv)
 
     def forward(self, input1, k, input2=None):
-        """Eval branch (memory_module.py:60-77): returns {'output': (nv, C)}; 'att' is never consumed in eval."""
+        """Eval branch (memory_module.py:60-77): returns {'output': (nv, C)}; 'att' is never consumed in eval.
+        Training branch (:31-59): input2 = the k positive point features of every pillar, (nv, k, C)."""
         if self.training:
-            raise NotImplementedError("hvpr_amd: the training branch of MemoryUnit_Agg is not built yet")
+            return self._forward_train(input1, k, input2)
         return {"output": kernels.memory_readout_fwd(input1.contiguous(), self.weight.detach().contiguous(), k)}
+
+    def _forward_train(self, pillars, k, positives):
+        nv, _, d = positives.shape
+        att = torch.softmax(F.linear(positives.reshape(-1, d), self.weight), dim=1)          # (nv*k, items)
+        if self.shrink_thres > 0:
+            att = hard_shrink_relu(att, self.shrink_thres)
+            att = F.normalize(att, p=1, dim=1)
+        mem = F.linear(att, self.weight.t()).reshape(nv, k, d)                             # read-out per positive
+        agg = torch.softmax((mem * pillars.unsqueeze(1)).sum(dim=2), dim=1)
+        return {"output": (agg.detach().unsqueeze(2) * mem).sum(dim=1), "att": att}
 
     def extra_repr(self):
         return f"mem_dim={self.mem_dim}, fea_dim={self.fea_dim}"
+
+
+def hard_shrink_relu(x, lambd=0.0, epsilon=1e-12):
+    """relu(x - l) * x / (|x - l| + eps) — memory_module.py:85-87."""
+    return (F.relu(x - lambd) * x) / (torch.abs(x - lambd) + epsilon)
+
+
+class _ScatterCanvas(torch.autograd.Function):
+    """Scatter (M,C) rows to a dense NHWC canvas with the HIP gather-form kernel; backward gathers the rows back."""
+
+    @staticmethod
+    def forward(ctx, feats, coords_i32, batch, nx, ny, ws):
+        c = feats.shape[1]
+        if c == 128:
+            sp, _ = kernels.scatter_bev_fwd(feats[:, :64].contiguous(), feats[:, 64:].contiguous(), None, coords_i32, batch, nx, ny, ws)
+        elif c == 64:
+            sp, _ = kernels.scatter_bev_fwd(feats.contiguous(), None, None, coords_i32, batch, nx, ny, ws)
+        else:           # narrower canvas (the 32-channel scale stream): pad to the 64-channel kernel and slice
+            assert c < 64
+            pad = torch.cat([feats, feats.new_zeros(feats.shape[0], 64 - c)], dim=1)
+            sp = kernels.scatter_bev_fwd(pad, None, None, coords_i32, batch, nx, ny, ws)[0][:, :c]
+        rows = (coords_i32[:, 0].long() * ny + coords_i32[:, 2].long()) * nx + coords_i32[:, 3].long()
+        ctx.save_for_backward(rows)
+        ctx.c = c
+        return sp
+
+    @staticmethod
+    def backward(ctx, grad):
+        (rows,) = ctx.saved_tensors
+        g = grad.permute(0, 2, 3, 1).reshape(-1, grad.shape[1])       # NHWC rows (a view when grad is channels_last)
+        return g.index_select(0, rows)[:, :ctx.c].contiguous(), None, None, None, None, None
 
 
 class _ScatterBase(nn.Module):
@@ -84,9 +127,43 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         self.shrink_thres = model_cfg.SHRINK_TH
         self.memory = MemoryUnit_Agg(self.mem_size, self.num_pt_features, self.shrink_thres)
 
+    def get_score(self, points, pillars):
+        """Point <-> pillar attention of one sample (pointpillar_scatter.py:67-83): points (N,C), pillars (M,C).
+        Returns the aggregate (M,C) AND the k positive point features (M,k,C) — the training branch of the memory needs the
+        latter."""
+        score = torch.softmax(points @ pillars.t(), dim=0)                       # (N, M), softmax over points
+        idx = torch.topk(score.detach(), self.k, dim=0)[1]                        # (k, M)
+        positives = points[idx].permute(1, 0, 2)                                  # (M, k, C)
+        w = torch.softmax(torch.bmm(pillars.unsqueeze(1), positives.transpose(1, 2)).squeeze(1), dim=1)
+        return (w.detach().unsqueeze(2) * positives).sum(dim=1), positives
+
+    def _forward_train(self, batch_dict):
+        """Training branch, pointpillar_scatter.py:87-167: three canvases (memory-fed, point-fed, scale)."""
+        pf, sf = batch_dict["pillar_features"], batch_dict["pillar_scale_features"]
+        coords = _coords_i32(batch_dict)
+        point_f, point_c = batch_dict["point_features"], batch_dict["point_coords"]
+        B = _batch_size(batch_dict)
+        pos_point, pos_mem = [], []
+        for b in range(B):
+            m = coords[:, 0] == b
+            pillars = pf[m]
+            agg, positives = self.get_score(point_f[point_c[:, 0] == b], pillars)
+            pos_point.append(agg)
+            pos_mem.append(self.memory(pillars, self.k, positives)["output"])
+        pos_point, pos_mem = torch.cat(pos_point, 0), torch.cat(pos_mem, 0)
+        ws = self._workspace(B, pf.device)
+        args = (coords, B, self.nx, self.ny, ws)
+        batch_dict["spatial_features"] = _ScatterCanvas.apply(torch.cat([pf.detach(), pos_mem], dim=1), *args)
+        batch_dict["spatial_features_point"] = _ScatterCanvas.apply(torch.cat([pf, pos_point], dim=1), *args)
+        batch_dict["spatial_scale_features"] = _ScatterCanvas.apply(sf, *args)
+        batch_dict["point_positive_features"] = pos_point
+        batch_dict["memory_positive_features"] = pos_mem
+        batch_dict["memory_items"] = self.memory.weight
+        return batch_dict
+
     def forward(self, batch_dict, **kwargs):
         if self.training:
-            raise NotImplementedError("hvpr_amd: the training branch of the scatter module is not built yet")
+            return self._forward_train(batch_dict)
         pf, sf = batch_dict["pillar_features"], batch_dict["pillar_scale_features"]
         md = batch_dict.get("voxel_count_device")
         B = _batch_size(batch_dict)

@@ -1,0 +1,182 @@
+"""PointNet++ point stream (training only) with the reference's interfaces:
+
+  * the ops of the absent native package pcdet/ops/pointnet2/pointnet2_batch (setup.py:94-109): index producers run as HIP
+    kernels (furthest point sampling, ball query, three-NN); gathers / interpolation are differentiable torch gathers;
+  * PointnetSAModuleMSG / PointnetFPModule with the constructor kwargs used at
+    pcdet/models/backbones_3d/pointnet2_backbone.py:27-34,43-47 and OpenPCDet's parameter names (mlps.{i}.{j}, mlp.{j});
+  * PointNet2MSG, pcdet/models/backbones_3d/pointnet2_backbone.py:9-95 (registry key of backbones_3d).
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels
+from ._lib import check, lib
+
+
+# ------------------------------------------------------------------------------------------------ index ops (HIP)
+def furthest_point_sample(xyz, npoint):
+    """xyz (B,N,3) f32 cuda -> idx (B,npoint) i32; first pick is index 0, ties -> lowest index."""
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    check(lib().hvpr_furthest_point_sample_f32(kernels._ptr(xyz.contiguous(), torch.float32, "xyz"), B, N, int(npoint),
+                                               idx.data_ptr(), kernels._stream()), "hvpr_furthest_point_sample_f32")
+    return idx
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample) i32 (first nsample within radius, first hit pre-fills)."""
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=xyz.device)
+    check(lib().hvpr_ball_query_f32(kernels._ptr(xyz.contiguous(), torch.float32, "xyz"),
+                                    kernels._ptr(new_xyz.contiguous(), torch.float32, "new_xyz"), B, N, M, float(radius),
+                                    int(nsample), idx.data_ptr(), kernels._stream()), "hvpr_ball_query_f32")
+    return idx
+
+
+def three_nn(unknown, known):
+    """unknown (B,n,3), known (B,m,3) -> dist (B,n,3) ascending, idx (B,n,3) i32."""
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    dist = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
+    idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+    check(lib().hvpr_three_nn_f32(kernels._ptr(unknown.contiguous(), torch.float32, "unknown"),
+                                  kernels._ptr(known.contiguous(), torch.float32, "known"), B, n, m, dist.data_ptr(),
+                                  idx.data_ptr(), kernels._stream()), "hvpr_three_nn_f32")
+    return dist, idx
+
+
+# ------------------------------------------------------------------------------------------------ differentiable gathers
+def gather_operation(features, idx):
+    """features (B,C,N), idx (B,np) -> (B,C,np)."""
+    B, C, _ = features.shape
+    return features.gather(2, idx.long().unsqueeze(1).expand(-1, C, -1))
+
+
+def grouping_operation(features, idx):
+    """features (B,C,N), idx (B,np,ns) -> (B,C,np,ns); backward scatters-adds into (B,C,N)."""
+    B, C, _ = features.shape
+    _, np_, ns = idx.shape
+    flat = idx.long().reshape(B, 1, np_ * ns).expand(-1, C, -1)
+    return features.gather(2, flat).reshape(B, C, np_, ns)
+
+
+def three_interpolate(features, idx, weight):
+    """features (B,C,m), idx (B,n,3), weight (B,n,3) -> (B,C,n)."""
+    B, C, _ = features.shape
+    n = idx.shape[1]
+    g = features.gather(2, idx.long().reshape(B, 1, n * 3).expand(-1, C, -1)).reshape(B, C, n, 3)
+    return (g * weight.unsqueeze(1)).sum(dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------ modules
+class QueryAndGroup(nn.Module):
+    def __init__(self, radius, nsample, use_xyz=True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            return grouped_xyz
+        grouped = grouping_operation(features, idx)
+        return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped   # xyz channels first
+
+
+def _shared_mlp(widths):
+    layers = []
+    for cin, cout in zip(widths[:-1], widths[1:]):
+        layers += [nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+class PointnetSAModuleMSG(nn.Module):
+    """Set abstraction with multi-scale grouping: FPS -> per scale (ball query, group, shared MLP, max over samples) -> concat."""
+
+    def __init__(self, *, npoint, radii, nsamples, mlps, use_xyz=True, bn=True):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.groupers = nn.ModuleList(QueryAndGroup(r, n, use_xyz) for r, n in zip(radii, nsamples))
+        self.mlps = nn.ModuleList()
+        for spec in mlps:
+            spec = list(spec)
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(_shared_mlp(spec))
+
+    def forward(self, xyz, features=None):
+        idx = furthest_point_sample(xyz, self.npoint)
+        new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            f = mlp(grouper(xyz, new_xyz, features))            # (B, C', npoint, nsample)
+            outs.append(f.max(dim=-1)[0])
+        return new_xyz, torch.cat(outs, dim=1)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: inverse-distance interpolation from the 3 nearest known points, concat skip, shared MLP."""
+
+    def __init__(self, *, mlp, bn=True):
+        super().__init__()
+        self.mlp = _shared_mlp(list(mlp))
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        dist, idx = three_nn(unknown, known)
+        w = 1.0 / (dist + 1e-8)
+        w = w / w.sum(dim=2, keepdim=True)
+        f = three_interpolate(known_feats, idx, w)
+        if unknow_feats is not None:
+            f = torch.cat([f, unknow_feats], dim=1)
+        return self.mlp(f.unsqueeze(-1)).squeeze(-1)
+
+
+class PointNet2MSG(nn.Module):
+    """Encoder/decoder producing one feature vector per input point — pointnet2_backbone.py:9-95."""
+
+    def __init__(self, model_cfg, input_channels, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        sa = model_cfg.SA_CONFIG
+        self.SA_modules = nn.ModuleList()
+        cin = input_channels - 3
+        skips = [cin]
+        for k in range(len(sa.NPOINTS)):
+            specs = [[cin] + list(m) for m in sa.MLPS[k]]
+            self.SA_modules.append(PointnetSAModuleMSG(npoint=sa.NPOINTS[k], radii=list(sa.RADIUS[k]), nsamples=list(sa.NSAMPLE[k]),
+                                                       mlps=specs, use_xyz=sa.get("USE_XYZ", True)))
+            cin = sum(s[-1] for s in specs)
+            skips.append(cin)
+        fp = [list(m) for m in model_cfg.FP_MLPS]
+        self.FP_modules = nn.ModuleList()
+        for k in range(len(fp)):
+            pre = fp[k + 1][-1] if k + 1 < len(fp) else cin
+            self.FP_modules.append(PointnetFPModule(mlp=[pre + skips[k]] + fp[k]))
+        self.num_point_features = fp[0][-1]
+
+    def forward(self, batch_dict):
+        B = batch_dict["batch_size"]
+        pts = batch_dict["points"]
+        bidx, xyz, feats = pts[:, 0], pts[:, 1:4].contiguous(), (pts[:, 4:].contiguous() if pts.shape[1] > 4 else None)
+        assert pts.shape[0] % B == 0, "PointNet2MSG needs the same number of points in every sample (pointnet2_backbone.py:76)"
+        xyz = xyz.view(B, -1, 3)
+        feats = feats.view(B, -1, feats.shape[-1]).permute(0, 2, 1).contiguous() if feats is not None else None
+        l_xyz, l_feat = [xyz], [feats]
+        for sa in self.SA_modules:
+            nx, nf = sa(l_xyz[-1], l_feat[-1])
+            l_xyz.append(nx)
+            l_feat.append(nf)
+        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+            l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], l_feat[i])
+        pf = l_feat[0].permute(0, 2, 1).contiguous()
+        batch_dict["point_features"] = pf.view(-1, pf.shape[-1])
+        batch_dict["point_coords"] = torch.cat((bidx[:, None].float(), l_xyz[0].reshape(-1, 3)), dim=1)
+        batch_dict["point_batch_idx"] = bidx
+        return batch_dict
+
+
+__all__ = {
+    "PointNet2MSG": PointNet2MSG,
+}

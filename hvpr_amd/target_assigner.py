@@ -1,0 +1,98 @@
+"""Anchor target assignment on the device, no host round trips.
+
+Restates AxisAlignedTargetAssigner (pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:36-213) with
+boxes3d_nearest_bev_iou (pcdet/utils/box_utils.py:252-323).  The reference trims padded ground-truth rows with a python
+loop over `.sum()` and takes arg-maxes through `.cpu().numpy()` (:53-57,:148,:153); here padding is a mask and everything
+stays vectorised on the GPU.  POS_FRACTION < 0 (no sampling), as hvpr.yaml:122 sets."""
+import numpy as np
+import torch
+
+from .common_utils import limit_period
+
+
+def nearest_bev_boxes(boxes):
+    """(N,7) -> axis-aligned (x1,y1,x2,y2) after snapping the heading to the nearest axis (box_utils.py:297-308)."""
+    rot = limit_period(boxes[:, 6], 0.5, np.pi).abs()
+    dims = torch.where(rot[:, None] < np.pi / 4, boxes[:, [3, 4]], boxes[:, [4, 3]])
+    return torch.cat((boxes[:, 0:2] - dims / 2, boxes[:, 0:2] + dims / 2), dim=1)
+
+
+def iou_axis_aligned(a, b):
+    """(N,4) x (M,4) -> (N,M) (box_utils.py:252-272)."""
+    xl = torch.max(a[:, 0, None], b[None, :, 0])
+    xr = torch.min(a[:, 2, None], b[None, :, 2])
+    yl = torch.max(a[:, 1, None], b[None, :, 1])
+    yr = torch.min(a[:, 3, None], b[None, :, 3])
+    inter = torch.clamp_min(xr - xl, 0) * torch.clamp_min(yr - yl, 0)
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / torch.clamp_min(area_a[:, None] + area_b[None, :] - inter, 1e-6)
+
+
+def boxes3d_nearest_bev_iou(boxes_a, boxes_b):
+    return iou_axis_aligned(nearest_bev_boxes(boxes_a), nearest_bev_boxes(boxes_b))
+
+
+class AxisAlignedTargetAssigner:
+    def __init__(self, model_cfg, class_names, box_coder, match_height=False):
+        assert not match_height, "hvpr path: MATCH_HEIGHT False (hvpr.yaml:124)"
+        acfg = model_cfg.ANCHOR_GENERATOR_CONFIG
+        tcfg = model_cfg.TARGET_ASSIGNER_CONFIG
+        assert tcfg.POS_FRACTION < 0, "hvpr path: no fg/bg sampling (hvpr.yaml:122)"
+        self.box_coder = box_coder
+        self.class_names = list(class_names)
+        self.anchor_class_names = [c["class_name"] for c in acfg]
+        self.matched = {c["class_name"]: c["matched_threshold"] for c in acfg}
+        self.unmatched = {c["class_name"]: c["unmatched_threshold"] for c in acfg}
+        self.norm_by_num_examples = tcfg.NORM_BY_NUM_EXAMPLES
+
+    def assign_targets(self, all_anchors, gt_boxes_with_classes):
+        """all_anchors: list of (nz,ny,nx,1,R,7); gt (B,G,8).  Returns box_cls_labels (B,A) i32, box_reg_targets (B,A,7),
+        reg_weights (B,A), anchors ordered (z,y,x,class,rot) as the single head predicts them."""
+        B = gt_boxes_with_classes.shape[0]
+        labels, targets, weights = [], [], []
+        for b in range(B):
+            gt = gt_boxes_with_classes[b]
+            G = gt.shape[0]
+            nz = gt.abs().sum(dim=1) != 0
+            ar = torch.arange(G, device=gt.device)
+            last = torch.where(nz, ar, torch.zeros_like(ar)).max()          # trailing zero rows are padding (:53-57)
+            valid = ar <= last
+            gcls = gt[:, -1].int()
+            per_class = []
+            for cname, anchors in zip(self.anchor_class_names, all_anchors):
+                fms = anchors.shape[:3]
+                a = anchors.reshape(-1, anchors.shape[-1])
+                name_idx = torch.tensor([self.class_names.index(cname)], device=gt.device)
+                # python-style class_names[c - 1]: class 0 (a padded row inside the valid range) wraps to the last class
+                same = torch.remainder(gcls - 1, len(self.class_names)) == name_idx
+                lab, tgt, w = self._assign_single(a, gt[:, :-1], gcls, valid & same, self.matched[cname], self.unmatched[cname])
+                per_class.append((lab.view(*fms, -1), tgt.view(*fms, -1, self.box_coder.code_size), w.view(*fms, -1)))
+            labels.append(torch.cat([p[0] for p in per_class], dim=-1).reshape(-1))
+            targets.append(torch.cat([p[1] for p in per_class], dim=-2).reshape(-1, self.box_coder.code_size))
+            weights.append(torch.cat([p[2] for p in per_class], dim=-1).reshape(-1))
+        return {"box_cls_labels": torch.stack(labels), "box_reg_targets": torch.stack(targets), "reg_weights": torch.stack(weights)}
+
+    def _assign_single(self, anchors, gt, gt_classes, use, matched_thr, unmatched_thr):
+        A = anchors.shape[0]
+        iou = boxes3d_nearest_bev_iou(anchors[:, 0:7], gt[:, 0:7])
+        iou = torch.where(use[None, :], iou, torch.full_like(iou, -2.0))            # masked ground truths never match
+        a2g_max, a2g_arg = iou.max(dim=1)
+        g2a_max = iou.max(dim=0)[0]
+        g2a_max = torch.where(g2a_max <= 0, torch.full_like(g2a_max, -1.0), g2a_max)   # no overlap at all: no forced match (:155-156)
+        force = (iou == g2a_max[None, :]).any(dim=1)                               # best anchor(s) of every ground truth (:158-161)
+        cls_of = gt_classes[a2g_arg]
+        labels = torch.full((A,), -1, dtype=torch.int32, device=anchors.device)
+        labels = torch.where(force, cls_of, labels)
+        labels = torch.where(a2g_max >= matched_thr, cls_of, labels)
+        labels = torch.where(a2g_max < unmatched_thr, torch.zeros_like(labels), labels)   # background ...
+        labels = torch.where(force, cls_of, labels)                                       # ... but forced matches win (:186-190)
+        fg = labels > 0
+        enc = self.box_coder.encode_torch(gt[a2g_arg][:, :7].clone(), anchors[:, :7].clone())
+        targets = torch.where(fg[:, None], enc, torch.zeros_like(enc))
+        if self.norm_by_num_examples:
+            n = torch.clamp((labels >= 0).sum().float(), min=1.0)
+            w = fg.float() / n
+        else:
+            w = fg.float()
+        return labels, targets, w

@@ -81,9 +81,9 @@ class PillarVFE_Scale(VFETemplate):
         return f
 
     def forward(self, batch_dict, **kwargs):
-        if self.training:
-            raise NotImplementedError("hvpr_amd: the training forward of PillarVFE_Scale is not built yet (SURVEY.md §8 a9-a15)")
         voxels, num, coords = batch_dict["voxels"], batch_dict["voxel_num_points"], batch_dict["voxel_coords"]
+        if self.training:
+            return self._forward_train(batch_dict, voxels, num, coords)
         folded = self._fold.get(voxels.device, self._build_folded)
         pf, sf, mask = kernels.pillar_vfe_fwd(voxels.contiguous(), _as_i32(num), _as_i32(coords).contiguous(), folded,
                                               self.voxel_size, self.offsets, m_device=batch_dict.get("voxel_count_device"))
@@ -91,6 +91,43 @@ class PillarVFE_Scale(VFETemplate):
         batch_dict["pillar_scale_features"] = sf
         batch_dict["pillar_mask"] = mask
         return batch_dict
+
+
+def _train_forward(self, batch_dict, voxels, num, coords):
+    """Training forward with batch-statistics BatchNorm and autograd (dense math through torch): the same decoration,
+    masking, two PFN layers and scale stream as the eval kernel (pillar_vfe.py:184-221; BN over all M*P slots, padded
+    slots included — SURVEY.md B.5)."""
+    md = batch_dict.get("voxel_count_device")
+    if md is not None:                      # rows past the live count are unspecified: drop them (one host read per step)
+        m = int(md.item())
+        voxels, num, coords = voxels[:m], num[:m], coords[:m]
+        batch_dict["voxels"], batch_dict["voxel_num_points"], batch_dict["voxel_coords"] = voxels, num, coords
+        batch_dict["voxel_count_device"] = None
+    n = num.to(voxels.dtype)
+    c = coords.to(voxels.dtype)
+    M, P, _ = voxels.shape
+    xyz = voxels[:, :, :3]
+    mean = xyz.sum(dim=1, keepdim=True) / n.view(-1, 1, 1)
+    vs = voxels.new_tensor(self.voxel_size)
+    off = voxels.new_tensor(self.offsets)
+    centre = c[:, [3, 2, 1]] * vs + off                                  # (M,3) pillar centre in x,y,z
+    mask = (torch.arange(P, device=voxels.device).view(1, -1) < num.view(-1, 1)).unsqueeze(-1).to(voxels.dtype)
+    x = torch.cat([voxels, xyz - mean, xyz - centre.unsqueeze(1)], dim=-1) * mask
+    for layer in self.pfn_layers:
+        y = layer.linear(x)
+        y = torch.relu(layer.norm(y.permute(0, 2, 1)).permute(0, 2, 1))
+        ymax = y.max(dim=1, keepdim=True)[0]
+        x = ymax if layer.last_vfe else torch.cat([y, ymax.expand(-1, P, -1)], dim=2)
+    s = torch.cat([n.unsqueeze(1), torch.norm(mean, 2, 2), mean.squeeze(1)], dim=-1)
+    for seq in self.pfn_scale_layers:
+        s = seq(s)
+    batch_dict["pillar_features"] = x.reshape(M, -1)
+    batch_dict["pillar_scale_features"] = s
+    batch_dict["pillar_mask"] = mask
+    return batch_dict
+
+
+PillarVFE_Scale._forward_train = _train_forward
 
 
 __all__ = {

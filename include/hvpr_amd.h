@@ -189,6 +189,21 @@ int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_t *order, c
 int hvpr_boxes_pairwise_f32(const float *boxes_a, int n, const float *boxes_b, int m, int mode, float *out,
                             hvpr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a9 (training)  PointNet++ index ops.  Replace the absent natives of pcdet/ops/pointnet2/pointnet2_batch (setup.py:94-109)
+ *     behind PointnetSAModuleMSG / PointnetFPModule (pcdet/models/backbones_3d/pointnet2_backbone.py:27-34,43-47,82,86-89).
+ *     Indices only (no gradient); tie rule: lowest index.  Distances are fp32 (dx*dx + dy*dy) + dz*dz.
+ *     hvpr_furthest_point_sample_f32: xyz [B,N,3] -> idx [B,npoint] i32, first pick = index 0, N <= 32768.
+ *     hvpr_ball_query_f32: first nsample points (index order) with d2 < radius^2; the first hit pre-fills all slots; zeros
+ *                          when there is none.  xyz [B,N,3], new_xyz [B,M,3] -> idx [B,M,nsample] i32.
+ *     hvpr_three_nn_f32:   unknown [B,n,3], known [B,m,3] -> dist [B,n,3] (sqrt of d2, ascending), idx [B,n,3] i32.
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_furthest_point_sample_f32(const float *xyz, int B, int N, int npoint, int32_t *idx, hvpr_stream_t stream);
+int hvpr_ball_query_f32(const float *xyz, const float *new_xyz, int B, int N, int M, float radius, int nsample, int32_t *idx,
+                        hvpr_stream_t stream);
+int hvpr_three_nn_f32(const float *unknown, const float *known, int B, int n, int m, float *dist, int32_t *idx,
+                      hvpr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

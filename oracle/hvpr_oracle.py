@@ -514,3 +514,56 @@ def cfg_from_model_cfg(cfg):
                 num_dir_bins=m.DENSE_HEAD.NUM_DIR_BINS, score_thresh=m.POST_PROCESSING.SCORE_THRESH,
                 nms_thresh=m.POST_PROCESSING.NMS_CONFIG.NMS_THRESH, nms_pre=m.POST_PROCESSING.NMS_CONFIG.NMS_PRE_MAXSIZE,
                 nms_post=m.POST_PROCESSING.NMS_CONFIG.NMS_POST_MAXSIZE)
+
+
+# ----------------------------------------------------------------------------------------
+# a9 (training)  PointNet++ index ops — pcdet/ops/pointnet2/pointnet2_batch (ABSENT from the reference,
+# setup.py:94-109; restated from SURVEY.md Appendix B.4).  PARITY UNPINNED.  fp32 distances computed as
+# (dx*dx + dy*dy) + dz*dz; ties resolve to the lowest index (the build's defined rule).
+# ----------------------------------------------------------------------------------------
+def _d2(a, b):
+    d = (a - b).astype(np.float32)
+    return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]).astype(np.float32) + d[..., 2] * d[..., 2]
+
+
+def furthest_point_sample(xyz, npoint):
+    """xyz (B,N,3) -> idx (B,npoint) int32; first pick index 0, running min distance initialised to 1e10."""
+    xyz = _f32(xyz)
+    B, N, _ = xyz.shape
+    out = np.zeros((B, npoint), np.int32)
+    for b in range(B):
+        md = np.full((N,), 1e10, np.float32)
+        last = 0
+        for j in range(1, npoint):
+            md = np.minimum(md, _d2(xyz[b], xyz[b, last]))
+            last = int(np.argmax(md))          # numpy argmax returns the first (lowest-index) maximum
+            out[b, j] = last
+    return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, M, _ = new_xyz.shape
+    r2 = np.float32(radius) * np.float32(radius)
+    out = np.zeros((B, M, nsample), np.int32)
+    for b in range(B):
+        for m in range(M):
+            hits = np.nonzero(_d2(xyz[b], new_xyz[b, m]) < r2)[0][:nsample]
+            if hits.size:
+                out[b, m, :] = hits[0]
+                out[b, m, :hits.size] = hits
+    return out
+
+
+def three_nn(unknown, known):
+    unknown, known = _f32(unknown), _f32(known)
+    B, n, _ = unknown.shape
+    dist = np.zeros((B, n, 3), np.float32)
+    idx = np.zeros((B, n, 3), np.int32)
+    for b in range(B):
+        for i in range(n):
+            d = _d2(known[b], unknown[b, i])
+            order = np.argsort(d, kind="stable")[:3]
+            idx[b, i] = order
+            dist[b, i] = np.sqrt(d[order])
+    return dist, idx

@@ -322,6 +322,108 @@ def math_pi():
     return float(np.pi)
 
 
+def _head_cfg(stride=1):
+    return EasyDict(
+        CLASS_AGNOSTIC=False, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
+        ANCHOR_GENERATOR_CONFIG=[dict(class_name="Car", anchor_sizes=[[3.9, 1.6, 1.56]], anchor_rotations=[0, 1.57],
+                                      anchor_bottom_heights=[-1.78], align_center=False, feature_map_stride=stride,
+                                      matched_threshold=0.6, unmatched_threshold=0.45)],
+        TARGET_ASSIGNER_CONFIG=dict(NAME="AxisAlignedTargetAssigner", POS_FRACTION=-1.0, SAMPLE_SIZE=512,
+                                    NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False, BOX_CODER="ResidualCoder"),
+        LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, mem_weight=1.0,
+                                           code_weights=[1.0] * 7)))
+
+
+def g8_assigner_losses(R):
+    """Target assignment + the five losses of the training head on a small grid (reference code, CPU)."""
+    gen = torch.Generator().manual_seed(808)
+    nx, ny = 40, 32
+    rng = np.array([0, -2.56, -2.5, 6.4, 2.56, 0.5], dtype=np.float32)     # 0.16 m cells
+    torch.manual_seed(808)
+    m = R.head_single.AnchorHeadSingle(model_cfg=_head_cfg(1), input_channels=24, num_class=1, class_names=["Car"],
+                                       grid_size=np.array([nx, ny, 1]), point_cloud_range=rng)
+    m.conv_box.weight.data.normal_(0, 0.05, generator=gen)
+    m.conv_dir_cls.weight.data.normal_(0, 0.2, generator=gen)
+    m.train()
+    B, G = 2, 5
+    gt = torch.zeros(B, G, 8)
+    gt[0, 0] = torch.tensor([2.1, 0.3, -1.0, 3.9, 1.6, 1.56, 0.1, 1])
+    gt[0, 1] = torch.tensor([4.8, -1.2, -1.0, 3.6, 1.5, 1.5, 1.45, 1])
+    gt[0, 2] = torch.tensor([5.9, 2.2, -0.9, 4.2, 1.7, 1.6, -2.9, 1])
+    gt[1, 0] = torch.tensor([3.3, -0.4, -1.1, 3.8, 1.6, 1.5, 0.8, 1])      # 45-degree-ish box: weak IoU with both anchors
+    gt[1, 1] = torch.tensor([1.0, 1.9, -1.0, 4.0, 1.65, 1.55, 1.6, 1])
+    f = torch.randn(B, 24, ny, nx, generator=gen)
+    fp = torch.randn(B, 24, ny, nx, generator=gen)
+    pos_p = torch.randn(37, 64, generator=gen)
+    pos_m = torch.randn(37, 64, generator=gen)
+    items = torch.randn(50, 64, generator=gen)
+    d = m({"spatial_features_2d": f.clone(), "spatial_features_point_2d": fp.clone(), "point_positive_features": pos_p,
+           "memory_positive_features": pos_m, "memory_items": items, "gt_boxes": gt.clone(), "batch_size": B})
+    fr = m.forward_ret_dict
+    targets = {k: fr[k].detach().clone().numpy() for k in ("box_cls_labels", "box_reg_targets", "reg_weights")}
+    rpn, rpn_pt, mem, tb, _ = m.get_loss()
+    np.savez_compressed(os.path.join(OUT, "g8_assigner_losses.npz"), nx=nx, ny=ny, point_cloud_range=rng, gt_boxes=gt.numpy(),
+                        spatial_features_2d=f.numpy(), spatial_features_point_2d=fp.numpy(), pos_point=pos_p.numpy(),
+                        pos_memory=pos_m.numpy(), rpn_loss=rpn.item(), rpn_loss_point=rpn_pt.item(), mem_loss=mem.item(),
+                        **{"tb." + k: np.float64(v) for k, v in tb.items()}, **{"target." + k: v for k, v in targets.items()},
+                        **{"param." + k: v for k, v in sd_np(m).items()})
+
+
+def g9_onecycle(R):
+    import collections
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable           # fastai_optim.py:3 predates python 3.10
+    fo = _load("tools_opt.fastai_optim", "tools/train_utils/optimization/fastai_optim.py")
+    sys.modules["tools_opt"] = types.ModuleType("tools_opt"); sys.modules["tools_opt"].__path__ = []
+    sys.modules["tools_opt.fastai_optim"] = fo
+    ls = _load("tools_opt.learning_schedules_fastai", "tools/train_utils/optimization/learning_schedules_fastai.py")
+    from functools import partial
+    torch.manual_seed(909)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5, bias=False), torch.nn.BatchNorm1d(5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    init = {k: v.detach().clone().numpy() for k, v in net.state_dict().items() if "num_batches" not in k}
+    flat = lambda mm: sum(map(flat, mm.children()), []) if len(list(mm.children())) else [mm]
+    opt = fo.OptimWrapper.create(partial(torch.optim.Adam, betas=(0.9, 0.99)), 3e-3, [torch.nn.Sequential(*flat(net))], wd=0.01,
+                                 true_wd=True, bn_wd=True)
+    sched = ls.OneCycle(opt, 100, 0.003, [0.95, 0.85], 10, 0.4)
+    lrs, moms = [], []
+    gen = torch.Generator().manual_seed(910)
+    xs = torch.randn(3, 16, 6, generator=gen)
+    after = []
+    for it in range(100):
+        sched.step(it)
+        lrs.append(float(opt.lr)); moms.append(float(opt.mom))
+        if it < 3:
+            net.train(); opt.zero_grad()
+            net(xs[it]).pow(2).mean().backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 10)
+            opt.step()
+            after.append({k: v.detach().clone().numpy() for k, v in net.state_dict().items() if "num_batches" not in k})
+    np.savez_compressed(os.path.join(OUT, "g9_onecycle.npz"), lr=np.array(lrs), mom=np.array(moms), x=xs.numpy(),
+                        **{"init." + k: v for k, v in init.items()},
+                        **{f"after{i}." + k: v for i, a in enumerate(after) for k, v in a.items()})
+
+
+def g10_train_memory(R):
+    gen = torch.Generator().manual_seed(1010)
+    cfg = EasyDict(NUM_BEV_FEATURES=128, NUM_COORD_POINTS=3, NUM_PT_FEATURES=64, NUM_SCALE_FEATURES=32, NUM_K=20, NUM_M=2000,
+                   SHRINK_TH=0.0025)
+    m = R.scatter.PointPillarScatter_Agg_Memory_1_scale(model_cfg=cfg, grid_size=np.array([12, 10, 1]))
+    load_det(m, 1010)
+    m.train()
+    pillars = torch.relu(torch.randn(60, 64, generator=gen))
+    points = torch.relu(torch.randn(900, 64, generator=gen))
+    with torch.no_grad():
+        gs = m.get_score(points, pillars.t())
+        score = torch.softmax(points @ pillars.t(), dim=0)
+        idx = torch.topk(score, 20, dim=0)[1]
+        positives = points[idx].permute(1, 0, 2).contiguous()
+        mem = m.memory(pillars, 20, positives)
+    np.savez_compressed(os.path.join(OUT, "g10_train_memory.npz"), pillars=pillars.numpy(), points=points.numpy(), W_seed=1010,
+                        W_name="memory.weight", get_score_output=gs["output"].numpy(), positives=positives.numpy(),
+                        memory_output=mem["output"].numpy(), memory_att_rowsum=mem["att"].sum(1).numpy(),
+                        memory_att_nnz=(mem["att"] > 0).sum(1).numpy())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     R = load_reference()
@@ -330,6 +432,9 @@ if __name__ == "__main__":
     g4_backbone(R)
     g5_head(R)
     g6_g7_coder(R)
+    g8_assigner_losses(R)
+    g9_onecycle(R)
+    g10_train_memory(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")

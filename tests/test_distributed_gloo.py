@@ -51,3 +51,86 @@ def test_single_process_is_a_noop():
     assert distributed.shard_frames(5, 0, 1) == [0, 1, 2, 3, 4]
     assert distributed.max_over_ranks(3.5, torch.device("cpu")) == 3.5
     assert distributed.gather_results({1: "a"}, 0, 1) == {1: "a"}
+
+
+# ------------------------------------------------------------------------------------------------ a15: DDP training
+class _DenseTrainStack:
+    """The dense (torch-autograd) half of the training graph — BEV backbone (two streams, shared weights) + anchor head +
+    target assigner + losses — on a 32x32 canvas so that it runs on CPU.  Built lazily inside each spawned worker."""
+
+    @staticmethod
+    def build():
+        import copy
+        import torch
+        from hvpr_amd import detector, synthetic_weights
+        from hvpr_amd.config import hvpr_car_cfg
+        cfg = copy.deepcopy(hvpr_car_cfg())
+        cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [0, -2.56, -3, 5.12, 2.56, 1]
+        model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg, training=True))
+        synthetic_weights.load_synthetic(model, seed=4, cls_bias=-4.595)
+
+        class Stack(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.backbone_2d, self.dense_head = model.backbone_2d, model.dense_head
+
+            def forward(self, d):
+                d = self.dense_head(self.backbone_2d(dict(d)))
+                rpn, rpn_point, mem, _, _ = self.dense_head.get_loss()
+                return rpn + rpn_point + mem
+        return Stack().train()
+
+    @staticmethod
+    def batch(seed):
+        import numpy as np
+        import torch
+        g = torch.Generator().manual_seed(seed)
+        r = lambda *s: torch.randn(*s, generator=g)
+        gt = np.zeros((1, 2, 8), np.float32)
+        gt[0, 0] = [2.0 + 0.3 * seed, 0.4, -1.0, 3.9, 1.6, 1.56, 0.3, 1]
+        return {"spatial_features": r(1, 128, 32, 32), "spatial_features_point": r(1, 128, 32, 32), "spatial_scale_features": r(1, 32, 32, 32),
+                "point_positive_features": r(5, 64), "memory_positive_features": r(5, 64), "memory_items": r(10, 64),
+                "gt_boxes": torch.from_numpy(gt), "batch_size": 1}
+
+
+def _local_grads(seed):
+    import torch
+    torch.manual_seed(0)
+    m = _DenseTrainStack.build()
+    m(_DenseTrainStack.batch(seed)).backward()
+    return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    torch.set_num_threads(2)
+    from hvpr_amd import distributed
+    distributed.init("gloo")
+    torch.manual_seed(0)
+    ddp = distributed.wrap_ddp(_DenseTrainStack.build(), torch.device("cpu"))
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    ddp(_DenseTrainStack.batch(rank)).backward()                       # every rank trains on its own shard
+    got = {k: p.grad.clone() for k, p in ddp.module.named_parameters() if p.grad is not None}
+    want = [_local_grads(r) for r in range(world)]                      # what each rank would have had alone
+    worst = 0.0
+    for k, g in got.items():
+        mean = sum(w[k] for w in want) / world
+        worst = max(worst, float((g - mean).abs().max() / (mean.abs().max() + 1e-12)))
+    distributed.finalize()
+    q.put((rank, len(got), worst))
+
+
+def test_ddp_gradients_are_the_rank_mean():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in procs)
+    for rank, n, worst in got:
+        assert n > 20 and worst < 1e-4, (rank, n, worst)
