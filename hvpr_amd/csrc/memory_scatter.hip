@@ -65,7 +65,9 @@ __device__ __forceinline__ unsigned long long bitonic64_desc_u64(unsigned long l
 __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__restrict__ f, int M,
                                                              const int *__restrict__ m_device,
                                                              const float *__restrict__ bank, int n_items, int k,
-                                                             float *__restrict__ out, int *__restrict__ topk_idx) {
+                                                             float *__restrict__ out, int *__restrict__ topk_idx,
+                                                             const int4 *__restrict__ coords, int batch, int nx, int ny,
+                                                             int *__restrict__ cell_map) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_logit = (float *)smem;                              // [kPillars][kItemsPad]
     float *s_f = s_logit + kPillars * kItemsPad;                 // [kPillars][kC]
@@ -231,6 +233,11 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         for (int r = 0; r < 32; ++r) esum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r));
         const float a = e / esum;
         if (topk_idx && lane < k) topk_idx[(size_t)(p0 + p) * k + lane] = idx;
+        if (cell_map && lane == 0) {   // fused a3+a4: this pillar's entry of the scatter cell map (k_cell_map's job)
+            const int4 c = coords[p0 + p];
+            if ((unsigned)c.x < (unsigned)batch && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx)
+                cell_map[((size_t)c.x * ny + c.z) * nx + c.w] = p0 + p;
+        }
         // lane = channel.  All 32 candidate rows are requested before the first is used (lanes >= k carry weight 0 and
         // row 0), so the gather costs one L2 round trip instead of k dependent ones.
         float rows[32];
@@ -319,8 +326,10 @@ int launch_scatter(const float *pillar, const float *memory, const float *scale,
 
 }  // namespace
 
-extern "C" int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t *m_device, const float *bank,
-                                           int n_items, int k, float *out, int32_t *topk_idx, hvpr_stream_t stream) {
+namespace {
+int launch_canvas(const float *, int, const float *, int, const float *, int, long long, int *, float *, float *, hipStream_t);
+int launch_readout(const float *f, int M, const int32_t *m_device, const float *bank, int n_items, int k, float *out,
+                   int32_t *topk_idx, const int32_t *coords, int batch, int nx, int ny, int *cell_map, hvpr_stream_t stream) {
     if (M < 0 || n_items < 1 || k < 1) return HVPR_ERR_INVALID_ARG;
     if (k > 32 || k > n_items || n_items > kItemsPad) return HVPR_ERR_UNSUPPORTED;
     if (M == 0) return HVPR_OK;
@@ -334,9 +343,15 @@ extern "C" int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t 
         attr_set = true;
     }
     hipLaunchKernelGGL(k_memory_readout, dim3(hvpr_cdiv(M, kPillars)), dim3(kThreads), lds, (hipStream_t)stream, f, M,
-                       m_device, bank, n_items, k, out, topk_idx);
+                       m_device, bank, n_items, k, out, topk_idx, (const int4 *)coords, batch, nx, ny, cell_map);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
+}
+}  // namespace
+
+extern "C" int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t *m_device, const float *bank,
+                                           int n_items, int k, float *out, int32_t *topk_idx, hvpr_stream_t stream) {
+    return launch_readout(f, M, m_device, bank, n_items, k, out, topk_idx, nullptr, 0, 0, 0, nullptr, stream);
 }
 
 extern "C" size_t hvpr_scatter_workspace_bytes(int batch, int nx, int ny) {
@@ -359,6 +374,29 @@ extern "C" int hvpr_scatter_bev_fwd_f32(const float *pillar_features, int c_pill
     const long long n_cells = (long long)batch * nx * ny;
     if (M > 0) hipLaunchKernelGGL(k_cell_map, dim3(hvpr_cdiv(M, 256)), dim3(256), 0, s, (const int4 *)coords, M, m_device,
                                   batch, nx, ny, cell_map);
+    return launch_canvas(pillar_features, c_pillar, memory_features, c_mem, scale_features, c_scale, n_cells, cell_map, spatial,
+                         spatial_scale, s);
+}
+
+extern "C" int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale_features, const int32_t *coords,
+                                           int M, const int32_t *m_device, const float *bank, int n_items, int k, int batch,
+                                           int nx, int ny, float *memory_features, float *spatial, float *spatial_scale,
+                                           void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
+    if (M < 0 || batch < 1 || nx < 1 || ny < 1 || !spatial || !spatial_scale || !workspace) return HVPR_ERR_INVALID_ARG;
+    if (M > 0 && (!pillar_features || !scale_features || !coords || !memory_features)) return HVPR_ERR_INVALID_ARG;
+    if (workspace_bytes < hvpr_scatter_workspace_bytes(batch, nx, ny)) return HVPR_ERR_WORKSPACE;
+    int *cell_map = (int *)workspace;
+    const int st = launch_readout(pillar_features, M, m_device, bank, n_items, k, memory_features, nullptr, coords, batch, nx,
+                                  ny, cell_map, stream);
+    if (st != HVPR_OK) return st;
+    return launch_canvas(pillar_features, 64, memory_features, 64, scale_features, 32, (long long)batch * nx * ny, cell_map,
+                         spatial, spatial_scale, (hipStream_t)stream);
+}
+
+namespace {
+int launch_canvas(const float *pillar_features, int c_pillar, const float *memory_features, int c_mem,
+                  const float *scale_features, int c_scale, long long n_cells, int *cell_map, float *spatial,
+                  float *spatial_scale, hipStream_t s) {
     if (c_pillar == 64 && c_mem == 64 && c_scale == 32)
         launch_scatter<64, 64, 32>(pillar_features, memory_features, scale_features, n_cells, cell_map, spatial, spatial_scale, s);
     else if (c_pillar == 64 && c_mem == 0 && c_scale == 0)
@@ -370,3 +408,4 @@ extern "C" int hvpr_scatter_bev_fwd_f32(const float *pillar_features, int c_pill
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
+}  // namespace

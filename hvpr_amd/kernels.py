@@ -130,6 +130,23 @@ def scatter_bev_fwd(pillar, memory, scale, coords, batch, nx, ny, workspace, m_d
     return spatial, spatial_scale
 
 
+def memory_scatter_fwd(pillar, scale, coords, bank, k, batch, nx, ny, workspace, m_device=None):
+    """Fused a3+a4 (64+64+32 channels): returns memory_features (M,64), spatial (B,128,ny,nx), spatial_scale (B,32,ny,nx)."""
+    M = pillar.shape[0]
+    dev = pillar.device
+    mem = torch.empty((M, 64), dtype=torch.float32, device=dev)
+    spatial = torch.empty((batch, ny, nx, 128), dtype=torch.float32, device=dev)
+    spatial_scale = torch.empty((batch, ny, nx, 32), dtype=torch.float32, device=dev)
+    if pillar.shape[1] != 64 or scale.shape[1] != 32 or bank.shape[1] != 64:
+        raise ValueError("memory_scatter_fwd is specialised for 64 pillar / 64 memory / 32 scale channels")
+    check(lib().hvpr_memory_scatter_fwd_f32(_ptr(pillar, torch.float32, "pillar_features"), _ptr(scale, torch.float32, "scale"),
+                                            _ptr(coords, torch.int32, "voxel_coords"), M, _ptr(m_device, torch.int32),
+                                            _ptr(bank, torch.float32, "memory.weight"), bank.shape[0], int(k), batch, nx, ny,
+                                            mem.data_ptr(), spatial.data_ptr(), spatial_scale.data_ptr(), workspace.data_ptr(),
+                                            workspace.numel() * 4, _stream()), "hvpr_memory_scatter_fwd_f32")
+    return mem, spatial.permute(0, 3, 1, 2), spatial_scale.permute(0, 3, 1, 2)
+
+
 # ------------------------------------------------------------------------------------------------ convolutions
 class PackedConv:
     """Weights of one conv layer in the kernel's layout [taps, Cin/8, 2, cout_pad, 4] with BatchNorm folded."""

@@ -167,9 +167,14 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         pf, sf = batch_dict["pillar_features"], batch_dict["pillar_scale_features"]
         md = batch_dict.get("voxel_count_device")
         B = _batch_size(batch_dict)
-        mem = kernels.memory_readout_fwd(pf.contiguous(), self.memory.weight.detach().contiguous(), self.k, m_device=md)
-        sp, sc = kernels.scatter_bev_fwd(pf.contiguous(), mem, sf.contiguous(), _coords_i32(batch_dict), B, self.nx,
-                                         self.ny, self._workspace(B, pf.device), m_device=md)
+        bank = self.memory.weight.detach().contiguous()
+        if pf.shape[1] == 64 and sf.shape[1] == 32 and bank.shape[1] == 64:   # hvpr.yaml widths: fused read-out + scatter
+            _, sp, sc = kernels.memory_scatter_fwd(pf.contiguous(), sf.contiguous(), _coords_i32(batch_dict), bank, self.k, B,
+                                                   self.nx, self.ny, self._workspace(B, pf.device), m_device=md)
+        else:
+            mem = kernels.memory_readout_fwd(pf.contiguous(), bank, self.k, m_device=md)
+            sp, sc = kernels.scatter_bev_fwd(pf.contiguous(), mem, sf.contiguous(), _coords_i32(batch_dict), B, self.nx,
+                                             self.ny, self._workspace(B, pf.device), m_device=md)
         batch_dict["spatial_features"] = sp           # (B, 128, ny, nx): ch 0-63 pillar (detached), 64-127 memory
         batch_dict["spatial_scale_features"] = sc     # (B, 32, ny, nx)
         return batch_dict

@@ -112,6 +112,14 @@ int hvpr_scatter_bev_fwd_f32(const float *pillar_features, int c_pillar, const f
                              const int32_t *m_device, int batch, int nx, int ny, float *spatial,
                              float *spatial_scale, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
 
+/* a3+a4 fused, the form PointPillarScatter_Agg_Memory_1_scale.forward (eval, pointpillar_scatter.py:169-222) uses: the
+ *     memory read-out also fills the scatter cell map (one launch less than the two calls above, same results).
+ *     Fixed channel counts 64 (pillar) + 64 (memory) + 32 (scale).  memory_features [M,64] is an output. */
+int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale_features, const int32_t *coords, int M,
+                                const int32_t *m_device, const float *bank, int n_items, int k, int batch, int nx, int ny,
+                                float *memory_features, float *spatial, float *spatial_scale, void *workspace,
+                                size_t workspace_bytes, hvpr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a5/a6  BEV backbone + head convolutions: implicit GEMM on the fp32 matrix cores, NHWC.
  *     Replaces the cuDNN convolutions behind BaseBEVBackbone_Scale.forward (eval),

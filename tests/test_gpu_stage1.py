@@ -61,6 +61,20 @@ def test_voxelize_batch_ragged_and_empty():
     _check_voxelize([synthetic.hvpr_frame(5)[:100], np.zeros((0, 4), np.float32)], 32, 40000)
 
 
+def test_voxelize_multi_frame_batches():
+    """ragged batches of 2-4 frames (scan tiles straddle frame borders), an empty frame in the middle, caps in both modes."""
+    two = [synthetic.hvpr_frame(20), synthetic.hvpr_frame(21, shuffle=True)]
+    _check_voxelize(two, 32, 40000)
+    _check_voxelize([two[0], two[1][:9000]], 32, 3000)
+    _check_voxelize([two[0], two[1][:9000]], 32, 3000, mode="v1")
+    three = [synthetic.hvpr_frame(22), np.zeros((0, 4), np.float32), synthetic.hvpr_frame(23, shuffle=True),
+             synthetic.hvpr_frame(24)[:5]]
+    _check_voxelize(three, 32, 40000)
+    _check_voxelize(three, 32, 3000, mode="v1")
+    _check_voxelize([synthetic.hvpr_frame(25)[:2048]], 32, 40000)      # exactly one scan tile
+    _check_voxelize([synthetic.hvpr_frame(25)[:2049]], 32, 40000)
+
+
 def test_voxelize_edges():
     # points exactly on / outside the range borders, z outside, a single point, duplicates
     p = np.array([[0.0, -19.84, -2.5, 0.1], [47.36, 0, 0, 0.2], [47.3599, 19.8399, 0.4999, 0.3], [10, 0, 0.5, 0.4],
@@ -232,3 +246,29 @@ def test_scatter_full_grid_vs_oracle():
     sp, sc = kernels.scatter_bev_fwd(*(torch.from_numpy(a).to(DEV) for a in (pf, mo, sf, coords)), 2, 296, 248, ws)
     np.testing.assert_array_equal(sp.cpu().numpy(), rsp.numpy())
     np.testing.assert_array_equal(sc.cpu().numpy(), rsc.numpy())
+
+
+def test_fused_memory_scatter_equals_the_two_calls():
+    v, c, n = O.voxelize(synthetic.hvpr_frame(9), VS, RNG, 32, 40000)
+    M = len(c)
+    rng = np.random.default_rng(1)
+    pf = torch.from_numpy(rng.normal(0, 1, (2 * M, 64)).astype(np.float32)).to(DEV)
+    sf = torch.from_numpy(rng.normal(0, 1, (2 * M, 32)).astype(np.float32)).to(DEV)
+    W = torch.from_numpy(rng.uniform(-0.125, 0.125, (2000, 64)).astype(np.float32)).to(DEV)
+    coords = torch.from_numpy(np.concatenate([np.concatenate([np.full((M, 1), b, np.int32), c], 1) for b in range(2)])).to(DEV)
+    ws = kernels.scatter_workspace(2, 296, 248, DEV)
+    mem = kernels.memory_readout_fwd(pf, W, 20)
+    sp, sc = kernels.scatter_bev_fwd(pf, mem, sf, coords, 2, 296, 248, ws)
+    for md in (None, torch.tensor([2 * M - 100], dtype=torch.int32, device=DEV)):
+        mem2, sp2, sc2 = kernels.memory_scatter_fwd(pf, sf, coords, W, 20, 2, 296, 248, ws, m_device=md)
+        assert (ws == -1).all()
+        if md is None:
+            assert torch.equal(mem2, mem) and torch.equal(sp2, sp) and torch.equal(sc2, sc)
+        else:      # only the first m_device pillars exist
+            spx, scx = kernels.scatter_bev_fwd(pf, mem, sf, coords, 2, 296, 248, ws, m_device=md)
+            assert torch.equal(sp2, spx) and torch.equal(sc2, scx)
+    # no pillars at all: zero canvases
+    e = torch.empty((0, 64), device=DEV)
+    _, sp0, sc0 = kernels.memory_scatter_fwd(e, torch.empty((0, 32), device=DEV), torch.empty((0, 4), dtype=torch.int32, device=DEV),
+                                             W, 20, 1, 296, 248, kernels.scatter_workspace(1, 296, 248, DEV))
+    assert float(sp0.abs().sum()) == 0.0 and float(sc0.abs().sum()) == 0.0
