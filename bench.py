@@ -141,7 +141,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe-steps", type=int, default=30, help="extra untimed steps with per-stage HIP events")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per frame")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one whole-frame hipGraph per step (frame latency = step) instead of the 3-stage frame pipeline")
     ap.add_argument("--cls-bias", type=float, default=-4.59511985013459, help="conv_cls.bias of the synthetic weights")
     args = ap.parse_args()
 
@@ -171,16 +173,35 @@ def main():
         distributed.barrier(device)
 
     # one hipGraph per frame: every data-dependent size on this path is a device word, so the launch sequence is static
-    step = (lambda b: model(dict(b), sync=False)) if args.no_graph else detector.GraphedForward(model, batches[0])
-    with torch.no_grad():
+    def timed(step):
         for i in range(args.warmup):
             step(batches[i % N_POOL])
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(batches[i % N_POOL])
+            step(batches[(args.warmup + i) % N_POOL])
         barrier()
-        dt = distributed.max_over_ranks(time.perf_counter() - t0, device)
+        return distributed.max_over_ranks(time.perf_counter() - t0, device)
+
+    with torch.no_grad():
+        if args.no_graph:
+            mode = "eager launches"
+            dt = timed(lambda b: model(dict(b), sync=False))
+            dt_single = None
+        else:
+            # latency mode: one whole-frame hipGraph per step (a1..a8 of ONE frame, serial)
+            dt_single = timed(detector.GraphedForward(model, batches[0]))
+            mode, dt = "one whole-frame hipGraph replay per step (frame latency = 1 step)", dt_single
+            if not args.no_pipeline:
+                # throughput mode: every step is one graph replay that encodes frame k, convolves frame k-1 and runs top-k +
+                # NMS of frame k-2 on three streams; K timed steps retire exactly K frames (the pipeline is full before and
+                # after the timed region; the warm-up fills it), nothing is skipped
+                pipe = detector.PipelinedForward(model, batches[0])
+                dt = timed(pipe)
+                for _ in pipe.flush():
+                    pass
+                mode = "3-stage frame pipeline: one hipGraph replay per step = encode(k) | convolutions(k-1) | top-k+NMS(k-2) " \
+                       "on three HIP streams (frame latency = 3 steps)"
 
         # ---- per-stage probe (untimed): HIP events on the launch stream ----
         stage = np.zeros(3)
@@ -223,7 +244,9 @@ def main():
                    "frame": f"synthetic 64-beam LiDAR, ~{raw_pts} raw points -> range mask -> {n_pts} sampled points, "
                             f"~{int(n_pillars)} pillars, grid {nx}x{ny}x1", "global_batch": world,
                    "weights": f"deterministic synthetic (seed 0), BN stats randomised, cls bias {args.cls_bias:.3f}",
-                   "nms_candidates_kept": kept, "launch": "eager" if args.no_graph else "one hipGraph replay per frame"},
+                   "nms_candidates_kept": kept, "launch": mode},
+        "single_graph_latency_mode": None if dt_single is None else {"value": round(world * args.steps / dt_single, 2),
+                                                                     "unit": "frames/s", "ms_per_frame": round(1e3 * dt_single / args.steps, 4)},
         "stage_ms": {"voxelize+vfe+memory+scatter": round(float(stage[0]), 4), "backbone+head+decode": round(float(stage[1]), 4),
                      "topk+nms": round(float(stage[2]), 4)},
         "roofline": {"kernel": "VFE+scatter group (4 voxelize launches, pillar VFE, memory read-out, cell map, scatter)",

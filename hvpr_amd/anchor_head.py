@@ -240,7 +240,8 @@ class AnchorHeadSingle(AnchorHeadTemplate):
             self.forward_ret_dict["dir_cls_preds"] = head[..., na * (nc + 7):]
         period = 2 * np.pi / nb if nb else 1.0
         cls, box, scores, labels = kernels.head_decode(head, na, nc, nb, P["xs"], P["ys"], P["table"],
-                                                       self.model_cfg.DIR_OFFSET, self.model_cfg.DIR_LIMIT_OFFSET, period)
+                                                       self.model_cfg.DIR_OFFSET, self.model_cfg.DIR_LIMIT_OFFSET, period,
+                                                       out=data_dict.get("_out_head"))
         data_dict["batch_cls_preds"] = cls
         data_dict["batch_box_preds"] = box
         data_dict["cls_preds_normalized"] = False

@@ -178,11 +178,14 @@ class BaseBEVBackbone_Scale(nn.Module):
         two_streams = self.overlap_branches
         coff = 0
         capturing = torch.cuda.is_current_stream_capturing()
+        held = []     # trunk outputs the side stream reads: referenced until the join, so that the allocator of the main
+        #               stream cannot hand their memory to the next level's convolutions while the branch still reads them
         for i, lv in enumerate(P["levels"]):
             for pc in lv["convs"]:
                 x = kernels.conv2d_nhwc(x, pc)
             if two_streams:
                 side.wait_stream(main)          # x (and y of the previous level) are ready for the branch
+                held.append(x)
                 ctx = torch.cuda.stream(side)
             else:
                 ctx = contextlib.nullcontext()
@@ -199,6 +202,7 @@ class BaseBEVBackbone_Scale(nn.Module):
             coff += self.up_filters[i]
         if two_streams:
             main.wait_stream(side)
+        held.clear()
         data_dict["spatial_features_2d"] = out.permute(0, 3, 1, 2)   # (B, 384, H, W), channels_last
         return data_dict
 

@@ -268,6 +268,17 @@ class MixAnchor_Memory(_VoxelizingDetector):
         tb_dict = {"loss_rpn": rpn.detach(), **tb_dict}
         return loss, tb_dict, {"items": items}
 
+    # the eval forward in the three stages a frame pipeline overlaps (PipelinedForward)
+    def stage_encode(self, batch_dict):
+        """a1-a4: points -> BEV canvases."""
+        if "voxels" not in batch_dict:
+            batch_dict = self.voxelize_on_device(batch_dict)
+        return self.map_to_bev_module(self.vfe(batch_dict))
+
+    def stage_dense(self, batch_dict):
+        """a5-a7: canvases -> decoded boxes and scores of every anchor."""
+        return self.dense_head(self.backbone_2d(batch_dict))
+
     def forward(self, batch_dict, sync=True):
         if "voxels" not in batch_dict:
             batch_dict = self.voxelize_on_device(batch_dict)
@@ -315,6 +326,85 @@ class GraphedForward:
                 self.static_in[k].copy_(v, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+class PipelinedForward:
+    """Frame pipeline of the eval forward for throughput: step k runs, concurrently on three HIP streams inside ONE graph
+    replay, stage_encode of frame k, stage_dense of frame k-1 and post_processing of frame k-2.
+
+    Why: at batch 1 the encode group (8 launches, ~0.1 ms) and top-k + NMS (~0.6 ms) are latency-bound chains of small
+    kernels that leave most of the 256 CUs idle; the convolutions (4 ms) are throughput-bound.  Overlapping the chains of
+    neighbouring frames with the convolutions hides them.  Results are bit-identical to the serial forward (same kernels,
+    same inputs; tests/test_gpu_e2e.py); the latency of one frame becomes three steps.
+
+    Two lanes of boundary buffers (canvases, head outputs) alternate, so there are two graphs (even / odd steps).
+    __call__(batch) enqueues frame k and returns the `sync=False` result of frame k-2 (None for the first two calls);
+    flush() drains the last two frames."""
+
+    _HEAD_KEYS = ("batch_cls_preds", "batch_box_preds", "batch_max_scores", "batch_max_labels")
+
+    def __init__(self, model, example_batch, warmup=2):
+        assert not model.training and hasattr(model, "stage_encode")
+        self.model, self.step = model, 0
+        self.B = example_batch["batch_size"]
+        self.inp = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()} for _ in range(2)]
+        self.canvas, self.head, self.aux = [None, None], [None, None], [None, None]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for p in range(2):                       # eager runs: lazy init + the persistent boundary buffers of each lane
+                for _ in range(warmup):
+                    bd = model.stage_encode(dict(self.inp[p]))
+                    self.canvas[p] = (bd["spatial_features"], bd["spatial_scale_features"])
+                    bd = model.stage_dense(bd)
+                    self.head[p] = tuple(bd[k] for k in self._HEAD_KEYS)
+                    model.post_processing(bd, sync=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.s_enc, self.s_post = torch.cuda.Stream(), torch.cuda.Stream()
+        self.graphs, self.out = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()], [None, None]
+        pool = None
+        for p in range(2):
+            q = 1 - p
+            with torch.cuda.graph(self.graphs[p], pool=pool), torch.no_grad():
+                main = torch.cuda.current_stream()
+                self.s_enc.wait_stream(main)
+                self.s_post.wait_stream(main)
+                with torch.cuda.stream(self.s_post):      # frame k-2 (lane p): top-k + NMS
+                    self.out[p] = model.post_processing(self._post_dict(p), sync=False)[0]
+                with torch.cuda.stream(self.s_enc):       # frame k (lane p): points -> canvases of lane p
+                    bd = model.stage_encode({**self.inp[p], "_out_spatial": self.canvas[p]})
+                    self.aux[p] = bd["voxel_offsets"]
+                # frame k-1 (lane q): convolutions on the capture stream (+ the backbone's own side stream)
+                model.stage_dense({"batch_size": self.B, "spatial_features": self.canvas[q][0],
+                                   "spatial_scale_features": self.canvas[q][1], "_out_head": self.head[q]})
+                main.wait_stream(self.s_enc)
+                main.wait_stream(self.s_post)
+            pool = self.graphs[p].pool()
+
+    def _post_dict(self, p):
+        d = dict(zip(self._HEAD_KEYS, self.head[p]))
+        d.update(batch_size=self.B, cls_preds_normalized=False)
+        return d
+
+    def __call__(self, batch):
+        p = self.step & 1
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                self.inp[p][k].copy_(v, non_blocking=True)
+        self.graphs[p].replay()
+        self.step += 1
+        return self.out[p] if self.step > 2 else None
+
+    def flush(self):
+        """Two more steps (re-encoding the last inputs, whose results are dropped): yields the results of the last two
+        frames, oldest first.  Each result is only valid until the next step on its lane — consume it before the next."""
+        for _ in range(2):
+            p = self.step & 1
+            self.graphs[p].replay()
+            self.step += 1
+            if self.step > 2:
+                yield self.out[p]
 
 
 class PointPillar(_VoxelizingDetector):

@@ -130,13 +130,20 @@ def scatter_bev_fwd(pillar, memory, scale, coords, batch, nx, ny, workspace, m_d
     return spatial, spatial_scale
 
 
-def memory_scatter_fwd(pillar, scale, coords, bank, k, batch, nx, ny, workspace, m_device=None):
-    """Fused a3+a4 (64+64+32 channels): returns memory_features (M,64), spatial (B,128,ny,nx), spatial_scale (B,32,ny,nx)."""
+def memory_scatter_fwd(pillar, scale, coords, bank, k, batch, nx, ny, workspace, m_device=None, out=None):
+    """Fused a3+a4 (64+64+32 channels): returns memory_features (M,64), spatial (B,128,ny,nx), spatial_scale (B,32,ny,nx).
+    `out` = (spatial, spatial_scale) as returned by an earlier call: write into those canvases instead of new ones."""
     M = pillar.shape[0]
     dev = pillar.device
     mem = torch.empty((M, 64), dtype=torch.float32, device=dev)
-    spatial = torch.empty((batch, ny, nx, 128), dtype=torch.float32, device=dev)
-    spatial_scale = torch.empty((batch, ny, nx, 32), dtype=torch.float32, device=dev)
+    if out is not None:
+        spatial, spatial_scale = (o.permute(0, 2, 3, 1) for o in out)
+        if spatial.shape != (batch, ny, nx, 128) or spatial_scale.shape != (batch, ny, nx, 32) or not spatial.is_contiguous() \
+                or not spatial_scale.is_contiguous():
+            raise ValueError("memory_scatter_fwd: `out` canvases do not match this call")
+    else:
+        spatial = torch.empty((batch, ny, nx, 128), dtype=torch.float32, device=dev)
+        spatial_scale = torch.empty((batch, ny, nx, 32), dtype=torch.float32, device=dev)
     if pillar.shape[1] != 64 or scale.shape[1] != 32 or bank.shape[1] != 64:
         raise ValueError("memory_scatter_fwd is specialised for 64 pillar / 64 memory / 32 scale channels")
     check(lib().hvpr_memory_scatter_fwd_f32(_ptr(pillar, torch.float32, "pillar_features"), _ptr(scale, torch.float32, "scale"),
@@ -231,14 +238,19 @@ def spatial_gate(y_nhwc, w18, conv_bias, bn_scale, bn_shift):
 
 
 def head_decode(head_nhwc, n_anchor, n_class, n_dir_bins, x_shifts, y_shifts, anchor_table, dir_offset, dir_limit_offset,
-                period, want_cls=True, want_scores=True):
+                period, want_cls=True, want_scores=True, out=None):
     N, H, W, CH = head_nhwc.shape
     A = H * W * n_anchor
     dev = head_nhwc.device
-    cls = torch.empty((N, A, n_class), dtype=torch.float32, device=dev) if want_cls else None
-    box = torch.empty((N, A, 7), dtype=torch.float32, device=dev)
-    scores = torch.empty((N, A), dtype=torch.float32, device=dev) if want_scores else None
-    labels = torch.empty((N, A), dtype=torch.int32, device=dev) if want_scores else None
+    if out is not None:      # (cls, box, scores, labels) of an earlier call with the same shapes
+        cls, box, scores, labels = out
+        if box.shape != (N, A, 7) or not all(t is None or t.is_contiguous() for t in out):
+            raise ValueError("head_decode: `out` tensors do not match this call")
+    else:
+        cls = torch.empty((N, A, n_class), dtype=torch.float32, device=dev) if want_cls else None
+        box = torch.empty((N, A, 7), dtype=torch.float32, device=dev)
+        scores = torch.empty((N, A), dtype=torch.float32, device=dev) if want_scores else None
+        labels = torch.empty((N, A), dtype=torch.int32, device=dev) if want_scores else None
     check(lib().hvpr_head_decode_f32(_ptr(head_nhwc, torch.float32, "head output"), N, H, W, CH, n_anchor, n_class,
                                      n_dir_bins, _ptr(x_shifts, torch.float32), _ptr(y_shifts, torch.float32),
                                      _ptr(anchor_table, torch.float32), float(dir_offset), float(dir_limit_offset),

@@ -170,7 +170,8 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         bank = self.memory.weight.detach().contiguous()
         if pf.shape[1] == 64 and sf.shape[1] == 32 and bank.shape[1] == 64:   # hvpr.yaml widths: fused read-out + scatter
             _, sp, sc = kernels.memory_scatter_fwd(pf.contiguous(), sf.contiguous(), _coords_i32(batch_dict), bank, self.k, B,
-                                                   self.nx, self.ny, self._workspace(B, pf.device), m_device=md)
+                                                   self.nx, self.ny, self._workspace(B, pf.device), m_device=md,
+                                                   out=batch_dict.get("_out_spatial"))
         else:
             mem = kernels.memory_readout_fwd(pf.contiguous(), bank, self.k, m_device=md)
             sp, sc = kernels.scatter_bev_fwd(pf.contiguous(), mem, sf.contiguous(), _coords_i32(batch_dict), B, self.nx,
