@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one whole-frame hipGraph per step (frame latency = step) instead of the 3-stage frame pipeline")
+    ap.add_argument("--skip-single", action="store_true", help="profiling: do not time the single-graph latency mode")
     ap.add_argument("--cls-bias", type=float, default=-4.59511985013459, help="conv_cls.bias of the synthetic weights")
     args = ap.parse_args()
 
@@ -190,7 +191,7 @@ def main():
             dt_single = None
         else:
             # latency mode: one whole-frame hipGraph per step (a1..a8 of ONE frame, serial)
-            dt_single = timed(detector.GraphedForward(model, batches[0]))
+            dt_single = None if (args.skip_single and not args.no_pipeline) else timed(detector.GraphedForward(model, batches[0]))
             mode, dt = "one whole-frame hipGraph replay per step (frame latency = 1 step)", dt_single
             if not args.no_pipeline:
                 # throughput mode: every step is one graph replay that encodes frame k, convolves frame k-1 and runs top-k +

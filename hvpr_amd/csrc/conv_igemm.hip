@@ -68,14 +68,18 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     constexpr int WM = BM / 2, WN = BN / 2;        // per-wave tile
     constexpr int MB = WM / 32, NB = WN / 32;
     static_assert(MB >= 1 && NB >= 1, "wave tile must hold at least one 32x32 block");
+    // TAPS: 9 = 3x3 conv; 1 = 1x1 conv, one 8-channel chunk per stage; 4 = 1x1 conv with FOUR 8-channel chunks per stage
+    // ("virtual taps" at the same pixel: 4x the multiply work per barrier — a 1x1 stage is otherwise 4 MFMAs per wave)
     constexpr int HALO = TAPS == 9 ? 2 : 0;
+    constexpr int NSUB = TAPS == 4 ? 4 : 1;        // 8-channel sub-chunks per stage
+    constexpr int KSTAGE = KC * NSUB;              // input channels per stage
     constexpr int PH = (TH - 1) * S + 1 + HALO, PW = (TW - 1) * S + 1 + HALO;
     // LDS images (float4 units), both split into two channel-half planes so that a half-wave (32 lanes, same half)
     // reads 32 consecutive float4 = conflict-free ds_read_b128:
     //   patch   [half][PPAD]       pixel-major inside a plane
     //   weights [tap][half][BN]
     constexpr int PPAD = (PH * PW + 63) / 64 * 64;
-    constexpr int PATCH_V4 = 2 * PPAD;
+    constexpr int PATCH_V4 = NSUB * 2 * PPAD;     //   patch   [sub][half][PPAD]
     constexpr int W_V4 = TAPS * BN * 2;
     constexpr int NLD_P = (PATCH_V4 + 255) / 256, NLD_W = (W_V4 + 255) / 256;
 
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NLD_P; ++i) {
         const int v = tid + i * 256;
-        const int part = v / PPAD, pix = v % PPAD;
+        const int part = v / PPAD, pix = v % PPAD;          // part = sub * 2 + half: channels part*4 .. part*4+3 of the stage
         const int py = pix / PW, px = pix % PW;
         const int iy = iy0 + py, ix = ix0 + px;
         pok[i] = v < PATCH_V4 && pix < PH * PW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
@@ -126,15 +130,16 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
         wok[i] = v < W_V4;
         const int th = v / BN, co_l = v % BN;
         const int tap = th >> 1, hf = th & 1;
-        woff[i] = wok[i] ? (unsigned)(((size_t)tap * w_tap_stride + ((size_t)hf * a.cout_pad + co0 + co_l) * 4) * sizeof(float)) : 0u;
+        const size_t tap_stride = TAPS == 4 ? w_chunk_stride : w_tap_stride;   // a virtual tap is the next cin chunk
+        woff[i] = wok[i] ? (unsigned)(((size_t)tap * tap_stride + ((size_t)hf * a.cout_pad + co0 + co_l) * 4) * sizeof(float)) : 0u;
     }
     const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * a.Cin);   // uniform
     const unsigned lds_patch0 = lds_addr_of(&s_patch[0][0]) + wave_s * 1024u;    // uniform (wave_s is an SGPR value)
     const unsigned lds_w0 = lds_addr_of(&s_w[0][0]) + wave_s * 1024u;
 
     auto stage = [&](int chunk, int buf) {
-        const char *pbase = in_n + (size_t)chunk * (KC * sizeof(float));
-        const char *wbase = (const char *)a.wpk + (size_t)chunk * w_chunk_stride * sizeof(float);
+        const char *pbase = in_n + (size_t)chunk * (KSTAGE * sizeof(float));
+        const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * sizeof(float);
 #pragma unroll
         for (int i = 0; i < NLD_P; ++i)
             if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * 256) * 16u);
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
-    const int n_chunks = a.Cin / KC;
+    const int n_chunks = a.Cin / KSTAGE;
     // one chunk: wait for it, let the next one stream into the other stage, multiply.  `buf` is a compile-time constant in
     // both call sites (the loop is unrolled by two) so that every LDS address is an immediate offset.
     auto chunk_step = [&](int c, auto buf_tag) {
@@ -187,7 +192,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
         auto lds_load = [&](int tap, int slot) {
             const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[slot][mb] = sp[a_off[mb] + ky * PW + kx];
+            for (int mb = 0; mb < MB; ++mb) av[slot][mb] = sp[a_off[mb] + (TAPS == 4 ? tap * 2 * PPAD : ky * PW + kx)];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) bv[slot][nb] = sw[b_off[nb] + tap * BN * 2];
         };
@@ -276,6 +281,7 @@ extern "C" int hvpr_conv2d_nhwc_f32(const float *in, int N, int H, int W, int Ci
     if (!in || !w_packed || !bias || !out || N < 1 || H < 1 || W < 1 || Cin < 8 || cout < 1) return HVPR_ERR_INVALID_ARG;
     if ((gate == nullptr) != (resid == nullptr)) return HVPR_ERR_INVALID_ARG;
     if (Cin % KC != 0 || (taps != 9 && taps != 1) || (stride != 1 && stride != 2) || up < 1) return HVPR_ERR_UNSUPPORTED;
+    const bool wide1x1 = taps == 1 && Cin % (4 * KC) == 0;   // four cin chunks per LDS stage
     if (taps == 1 && stride != 1) return HVPR_ERR_UNSUPPORTED;
     if (up > 1 && (taps != 1 || gate)) return HVPR_ERR_UNSUPPORTED;
     ConvArgs a;
@@ -295,6 +301,7 @@ extern "C" int hvpr_conv2d_nhwc_f32(const float *in, int N, int H, int W, int Ci
 #define HV_CASE(TH, TW, BN)                                                        \
     if (taps == 9 && stride == 1) launch<TH, TW, BN, 1, 9>(a, s);                   \
     else if (taps == 9 && stride == 2) launch<TH, TW, BN, 2, 9>(a, s);              \
+    else if (wide1x1) launch<TH, TW, BN, 1, 4>(a, s);                                \
     else launch<TH, TW, BN, 1, 1>(a, s);
     if (tile_cfg == 0) { HV_CASE(8, 16, 128) }
     else if (tile_cfg == 1) { HV_CASE(8, 8, 64) }
