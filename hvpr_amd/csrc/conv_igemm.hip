@@ -94,33 +94,19 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     const int wm = wid >> 1, wn = wid & 1;
     const int half = lane >> 5, l31 = lane & 31;
 
-    // Persistent workgroups: the grid is (resident workgroups per CU) x 256 and workgroup w walks tiles w, w+G, w+2G ...
-    // so that every CU ends up with the same number of tiles (+-1) whatever the dispatcher does after the first wave.
-    // tile -> (cout tile, pixel tile): cout tile fastest, so concurrently running workgroups share input patches.
-    const int total_tiles = a.n_ct * a.tiles_x * a.tiles_y * a.N;
-    for (int bid = blockIdx.x; bid < total_tiles; bid += gridDim.x) {
-    const int ct = bid % a.n_ct;
-    int pt = bid / a.n_ct;
-    const int tx = pt % a.tiles_x; pt /= a.tiles_x;
-    const int ty = pt % a.tiles_y;
-    const int n = pt / a.tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - (HALO / 2), ix0 = ox0 * S - (HALO / 2);
-    const int co0 = ct * BN;
-
-    // ---- global -> register staging descriptors (constant over the K loop) ----
-    unsigned poff[NLD_P];    // byte offset of this lane's 16 B inside image n (without the chunk term)
-    bool pok[NLD_P];
+    // ---- tile-independent staging descriptors.  Everything a tile needs per DMA piece is two adds, four compares and
+    // two multiply-adds: vector-ALU instructions of a workgroup that is between tiles issue only in the gaps its
+    // neighbours' MFMAs leave (one per 64 cycles), so the per-tile scalar work is what costs. ----
+    int p_py[NLD_P], p_px[NLD_P], p_part[NLD_P];
+    bool p_live[NLD_P];
 #pragma unroll
     for (int i = 0; i < NLD_P; ++i) {
         const int v = tid + i * 256;
         const int part = v / PPAD, pix = v % PPAD;          // part = sub * 2 + half: channels part*4 .. part*4+3 of the stage
-        const int py = pix / PW, px = pix % PW;
-        const int iy = iy0 + py, ix = ix0 + px;
-        pok[i] = v < PATCH_V4 && pix < PH * PW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        poff[i] = pok[i] ? (unsigned)((((size_t)iy * a.W + ix) * a.Cin + part * 4) * sizeof(float)) : 0u;
+        p_py[i] = pix / PW; p_px[i] = pix % PW; p_part[i] = part * 4;
+        p_live[i] = v < PATCH_V4 && pix < PH * PW;
     }
-    unsigned woff[NLD_W];    // byte offset inside the packed weights (without the chunk term)
+    unsigned woff0[NLD_W];   // byte offset inside the packed weights without the cout-tile and chunk terms
     bool wok[NLD_W];
     const size_t w_chunk_stride = (size_t)a.cout_pad * KC;                 // floats between cin chunks
     const size_t w_tap_stride = (size_t)(a.Cin / KC) * w_chunk_stride;     // floats between taps
@@ -131,28 +117,8 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
         const int th = v / BN, co_l = v % BN;
         const int tap = th >> 1, hf = th & 1;
         const size_t tap_stride = TAPS == 4 ? w_chunk_stride : w_tap_stride;   // a virtual tap is the next cin chunk
-        woff[i] = wok[i] ? (unsigned)(((size_t)tap * tap_stride + ((size_t)hf * a.cout_pad + co0 + co_l) * 4) * sizeof(float)) : 0u;
+        woff0[i] = wok[i] ? (unsigned)(((size_t)tap * tap_stride + ((size_t)hf * a.cout_pad + co_l) * 4) * sizeof(float)) : 0u;
     }
-    const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * a.Cin);   // uniform
-    const unsigned lds_patch0 = lds_addr_of(&s_patch[0][0]) + wave_s * 1024u;    // uniform (wave_s is an SGPR value)
-    const unsigned lds_w0 = lds_addr_of(&s_w[0][0]) + wave_s * 1024u;
-
-    auto stage = [&](int chunk, int buf) {
-        const char *pbase = in_n + (size_t)chunk * (KSTAGE * sizeof(float));
-        const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * sizeof(float);
-#pragma unroll
-        for (int i = 0; i < NLD_P; ++i)
-            if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * 256) * 16u);
-#pragma unroll
-        for (int i = 0; i < NLD_W; ++i)
-            if (wok[i]) lds_dma16(wbase, woff[i], lds_w0 + (unsigned)(buf * W_PAD + i * 256) * 16u);
-    };
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < NLD_P; ++i) s_patch[b][tid + i * 256] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
     // ---- per-lane LDS read offsets (float4 units) ----
     int a_off[MB];
 #pragma unroll
@@ -164,7 +130,59 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     int b_off[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) b_off[nb] = half * BN + wn * WN + nb * 32 + l31;
+    const unsigned lds_patch0 = lds_addr_of(&s_patch[0][0]) + wave_s * 1024u;    // uniform (wave_s is an SGPR value)
+    const unsigned lds_w0 = lds_addr_of(&s_w[0][0]) + wave_s * 1024u;
 
+    // Persistent workgroups: the grid is (resident workgroups per CU) x 256 and workgroup w walks tiles w, w+G, w+2G ...
+    // so that every CU ends up with the same number of tiles (+-1) whatever the dispatcher does after the first wave.
+    // XCD-aware order: consecutive workgroup ids land on consecutive XCDs (8 of them, each with its own L2), so the walk
+    // index is split as (xcd = it % 8, j = it / 8) and the n_ct cout tiles of ONE pixel tile are given to consecutive j of
+    // the SAME xcd: they run at the same time on the same L2 and the input patch is fetched from HBM once, not n_ct times.
+    const int n_pt = a.tiles_x * a.tiles_y * a.N;
+    const int total_walk = ((n_pt + 7) / 8) * 8 * a.n_ct;
+    for (int it = blockIdx.x; it < total_walk; it += gridDim.x) {
+    const int xcd = it & 7, j = it >> 3;
+    const int ct = j % a.n_ct;
+    int pt = (j / a.n_ct) * 8 + xcd;
+    if (pt >= n_pt) continue;
+    const int tx = pt % a.tiles_x; pt /= a.tiles_x;
+    const int ty = pt % a.tiles_y;
+    const int n = pt / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - (HALO / 2), ix0 = ox0 * S - (HALO / 2);
+    const int co0 = ct * BN;
+
+    unsigned poff[NLD_P];    // byte offset of this lane's 16 B inside image n (without the chunk term)
+    bool pok[NLD_P];
+#pragma unroll
+    for (int i = 0; i < NLD_P; ++i) {
+        const int iy = iy0 + p_py[i], ix = ix0 + p_px[i];
+        pok[i] = p_live[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        poff[i] = pok[i] ? (unsigned)(((iy * a.W + ix) * a.Cin + p_part[i]) * (int)sizeof(float)) : 0u;
+    }
+    const unsigned w_co0 = (unsigned)(co0 * 4 * sizeof(float));
+    const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * a.Cin);   // uniform
+
+    auto stage = [&](int chunk, int buf) {
+        const char *pbase = in_n + (size_t)chunk * (KSTAGE * sizeof(float));
+        const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * sizeof(float);
+#pragma unroll
+        for (int i = 0; i < NLD_P; ++i)
+            if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * 256) * 16u);
+#pragma unroll
+        for (int i = 0; i < NLD_W; ++i)
+            if (wok[i]) lds_dma16(wbase, woff0[i] + w_co0, lds_w0 + (unsigned)(buf * W_PAD + i * 256) * 16u);
+    };
+    // a DMA piece outside the image is skipped and must read as zero: clear both stages first when this tile's patch
+    // sticks out of the image (uniform decision; interior tiles overwrite every slot they read)
+    const bool border = iy0 < 0 || ix0 < 0 || iy0 + PH > a.H || ix0 + PW > a.W;
+    if (border) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < NLD_P; ++i) s_patch[b][tid + i * 256] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
     f32x16 acc[MB][NB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -207,10 +225,10 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mb].x, bv[cur][nb].x, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mb].y, bv[cur][nb].y, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mb].z, bv[cur][nb].z, acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mb].w, bv[cur][nb].w, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][nb].x, av[cur][mb].x, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][nb].y, av[cur][mb].y, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][nb].z, av[cur][mb].z, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][nb].w, av[cur][mb].w, acc[mb][nb], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -222,29 +240,35 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     }
     if (n_chunks & 1) chunk_step(n_chunks - 1, std::integral_constant<int, 0>{});
 
-    // ---- epilogue: bias (+ReLU) (+gate * y + residual), NHWC store; C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5) ----
+    // ---- epilogue: bias (+ReLU) (+gate * y + residual), NHWC store.  The weights are the MFMA "A" operand, so a lane
+    // holds ONE pixel (column lane&31 of the block) and 16 channels: rows (r&3) + 8*(r>>2) + 4*(lane>>5), i.e. four runs of
+    // four consecutive channels -> float4 bias / residual loads and float4 stores, one address per pixel. ----
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int col = co0 + wn * WN + nb * 32 + l31;
-        if (col >= a.cout_gemm) continue;
-        const float bias = a.bias[col];
-        int co = col, sub = 0;
-        if (a.up > 1) { sub = col / a.cout_real; co = col - sub * a.cout_real; }
-        const int sy = a.up > 1 ? sub / a.up : 0, sx = a.up > 1 ? sub % a.up : 0;
+    for (int mb = 0; mb < MB; ++mb) {
+        const int q = mb * 32 + l31;
+        const int oy = oy0 + wm * (TH / 2) + q / TW, ox = ox0 + q % TW;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const size_t pix = ((size_t)n * a.OH + oy) * a.OW + ox;
+        const float gate = a.gate ? a.gate[pix] : 0.f;
+        const float *rrow = a.gate ? a.resid + pix * a.resid_cstride : nullptr;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
+        for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int q = mb * 32 + row;
-                const int oy = oy0 + wm * (TH / 2) + q / TW, ox = ox0 + q % TW;
-                if (oy >= a.OH || ox >= a.OW) continue;
-                float y = acc[mb][nb][r] + bias;
-                if (a.relu) y = fmaxf(y, 0.f);
-                const size_t pix = ((size_t)n * a.OH + oy) * a.OW + ox;
-                if (a.gate) y = fmaf(a.gate[pix], y, a.resid[pix * a.resid_cstride + co]);
+            for (int g = 0; g < 4; ++g) {
+                const int col = co0 + wn * WN + nb * 32 + 8 * g + 4 * half;
+                if (col >= a.cout_gemm) continue;
+                const float4 bias = *(const float4 *)(a.bias + col);
+                float4 y = make_float4(acc[mb][nb][4 * g] + bias.x, acc[mb][nb][4 * g + 1] + bias.y,
+                                       acc[mb][nb][4 * g + 2] + bias.z, acc[mb][nb][4 * g + 3] + bias.w);
+                if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                int co = col, sy = 0, sx = 0;
+                if (a.up > 1) { const int sub = col / a.cout_real; co = col - sub * a.cout_real; sy = sub / a.up; sx = sub % a.up; }
+                if (a.gate) {
+                    const float4 r = *(const float4 *)(rrow + co);
+                    y.x = fmaf(gate, y.x, r.x); y.y = fmaf(gate, y.y, r.y); y.z = fmaf(gate, y.z, r.z); y.w = fmaf(gate, y.w, r.w);
+                }
                 const size_t opix = a.up > 1 ? ((size_t)n * a.OH * a.up + (oy * a.up + sy)) * ((size_t)a.OW * a.up) + (ox * a.up + sx) : pix;
-                a.out[opix * a.out_cstride + a.out_coff + co] = y;
+                *(float4 *)(a.out + opix * a.out_cstride + a.out_coff + co) = y;
             }
         }
     }
@@ -267,7 +291,8 @@ int launch(ConvArgs a, hipStream_t s) {
             per_cu = 1;
         resident = per_cu * cus;
     }
-    const long long blocks = tiles < resident ? tiles : resident;
+    long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;   // a multiple of 8: workgroup id % 8 = its XCD
+    if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
     hipLaunchKernelGGL((k_conv<TH, TW, BN, S, TAPS>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return 0;
 }
@@ -284,6 +309,8 @@ extern "C" int hvpr_conv2d_nhwc_f32(const float *in, int N, int H, int W, int Ci
     const bool wide1x1 = taps == 1 && Cin % (4 * KC) == 0;   // four cin chunks per LDS stage
     if (taps == 1 && stride != 1) return HVPR_ERR_UNSUPPORTED;
     if (up > 1 && (taps != 1 || gate)) return HVPR_ERR_UNSUPPORTED;
+    // the epilogue moves four consecutive channels per access
+    if (cout % 4 != 0 || out_cstride % 4 != 0 || out_coff % 4 != 0 || (resid && resid_cstride % 4 != 0)) return HVPR_ERR_UNSUPPORTED;
     ConvArgs a;
     a.in = in; a.wpk = w_packed; a.bias = bias; a.out = out; a.gate = gate; a.resid = resid;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin;
