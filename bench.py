@@ -250,7 +250,7 @@ def main():
                                                                      "unit": "frames/s", "ms_per_frame": round(1e3 * dt_single / args.steps, 4)},
         "stage_ms": {"voxelize+vfe+memory+scatter": round(float(stage[0]), 4), "backbone+head+decode": round(float(stage[1]), 4),
                      "topk+nms": round(float(stage[2]), 4)},
-        "roofline": {"kernel": "VFE+scatter group (4 voxelize launches, pillar VFE, memory read-out, cell map, scatter)",
+        "roofline": {"kernel": "VFE+scatter group (4 voxelize launches, pillar VFE, memory read-out + cell map, scatter): 7 launches, event-to-event",
                      "bound": "hbm", "achieved": round(group_bytes / group_s / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(group_bytes / group_s / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": group_bytes,
                      "avg_duration_us": round(group_s * 1e6, 2),
