@@ -212,6 +212,26 @@ int hvpr_ball_query_f32(const float *xyz, const float *new_xyz, int B, int N, in
 int hvpr_three_nn_f32(const float *unknown, const float *known, int B, int n, int m, float *dist, int32_t *idx,
                       hvpr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * f2 ("next" row)  KITTI point pre-processing in front of the voxelizer, on the device.
+ *     hvpr_point_flags_f32  mode 0: mask_points_by_range (pcdet/utils/common_utils.py:59-62: x,y in [lo,hi] inclusive;
+ *                           range_xy = {x0,y0,x1,y1}) AND, when the two fov matrices are given, KittiDataset.get_fov_flag
+ *                           (pcdet/datasets/kitti/kitti_dataset.py:100-116; fov_lidar_to_rect = (V2C^T R0^T) [4][3],
+ *                           fov_rect_to_img = P2^T [4][3], both row-major float32 as calibration_kitti.py:65-84 forms them);
+ *                           mode 1: the near flag of DataProcessor.sample_points (data_processor.py:89-90): |xyz| < near_thresh.
+ *                           points [n, stride] f32 with x,y,z in columns 0..2; flags [n] u8.
+ *     hvpr_compact_rows_f32 dst = src[flags != 0] (stable), *count = number of rows (clamped to capacity).
+ *     hvpr_gather_rows_f32  dst[r] = src[idx[r]] (points[choice] of sample_points; idx i32, out-of-range rows are zeros).
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_point_flags_f32(const float *points, int n, int stride, int mode, const float *range_xy, float near_thresh,
+                         const float *fov_lidar_to_rect, const float *fov_rect_to_img, int img_h, int img_w, uint8_t *flags,
+                         hvpr_stream_t stream);
+size_t hvpr_compact_workspace_bytes(int n);
+int hvpr_compact_rows_f32(const float *src, int n, int row_floats, const uint8_t *flags, float *dst, int capacity,
+                          int32_t *count, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+int hvpr_gather_rows_f32(const float *src, int n_src, int row_floats, const int32_t *idx, int m, float *dst,
+                         hvpr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

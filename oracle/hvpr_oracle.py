@@ -567,3 +567,62 @@ def three_nn(unknown, known):
             idx[b, i] = order
             dist[b, i] = np.sqrt(d[order])
     return dist, idx
+
+
+# ----------------------------------------------------------------------------------------
+# f2  KITTI point pre-processing — numpy restatement, pinned by fixture G11 to the reference's
+# DataProcessor / Calibration / get_fov_flag run in the build container.
+# ----------------------------------------------------------------------------------------
+def mask_points_by_range(points, limit_range):
+    """pcdet/utils/common_utils.py:59-62: x and y only, both ends inclusive."""
+    p = _f32(points)
+    r = _f32(limit_range)
+    return (p[:, 0] >= r[0]) & (p[:, 0] <= r[3]) & (p[:, 1] >= r[1]) & (p[:, 1] <= r[4])
+
+
+def _dot4(xyz, m):
+    """[x,y,z,1] @ m (4,3) in fp32, left to right, no FMA (the order the HIP kernel uses)."""
+    x, y, z = xyz[:, 0:1], xyz[:, 1:2], xyz[:, 2:3]
+    return (((x * m[0] + y * m[1]).astype(np.float32) + z * m[2]).astype(np.float32) + m[3]).astype(np.float32)
+
+
+def fov_flag(points_xyz, V2C, R0, P2, img_shape):
+    """Calibration.lidar_to_rect + rect_to_img (pcdet/utils/calibration_kitti.py:65-84) + KittiDataset.get_fov_flag
+    (pcdet/datasets/kitti/kitti_dataset.py:100-116).  All float32."""
+    A = np.dot(_f32(V2C).T, _f32(R0).T).astype(np.float32)      # (4,3), formed exactly as calibration_kitti.py:71 does
+    Pt = _f32(P2).T                                              # (4,3)
+    rect = _dot4(_f32(points_xyz), A)
+    hom = _dot4(rect, Pt)
+    u, v = hom[:, 0] / rect[:, 2], hom[:, 1] / rect[:, 2]
+    depth = hom[:, 2] - Pt[3, 2]
+    return (u >= 0) & (u < img_shape[1]) & (v >= 0) & (v < img_shape[0]) & (depth >= 0)
+
+
+def near_flag(points, thresh=40.0):
+    p = _f32(points)
+    return np.sqrt(((p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]).astype(np.float32) + p[:, 2] * p[:, 2]).astype(np.float32)) < np.float32(thresh)
+
+
+def sample_points_choice(near, num_points, rng):
+    """The index selection of DataProcessor.sample_points (pcdet/datasets/processor/data_processor.py:77-108) with the
+    same sequence of RNG calls (`rng` offers choice / shuffle like numpy.random), including the redundant first draw."""
+    n = len(near)
+    if num_points == -1:
+        return np.arange(n)
+    if num_points < n:
+        far_idx = np.where(near == 0)[0]
+        near_idx = np.where(near == 1)[0]
+        picked = rng.choice(near_idx, num_points - len(far_idx), replace=False)      # drawn unconditionally (:93)
+        if num_points > len(far_idx):
+            picked = rng.choice(near_idx, num_points - len(far_idx), replace=False)
+            choice = np.concatenate((picked, far_idx), axis=0) if len(far_idx) > 0 else picked
+        else:
+            choice = rng.choice(np.arange(0, n, dtype=np.int32), num_points, replace=False)
+        rng.shuffle(choice)
+    else:
+        choice = np.arange(0, n, dtype=np.int32)
+        if num_points > n:
+            extra = rng.choice(choice, num_points - n, replace=False)
+            choice = np.concatenate((choice, extra), axis=0)
+        rng.shuffle(choice)
+    return choice

@@ -424,6 +424,54 @@ def g10_train_memory(R):
                         memory_att_nnz=(mem["att"] > 0).sum(1).numpy())
 
 
+def g11_preprocess(R):
+    """Point pre-processing: range mask, KITTI FOV flag, sample_points (reference code, numpy RNG seeded)."""
+    import ast
+    _stub("pcdet.datasets", os.path.join(REF, "pcdet/datasets"))
+    _stub("pcdet.datasets.processor", os.path.join(REF, "pcdet/datasets/processor"))
+    dp = _load("pcdet.datasets.processor.data_processor", "pcdet/datasets/processor/data_processor.py")
+    calib_mod = _load("pcdet.utils.calibration_kitti", "pcdet/utils/calibration_kitti.py")
+    # get_fov_flag lives in a module that imports the whole dataset stack: take the function's own source out of the file
+    tree = ast.parse(open(os.path.join(REF, "pcdet/datasets/kitti/kitti_dataset.py")).read())
+    fn = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "get_fov_flag"][0]
+    fn.decorator_list = []
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "kitti_dataset.py", "exec"), ns)
+    get_fov_flag = ns["get_fov_flag"]
+
+    rng = np.random.default_rng(1111)
+    n = 3000
+    mix = np.where(rng.random((n - 8, 1)) < 0.8, rng.uniform([-10, -30, -3, 0], [36, 30, 1, 1], (n - 8, 4)),
+                   rng.uniform([-10, -45, -3, 0], [80, 45, 1, 1], (n - 8, 4)))      # ~12 % beyond 40 m
+    pts = np.concatenate([mix,
+                          [[0, -39.68, 0, 0], [69.12, 39.68, 0, 0], [69.12001, 0, 0, 0], [-1e-6, 0, 0, 0], [0, 0, 0, 0],
+                           [30, 0, -1, 0.5], [39.99, 0.5, 0.3, 0.1], [40.5, 1, -1, 0.2]]]).astype(np.float32)
+    rngr = np.array([0, -39.68, -3, 69.12, 39.68, 1], np.float32)
+    mask = R.common_utils.mask_points_by_range(pts, rngr)
+    calib = {"P2": np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]], np.float32),
+             "R0": np.array([[0.9999239, 0.00983776, -0.007445048], [-0.009869795, 0.9999421, -0.004278459],
+                             [0.007402527, 0.004351614, 0.9999631]], np.float32),
+             "Tr_velo2cam": np.array([[0.007533745, -0.9999714, -0.000616602, -0.004069766],
+                                      [0.01480249, 0.0007280733, -0.9998902, -0.07631618],
+                                      [0.9998621, 0.00752379, 0.01480755, -0.2717806]], np.float32)}
+    C = calib_mod.Calibration(calib)
+    img_shape = np.array([375, 1242], np.int32)
+    fov = get_fov_flag(C.lidar_to_rect(pts[:, 0:3]), img_shape, C)
+    cases = {}
+    proc = dp.DataProcessor([], rngr, training=False)
+    for tag, m, num in (("down", 2500, 1024), ("down_more_far", 2500, 700), ("up", 700, 1024), ("same", 1024, 1024)):
+        np.random.seed(7 + num + m)
+        sub = pts[:m].copy()
+        out = proc.sample_points({"points": sub.copy()}, config=EasyDict(NUM_POINTS={"train": num, "test": num}))["points"]
+        cases[tag + "_in"] = sub
+        cases[tag + "_out"] = out
+        cases[tag + "_seed"] = np.int64(7 + num + m)
+        cases[tag + "_num"] = np.int64(num)
+    np.savez_compressed(os.path.join(OUT, "g11_preprocess.npz"), points=pts, range=rngr, range_mask=mask, fov=fov,
+                        P2=calib["P2"], R0=calib["R0"], V2C=calib["Tr_velo2cam"], img_shape=img_shape, **cases)
+    print("g11 ok: range keeps", int(mask.sum()), "fov keeps", int(fov.sum()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     R = load_reference()
@@ -435,6 +483,7 @@ if __name__ == "__main__":
     g8_assigner_losses(R)
     g9_onecycle(R)
     g10_train_memory(R)
+    g11_preprocess(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")
