@@ -1,0 +1,338 @@
+// a5 (optional precision mode) — the BEV backbone convolutions on the bf16 matrix cores with 3-term split operands:
+//   x = x_hi + x_lo (two bf16, round-to-nearest),  w = w_hi + w_lo   ->   x*w ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (dropped term ~2^-16 relative: "bf16x3").  SURVEY.md §8d allows a
+// reduced-precision path "evidenced within tolerance" (north_star: feature tensors within 1e-3 relative of fp32); the exact
+// fp32 kernel (conv_igemm.hip) stays the default and the parity reference.  Same implicit-GEMM structure as k_conv:
+// NHWC, LDS-DMA double buffer, persistent XCD-aware tile walk, weights as the MFMA "A" operand.
+//
+// Split-bf16 NHWC: every group of 8 channels of a pixel is stored as [8 x bf16 hi | 8 x bf16 lo] = 32 bytes — the same
+// footprint and addressing as 8 fp32 channels, so staging moves the same 16-byte pieces.  One MFMA consumes K = 16 channels:
+// lanes 0-31 supply the 8 channels of the even chunk, lanes 32-63 those of the odd chunk.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int KC = 8;
+
+__device__ __forceinline__ void lds_dma16(const void *sbase_uniform, unsigned voff_bytes, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(sbase_uniform), "s"(lds_dst_uniform)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ bf16x8 as_bf(float4 v) {
+    union { float4 f; bf16x8 b; } u;
+    u.f = v;
+    return u.b;
+}
+// x -> (hi, lo): hi = rne_bf16(x), lo = rne_bf16(x - hi); returned as the 16 bits of each
+__device__ __forceinline__ void split1(float x, unsigned &hi, unsigned &lo) {
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    hi = (unsigned)__builtin_bit_cast(unsigned short, h);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+
+struct Conv3Args {
+    const float4 *in;     // split-bf16 NHWC: [N, H, W, Cin/8][hi 16 B | lo 16 B]
+    const float4 *wpk;    // [TAPS, Cin/8, 2 (hi|lo), CoutPad] x 16 B (8 x bf16 over the chunk's input channels)
+    const float *bias;    // [CoutPad]
+    void *out;            // fp32 NHWC [N, OH, OW, out_cstride] or split-bf16 NHWC with out_cstride channels
+    const float *gate;    // [N, OH, OW] or null
+    const float4 *resid;  // split-bf16 NHWC, resid_cstride channels, or null
+    int N, H, W, Cin, OH, OW, cout_gemm, cout_pad, out_cstride, out_coff, resid_cstride, relu, out_split;
+    int tiles_x, tiles_y, n_ct;
+};
+
+template <int TH, int TW, int BN, int S>
+__global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
+    constexpr int TAPS = 9, HALO = 2, NSUB = 2, KSTAGE = KC * NSUB;
+    constexpr int BM = TH * TW;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MB = WM / 32, NB = WN / 32;
+    static_assert(MB >= 1 && NB >= 1, "wave tile must hold at least one 32x32 block");
+    constexpr int PH = (TH - 1) * S + 1 + HALO, PW = (TW - 1) * S + 1 + HALO;
+    constexpr int PPAD = (PH * PW + 63) / 64 * 64;
+    constexpr int PATCH_V4 = NSUB * 2 * PPAD;          // patch   [sub][hi|lo][PPAD]
+    constexpr int W_V4 = TAPS * NSUB * 2 * BN;         // weights [tap][sub][hi|lo][BN]
+    constexpr int NLD_P = (PATCH_V4 + 255) / 256, NLD_W = (W_V4 + 255) / 256;
+    constexpr int PATCH_PAD = NLD_P * 256, W_PAD = NLD_W * 256;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    float4 *s_patch = smem;                            // [2][PATCH_PAD]
+    float4 *s_w = smem + 2 * PATCH_PAD;                // [2][W_PAD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned wave_s = __builtin_amdgcn_readfirstlane((unsigned)(threadIdx.x >> 6));
+    const int wm = wid >> 1, wn = wid & 1;
+    const int half = lane >> 5, l31 = lane & 31;       // half = which 8-channel chunk of the K=16 step this lane feeds
+
+    int p_py[NLD_P], p_px[NLD_P], p_part[NLD_P];
+    bool p_live[NLD_P];
+#pragma unroll
+    for (int i = 0; i < NLD_P; ++i) {
+        const int v = tid + i * 256;
+        const int part = v / PPAD, pix = v % PPAD;     // part = sub * 2 + (hi|lo): 16-byte piece `part` of the stage's 64 bytes
+        p_py[i] = pix / PW; p_px[i] = pix % PW; p_part[i] = part;
+        p_live[i] = v < PATCH_V4 && pix < PH * PW;
+    }
+    unsigned woff0[NLD_W];
+    bool wok[NLD_W];
+    const size_t w_chunk_stride = (size_t)a.cout_pad * 2;              // float4 units between cin chunks
+    const size_t w_tap_stride = (size_t)(a.Cin / KC) * w_chunk_stride;
+#pragma unroll
+    for (int i = 0; i < NLD_W; ++i) {
+        const int v = tid + i * 256;                                   // = ((tap*NSUB + sub)*2 + hl)*BN + co_local
+        wok[i] = v < W_V4;
+        const int co_l = v % BN, r = v / BN;
+        const int hl = r & 1, sub = (r >> 1) % NSUB, tap = (r >> 1) / NSUB;
+        woff0[i] = wok[i] ? (unsigned)(((size_t)tap * w_tap_stride + (size_t)sub * w_chunk_stride + (size_t)hl * a.cout_pad + co_l) * 16) : 0u;
+    }
+    int a_off[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int q = mb * 32 + l31;
+        const int py = wm * (TH / 2) + q / TW, px = q % TW;
+        a_off[mb] = (half * 2) * PPAD + (py * S) * PW + px * S;        // hi plane of this lane's chunk; lo plane = + PPAD
+    }
+    int b_off[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b_off[nb] = (half * 2) * BN + wn * WN + nb * 32 + l31;   // hi; lo = + BN; next tap = + NSUB*2*BN
+    const unsigned lds_patch0 = lds_addr_of(s_patch) + wave_s * 1024u;
+    const unsigned lds_w0 = lds_addr_of(s_w) + wave_s * 1024u;
+
+    const int n_pt = a.tiles_x * a.tiles_y * a.N;
+    const int total_walk = ((n_pt + 7) / 8) * 8 * a.n_ct;
+    const int n_chunks = a.Cin / KSTAGE;
+    for (int it = blockIdx.x; it < total_walk; it += gridDim.x) {
+    const int xcd = it & 7, j = it >> 3;
+    const int ct = j % a.n_ct;
+    int pt = (j / a.n_ct) * 8 + xcd;
+    if (pt >= n_pt) continue;
+    const int tx = pt % a.tiles_x; pt /= a.tiles_x;
+    const int ty = pt % a.tiles_y;
+    const int n = pt / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int co0 = ct * BN;
+
+    unsigned poff[NLD_P];
+    bool pok[NLD_P];
+#pragma unroll
+    for (int i = 0; i < NLD_P; ++i) {
+        const int iy = iy0 + p_py[i], ix = ix0 + p_px[i];
+        pok[i] = p_live[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        poff[i] = pok[i] ? (unsigned)(((iy * a.W + ix) * (a.Cin / 4) + p_part[i]) * 16) : 0u;   // Cin/8 groups x 2 pieces
+    }
+    const unsigned w_co0 = (unsigned)(co0 * 16);
+    const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * (a.Cin / 4));
+
+    auto stage = [&](int chunk, int buf) {
+        const char *pbase = in_n + (size_t)chunk * (NSUB * 32);
+        const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * 16;
+#pragma unroll
+        for (int i = 0; i < NLD_P; ++i)
+            if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * 256) * 16u);
+#pragma unroll
+        for (int i = 0; i < NLD_W; ++i)
+            if (wok[i]) lds_dma16(wbase, woff0[i] + w_co0, lds_w0 + (unsigned)(buf * W_PAD + i * 256) * 16u);
+    };
+    const bool border = iy0 < 0 || ix0 < 0 || iy0 + PH > a.H || ix0 + PW > a.W;
+    if (border) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < NLD_P; ++i) s_patch[b * PATCH_PAD + tid + i * 256] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+    }
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    auto chunk_step = [&](int c, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
+        const float4 *sp = s_patch + BUF * PATCH_PAD;
+        const float4 *sw = s_w + BUF * W_PAD;
+        constexpr int PF = 2;
+        float4 ah[PF + 1][MB], al[PF + 1][MB], bh[PF + 1][NB], bl[PF + 1][NB];
+        auto lds_load = [&](int tap, int slot) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                ah[slot][mb] = sp[a_off[mb] + ky * PW + kx];
+                al[slot][mb] = sp[a_off[mb] + ky * PW + kx + PPAD];
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bh[slot][nb] = sw[b_off[nb] + tap * NSUB * 2 * BN];
+                bl[slot][nb] = sw[b_off[nb] + tap * NSUB * 2 * BN + BN];
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < PF; ++t) lds_load(t, t);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            if (tap + PF < TAPS) lds_load(tap + PF, (tap + PF) % (PF + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            const int cur = tap % (PF + 1);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    // small terms first, the dominant hi*hi last
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(bl[cur][nb]), as_bf(ah[cur][mb]), acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(bh[cur][nb]), as_bf(al[cur][mb]), acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(bh[cur][nb]), as_bf(ah[cur][mb]), acc[mb][nb], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    stage(0, 0);
+    for (int c = 0; c + 1 < n_chunks; c += 2) {
+        chunk_step(c, std::integral_constant<int, 0>{});
+        chunk_step(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (n_chunks & 1) chunk_step(n_chunks - 1, std::integral_constant<int, 0>{});
+
+    // epilogue: a lane holds one pixel x 16 channels in four runs of four consecutive channels (8g + 4*half + 0..3)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int q = mb * 32 + l31;
+        const int oy = oy0 + wm * (TH / 2) + q / TW, ox = ox0 + q % TW;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const size_t pix = ((size_t)n * a.OH + oy) * a.OW + ox;
+        const float gate = a.gate ? a.gate[pix] : 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = co0 + wn * WN + nb * 32 + 8 * g + 4 * half;
+                if (col >= a.cout_gemm) continue;
+                const float4 bias = *(const float4 *)(a.bias + col);
+                float y[4] = {acc[mb][nb][4 * g] + bias.x, acc[mb][nb][4 * g + 1] + bias.y, acc[mb][nb][4 * g + 2] + bias.z,
+                              acc[mb][nb][4 * g + 3] + bias.w};
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+                }
+                if (a.gate) {       // residual in split form: group (col/8), 4 channels at position 4*half
+                    const uint2 *rp = (const uint2 *)(a.resid + (pix * (a.resid_cstride / 8) + col / 8) * 2);
+                    const uint2 rh = rp[half], rl = rp[2 + half];
+                    const unsigned hw[4] = {rh.x << 16, rh.x & 0xffff0000u, rh.y << 16, rh.y & 0xffff0000u};
+                    const unsigned lw[4] = {rl.x << 16, rl.x & 0xffff0000u, rl.y << 16, rl.y & 0xffff0000u};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = fmaf(gate, y[e], __uint_as_float(hw[e]) + __uint_as_float(lw[e]));
+                }
+                if (a.out_split) {
+                    unsigned h[4], l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split1(y[e], h[e], l[e]);
+                    const int oc = a.out_coff + col;
+                    uint2 *op = (uint2 *)((float4 *)a.out + (pix * (a.out_cstride / 8) + oc / 8) * 2);
+                    op[half] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    op[2 + half] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                } else {
+                    *(float4 *)((float *)a.out + pix * a.out_cstride + a.out_coff + col) = make_float4(y[0], y[1], y[2], y[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    }
+}
+
+// fp32 NHWC -> split-bf16 NHWC (one thread per 8-channel group)
+__global__ void __launch_bounds__(256) k_split(const float4 *__restrict__ src, long long groups, float4 *__restrict__ dst) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const float4 a = src[g * 2], b = src[g * 2 + 1];
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split1(x[e], h[e], l[e]);
+    uint4 hv = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    uint4 lv = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    ((uint4 *)dst)[g * 2] = hv;
+    ((uint4 *)dst)[g * 2 + 1] = lv;
+}
+
+template <int TH, int TW, int BN, int S>
+int launch3(Conv3Args a, hipStream_t s) {
+    a.tiles_x = (a.OW + TW - 1) / TW;
+    a.tiles_y = (a.OH + TH - 1) / TH;
+    a.n_ct = a.cout_pad / BN;
+    constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
+    constexpr int PPAD = (PH * PW + 63) / 64 * 64;
+    constexpr int NLD_P = (4 * PPAD + 255) / 256, NLD_W = (9 * 4 * BN + 255) / 256;
+    const size_t lds = (size_t)2 * (NLD_P + NLD_W) * 256 * 16;
+    const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
+    static int resident = 0;
+    if (resident == 0) {
+        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return HVPR_ERR_LAUNCH;
+        int per_cu = 0, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        resident = per_cu * cus;
+    }
+    long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
+    if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
+    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return HVPR_OK;
+}
+
+}  // namespace
+
+extern "C" int hvpr_split_bf16_f32(const float *src, long long n_floats, void *dst, hvpr_stream_t stream) {
+    if (!src || !dst || n_floats < 0 || n_floats % 8 != 0) return HVPR_ERR_INVALID_ARG;
+    if (n_floats == 0) return HVPR_OK;
+    const long long groups = n_floats / 8;
+    hipLaunchKernelGGL(k_split, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, groups,
+                       (float4 *)dst);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_conv2d_nhwc_bf16x3(const void *in_split, int N, int H, int W, int Cin, const void *w_split,
+                                       const float *bias, int stride, int cout, int cout_pad, int relu, const float *gate,
+                                       const void *resid_split, int resid_cstride, void *out, int out_split,
+                                       int out_cstride, int out_coff, int tile_cfg, hvpr_stream_t stream) {
+    if (!in_split || !w_split || !bias || !out || N < 1 || H < 1 || W < 1 || cout < 1) return HVPR_ERR_INVALID_ARG;
+    if ((gate == nullptr) != (resid_split == nullptr)) return HVPR_ERR_INVALID_ARG;
+    if (Cin % 16 != 0 || (stride != 1 && stride != 2)) return HVPR_ERR_UNSUPPORTED;
+    if (cout % 4 != 0 || out_cstride % 8 != 0 || out_coff % 8 != 0 || (resid_split && resid_cstride % 8 != 0)) return HVPR_ERR_UNSUPPORTED;
+    Conv3Args a;
+    a.in = (const float4 *)in_split; a.wpk = (const float4 *)w_split; a.bias = bias; a.out = out; a.gate = gate;
+    a.resid = (const float4 *)resid_split;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin;
+    a.OH = (H + 2 - 3) / stride + 1; a.OW = (W + 2 - 3) / stride + 1;
+    a.cout_gemm = cout; a.cout_pad = cout_pad; a.out_cstride = out_cstride; a.out_coff = out_coff; a.resid_cstride = resid_cstride;
+    a.relu = relu; a.out_split = out_split;
+    hipStream_t s = (hipStream_t)stream;
+    int st;
+    if (tile_cfg == 0) {            // 128 px x 64 ch
+        if (cout_pad % 64) return HVPR_ERR_INVALID_ARG;
+        st = stride == 1 ? launch3<8, 16, 64, 1>(a, s) : launch3<8, 16, 64, 2>(a, s);
+    } else if (tile_cfg == 1) {     // 64 px x 64 ch
+        if (cout_pad % 64) return HVPR_ERR_INVALID_ARG;
+        st = stride == 1 ? launch3<8, 8, 64, 1>(a, s) : launch3<8, 8, 64, 2>(a, s);
+    } else return HVPR_ERR_INVALID_ARG;
+    if (st != HVPR_OK) return st;
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
