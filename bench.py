@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one whole-frame hipGraph per step (frame latency = step) instead of the 3-stage frame pipeline")
+    ap.add_argument("--conv-precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="fp32: exact fp32 matrix-core convolutions; bf16x3: 3-term split-bf16 trunk/SFM convolutions")
     ap.add_argument("--skip-single", action="store_true", help="profiling: do not time the single-graph latency mode")
     ap.add_argument("--cls-bias", type=float, default=-4.59511985013459, help="conv_cls.bias of the synthetic weights")
     args = ap.parse_args()
@@ -163,6 +165,7 @@ def main():
     # keeps NMS_POST_MAXSIZE = 500: the post-processing runs at its maximum size
     params = synthetic_weights.load_synthetic(model, seed=0, cls_bias=args.cls_bias)
     model = model.to(device).eval()
+    model.backbone_2d.set_conv_precision(args.conv_precision)
 
     frames = [synthetic.hvpr_frame(rank * 1000 + i) for i in range(N_POOL)]
     raw_pts = int(np.mean([len(synthetic.kitti_like_frame(rank * 1000 + i)) for i in range(2)]))
@@ -184,6 +187,7 @@ def main():
         barrier()
         return distributed.max_over_ranks(time.perf_counter() - t0, device)
 
+    alt = None
     with torch.no_grad():
         if args.no_graph:
             mode = "eager launches"
@@ -203,6 +207,20 @@ def main():
                     pass
                 mode = "3-stage frame pipeline: one hipGraph replay per step = encode(k) | convolutions(k-1) | top-k+NMS(k-2) " \
                        "on three HIP streams (frame latency = 3 steps)"
+
+        if not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32" and not args.skip_single:
+            # reported next to the headline, never as `value`: the same pipeline with the trunk/SFM convolutions in bf16x3
+            model.backbone_2d.set_conv_precision("bf16x3")
+            pipe3 = detector.PipelinedForward(model, batches[0])
+            dt3 = timed(pipe3)
+            for _ in pipe3.flush():
+                pass
+            del pipe3
+            model.backbone_2d.set_conv_precision("fp32")
+            alt = {"mode": "bf16x3: trunk + SFM 3x3 convolutions as 3-term split bf16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate; "
+                           "everything else as in `value` (opt-in: HVPR_CONV_PRECISION=bf16x3)",
+                   "value": round(world * args.steps / dt3, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt3 / args.steps, 4),
+                   "tolerance": "features / boxes within 1e-3 relative of the fp32 path (tests/test_gpu_e2e.py), observed ~1e-5"}
 
         # ---- per-stage probe (untimed): HIP events on the launch stream ----
         stage = np.zeros(3)
@@ -261,6 +279,7 @@ def main():
                           "algorithmic_flops": flops, "avg_duration_us": round(float(stage[1]) * 1e3, 1),
                           "traffic": None if traffic is None else traffic.get("conv_stack_bytes")},
     }
+    res["alt_precision"] = alt
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, params)
     else:

@@ -93,6 +93,15 @@ class BaseBEVBackbone_Scale(nn.Module):
         self._shape_key = None
         self._side = None
         self.overlap_branches = os.environ.get("HVPR_BEV_STREAMS", "2") != "1"
+        # "fp32": exact fp32 matrix-core kernel (default, the parity reference).  "bf16x3": trunk and SFM 3x3 convolutions
+        # on the bf16 matrix cores with 3-term split operands (kernels.conv2d_nhwc_bf3; ~5e-6 relative error per layer)
+        self.conv_precision = os.environ.get("HVPR_CONV_PRECISION", model_cfg.get("CONV_PRECISION", "fp32"))
+        assert self.conv_precision in ("fp32", "bf16x3")
+
+    def set_conv_precision(self, precision):
+        assert precision in ("fp32", "bf16x3")
+        self.conv_precision = precision
+        self._fold.invalidate()
 
     def _side_stream(self, device):
         if self._side is None or self._side.device != device:
@@ -124,6 +133,16 @@ class BaseBEVBackbone_Scale(nn.Module):
                 lv["convs"].append(kernels.pack_conv(blk[4 + 3 * k].weight, sc, sh, tile_cfg=cfg))
             sc, sh = bn_scale_shift(self.sfmblocks_down[i][1])
             lv["sfm"] = kernels.pack_conv(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=cfg)
+            if self.conv_precision == "bf16x3":
+                c3 = 1 if h * w < 20000 else 0        # 64-pixel tiles on the small levels, 128-pixel tiles on level 0
+                lv["convs3"] = []
+                sc, sh = bn_scale_shift(blk[2])
+                lv["convs3"].append(kernels.pack_conv_bf3(blk[1].weight, sc, sh, stride=s, tile_cfg=c3))
+                for k in range(self.layer_nums[i]):
+                    sc, sh = bn_scale_shift(blk[5 + 3 * k])
+                    lv["convs3"].append(kernels.pack_conv_bf3(blk[4 + 3 * k].weight, sc, sh, tile_cfg=c3))
+                sc, sh = bn_scale_shift(self.sfmblocks_down[i][1])
+                lv["sfm3"] = kernels.pack_conv_bf3(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=c3)
             sl = self.scale_layers[i]
             sc, sh = bn_scale_shift(sl[2])
             lv["scale"] = kernels.pack_conv(sl[1].weight, sc, sh, stride=s, tile_cfg=_tile_cfg(h, w, sl[1].weight.shape[0]))
@@ -180,9 +199,16 @@ class BaseBEVBackbone_Scale(nn.Module):
         capturing = torch.cuda.is_current_stream_capturing()
         held = []     # trunk outputs the side stream reads: referenced until the join, so that the allocator of the main
         #               stream cannot hand their memory to the next level's convolutions while the branch still reads them
+        bf3 = self.conv_precision == "bf16x3"
+        if bf3:
+            x = kernels.split_bf16(x)          # the trunk runs in split-bf16 form from here on
         for i, lv in enumerate(P["levels"]):
-            for pc in lv["convs"]:
-                x = kernels.conv2d_nhwc(x, pc)
+            if bf3:
+                for pc in lv["convs3"]:
+                    x = kernels.conv2d_nhwc_bf3(x, pc)
+            else:
+                for pc in lv["convs"]:
+                    x = kernels.conv2d_nhwc(x, pc)
             if two_streams:
                 side.wait_stream(main)          # x (and y of the previous level) are ready for the branch
                 held.append(x)
@@ -193,8 +219,14 @@ class BaseBEVBackbone_Scale(nn.Module):
                 y = kernels.conv2d_nhwc(y, lv["scale"])
                 gate = kernels.spatial_gate(y, gw, gb, gs, gt)
                 x_att = x
-                for _ in range(self.sfm_layer_nums[i]):
-                    x_att = kernels.conv2d_nhwc(x_att, lv["sfm"], gate=gate, resid=x_att)
+                nsfm = self.sfm_layer_nums[i]
+                for it in range(nsfm):
+                    if bf3:     # the last step hands fp32 to the (fp32) deconvolution
+                        x_att = kernels.conv2d_nhwc_bf3(x_att, lv["sfm3"], out_split=it + 1 < nsfm, gate=gate, resid=x_att)
+                    else:
+                        x_att = kernels.conv2d_nhwc(x_att, lv["sfm"], gate=gate, resid=x_att)
+                if bf3 and nsfm == 0:
+                    raise NotImplementedError("bf16x3 path needs SFM_LAYER_NUMS >= 1 on every level")
                 kernels.conv2d_nhwc(x_att, lv["deconv"], out=out, out_coff=coff)
                 if two_streams and not capturing:     # eager mode: keep the caching allocator from recycling early
                     for t in (x, out):

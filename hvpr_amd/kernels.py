@@ -130,6 +130,57 @@ def scatter_bev_fwd(pillar, memory, scale, coords, batch, nx, ny, workspace, m_d
     return spatial, spatial_scale
 
 
+# ------------------------------------------------------------------------------------------------ bf16x3 convolutions
+class PackedConvBf3:
+    """3x3 conv weights split into bf16 hi/lo, layout [9, Cin/8, 2, cout_pad, 8] (BatchNorm scale folded), bias fp32."""
+
+    def __init__(self, w, bias, cin, cout, cout_pad, stride, relu, tile_cfg):
+        self.w, self.bias, self.cin, self.cout, self.cout_pad = w, bias, cin, cout, cout_pad
+        self.stride, self.relu, self.tile_cfg = stride, relu, tile_cfg
+
+
+def pack_conv_bf3(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=0):
+    cout, cin, kh, kw = weight.shape
+    assert kh == kw == 3 and cin % 16 == 0 and cout % 4 == 0
+    w = weight.detach().float()
+    if scale is not None:
+        w = w * scale.view(-1, 1, 1, 1)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    cout_pad = (cout + 63) // 64 * 64
+    wp = torch.zeros((9, cin // 8, 2, cout_pad, 8), dtype=torch.bfloat16, device=w.device)
+    for k, part in enumerate((hi, lo)):       # (Cout, Cin, 3, 3) -> tap, chunk, ci, co -> tap, chunk, co, ci
+        wp[:, :, k, :cout, :] = part.permute(2, 3, 1, 0).reshape(9, cin // 8, 8, cout).permute(0, 1, 3, 2)
+    b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
+    if shift is not None:
+        b[:cout] = shift.detach().float()
+    return PackedConvBf3(wp.contiguous(), b, cin, cout, cout_pad, stride, relu, tile_cfg)
+
+
+def split_bf16(x):
+    """fp32 NHWC (C % 8 == 0) -> split-bf16 NHWC, returned as an fp32-typed tensor of the same shape (opaque bytes)."""
+    assert x.is_contiguous() and x.shape[-1] % 8 == 0
+    out = torch.empty_like(x)
+    check(lib().hvpr_split_bf16_f32(_ptr(x, torch.float32, "activations"), x.numel(), out.data_ptr(), _stream()), "hvpr_split_bf16_f32")
+    return out
+
+
+def conv2d_nhwc_bf3(xs, pc, out_split=True, gate=None, resid=None, out=None, out_coff=0):
+    """xs: split-bf16 NHWC (N,H,W,Cin).  Returns split-bf16 NHWC (out_split) or fp32 NHWC."""
+    N, H, W, cin = xs.shape
+    assert cin == pc.cin
+    OH, OW = (H + 2 - 3) // pc.stride + 1, (W + 2 - 3) // pc.stride + 1
+    if out is None:
+        out = torch.empty((N, OH, OW, pc.cout), dtype=torch.float32, device=xs.device)
+    assert out.shape[:3] == (N, OH, OW) and out.is_contiguous()
+    check(lib().hvpr_conv2d_nhwc_bf16x3(_ptr(xs, torch.float32, "conv input"), N, H, W, cin, pc.w.data_ptr(), pc.bias.data_ptr(),
+                                        pc.stride, pc.cout, pc.cout_pad, 1 if pc.relu else 0, _ptr(gate, torch.float32, "gate"),
+                                        _ptr(resid, torch.float32, "resid"), 0 if resid is None else resid.shape[-1],
+                                        out.data_ptr(), 1 if out_split else 0, out.shape[-1], out_coff, pc.tile_cfg, _stream()),
+          "hvpr_conv2d_nhwc_bf16x3")
+    return out
+
+
 def memory_scatter_fwd(pillar, scale, coords, bank, k, batch, nx, ny, workspace, m_device=None, out=None):
     """Fused a3+a4 (64+64+32 channels): returns memory_features (M,64), spatial (B,128,ny,nx), spatial_scale (B,32,ny,nx).
     `out` = (spatial, spatial_scale) as returned by an earlier call: write into those canvases instead of new ones."""
