@@ -52,12 +52,15 @@ struct Conv3Args {
     int tiles_x, tiles_y, n_ct;
 };
 
-template <int TH, int TW, int BN, int S>
+// WGM x WGN = the 4 waves of a workgroup along pixels x channels (2 x 2, or 4 x 1 for the 256-pixel tile)
+template <int TH, int TW, int BN, int S, int WGM>
 __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
     constexpr int TAPS = 9, HALO = 2, NSUB = 2, KSTAGE = KC * NSUB;
+    constexpr int WGN = 4 / WGM;
     constexpr int BM = TH * TW;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MB = WM / 32, NB = WN / 32;
+    static_assert(TH % WGM == 0 && (TH / WGM) * TW == WM, "a wave owns whole tile rows");
     static_assert(MB >= 1 && NB >= 1, "wave tile must hold at least one 32x32 block");
     constexpr int PH = (TH - 1) * S + 1 + HALO, PW = (TW - 1) * S + 1 + HALO;
     constexpr int PPAD = (PH * PW + 63) / 64 * 64;
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned wave_s = __builtin_amdgcn_readfirstlane((unsigned)(threadIdx.x >> 6));
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WGN, wn = wid % WGN;
     const int half = lane >> 5, l31 = lane & 31;       // half = which 8-channel chunk of the K=16 step this lane feeds
 
     int p_py[NLD_P], p_px[NLD_P], p_part[NLD_P];
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int q = mb * 32 + l31;
-        const int py = wm * (TH / 2) + q / TW, px = q % TW;
+        const int py = wm * (TH / WGM) + q / TW, px = q % TW;
         a_off[mb] = (half * 2) * PPAD + (py * S) * PW + px * S;        // hi plane of this lane's chunk; lo plane = + PPAD
     }
     int b_off[NB];
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int q = mb * 32 + l31;
-        const int oy = oy0 + wm * (TH / 2) + q / TW, ox = ox0 + q % TW;
+        const int oy = oy0 + wm * (TH / WGM) + q / TW, ox = ox0 + q % TW;
         if (oy >= a.OH || ox >= a.OW) continue;
         const size_t pix = ((size_t)n * a.OH + oy) * a.OW + ox;
         const float gate = a.gate ? a.gate[pix] : 0.f;
@@ -270,7 +273,7 @@ __global__ void __launch_bounds__(256) k_split(const float4 *__restrict__ src, l
     ((uint4 *)dst)[g * 2 + 1] = lv;
 }
 
-template <int TH, int TW, int BN, int S>
+template <int TH, int TW, int BN, int S, int WGM>
 int launch3(Conv3Args a, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
@@ -282,17 +285,17 @@ int launch3(Conv3Args a, hipStream_t s) {
     const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
     static int resident = 0;
     if (resident == 0) {
-        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return HVPR_ERR_LAUNCH;
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         resident = per_cu * cus;
     }
     long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
     if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
-    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     return HVPR_OK;
 }
 
@@ -327,10 +330,14 @@ extern "C" int hvpr_conv2d_nhwc_bf16x3(const void *in_split, int N, int H, int W
     int st;
     if (tile_cfg == 0) {            // 128 px x 64 ch
         if (cout_pad % 64) return HVPR_ERR_INVALID_ARG;
-        st = stride == 1 ? launch3<8, 16, 64, 1>(a, s) : launch3<8, 16, 64, 2>(a, s);
+        st = stride == 1 ? launch3<8, 16, 64, 1, 2>(a, s) : launch3<8, 16, 64, 2, 2>(a, s);
     } else if (tile_cfg == 1) {     // 64 px x 64 ch
         if (cout_pad % 64) return HVPR_ERR_INVALID_ARG;
-        st = stride == 1 ? launch3<8, 8, 64, 1>(a, s) : launch3<8, 8, 64, 2>(a, s);
+        st = stride == 1 ? launch3<8, 8, 64, 1, 2>(a, s) : launch3<8, 8, 64, 2, 2>(a, s);
+    } else if (tile_cfg == 2) {     // 256 px x 64 ch, waves 4 x 1 (each 64 px x 64 ch): stride 1 only
+        if (cout_pad % 64) return HVPR_ERR_INVALID_ARG;
+        if (stride != 1) return HVPR_ERR_UNSUPPORTED;
+        st = launch3<16, 16, 64, 1, 4>(a, s);
     } else return HVPR_ERR_INVALID_ARG;
     if (st != HVPR_OK) return st;
     HVPR_CHECK_LAUNCH();
