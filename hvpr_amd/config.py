@@ -64,3 +64,8 @@ CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfgs")
 
 def hvpr_car_cfg():
     return cfg_from_yaml_file(os.path.join(CFG_DIR, "kitti_models", "hvpr_car.yaml"))
+
+
+def hvpr_3class_cfg():
+    """BASELINE.json configs[3]: Car / Pedestrian / Cyclist, 6 anchors per location."""
+    return cfg_from_yaml_file(os.path.join(CFG_DIR, "kitti_models", "hvpr_3class.yaml"))

@@ -488,8 +488,11 @@ def forward_frames(frames, params, cfg, stages=None, timings=None):
     inter["spatial_features_2d"] = f2d
     cls, box, dirp = head_forward(f2d, _sub(params, "dense_head."))
     stride = cfg["feature_map_stride"]
-    anchors = generate_anchors(rng, (nx // stride, ny // stride), cfg["anchor_sizes"], cfg["anchor_rotations"],
-                               cfg["anchor_bottom_heights"])
+    # one anchor block per class config, concatenated along the size axis (anchor_head_template.py:296 cats dim=-3)
+    acfgs = cfg.get("anchor_configs") or [dict(anchor_sizes=cfg["anchor_sizes"], anchor_rotations=cfg["anchor_rotations"],
+                                                 anchor_bottom_heights=cfg["anchor_bottom_heights"])]
+    anchors = torch.cat([generate_anchors(rng, (nx // stride, ny // stride), a["anchor_sizes"], a["anchor_rotations"],
+                                          a["anchor_bottom_heights"]) for a in acfgs], dim=-3)
     bc, bb = generate_predicted_boxes(cls, box, dirp, anchors, cfg["dir_offset"], cfg["dir_limit_offset"], cfg["num_dir_bins"])
     lap("head_decode")
     inter.update(batch_cls_preds=bc, batch_box_preds=bb)
@@ -510,6 +513,8 @@ def cfg_from_model_cfg(cfg):
                 sfm_layer_nums=list(m.BACKBONE_2D.SFM_LAYER_NUMS), upsample_strides=list(m.BACKBONE_2D.UPSAMPLE_STRIDES),
                 anchor_sizes=ag["anchor_sizes"], anchor_rotations=ag["anchor_rotations"],
                 anchor_bottom_heights=ag["anchor_bottom_heights"], feature_map_stride=ag["feature_map_stride"],
+                anchor_configs=[dict(anchor_sizes=a["anchor_sizes"], anchor_rotations=a["anchor_rotations"],
+                                     anchor_bottom_heights=a["anchor_bottom_heights"]) for a in m.DENSE_HEAD.ANCHOR_GENERATOR_CONFIG],
                 dir_offset=m.DENSE_HEAD.DIR_OFFSET, dir_limit_offset=m.DENSE_HEAD.DIR_LIMIT_OFFSET,
                 num_dir_bins=m.DENSE_HEAD.NUM_DIR_BINS, score_thresh=m.POST_PROCESSING.SCORE_THRESH,
                 nms_thresh=m.POST_PROCESSING.NMS_CONFIG.NMS_THRESH, nms_pre=m.POST_PROCESSING.NMS_CONFIG.NMS_PRE_MAXSIZE,

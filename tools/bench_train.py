@@ -16,22 +16,26 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hvpr_amd import detector, distributed, optim, synthetic, synthetic_weights  # noqa: E402
-from hvpr_amd.config import hvpr_car_cfg  # noqa: E402
+from hvpr_amd.config import hvpr_3class_cfg, hvpr_car_cfg  # noqa: E402
 
 
-def gt_boxes(B, rng, per_frame=8):
+SIZES = np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]], np.float32)
+
+
+def gt_boxes(B, rng, per_frame=8, n_class=1):
     g = np.zeros((B, per_frame, 8), np.float32)
+    cls = rng.integers(0, n_class, (B, per_frame))
     g[..., 0] = rng.uniform(3, 44, (B, per_frame)); g[..., 1] = rng.uniform(-17, 17, (B, per_frame))
     g[..., 2] = rng.uniform(-1.2, -0.8, (B, per_frame))
-    g[..., 3:6] = np.array([3.9, 1.6, 1.56], np.float32) * rng.uniform(0.9, 1.1, (B, per_frame, 3))
-    g[..., 6] = rng.uniform(-np.pi, np.pi, (B, per_frame)); g[..., 7] = 1
+    g[..., 3:6] = SIZES[cls] * rng.uniform(0.9, 1.1, (B, per_frame, 3))
+    g[..., 6] = rng.uniform(-np.pi, np.pi, (B, per_frame)); g[..., 7] = cls + 1
     return g
 
 
-def make_batch(seed0, B, device, rng):
+def make_batch(seed0, B, device, rng, n_class=1):
     frames = [synthetic.hvpr_frame(seed0 + b, shuffle=True) for b in range(B)]
     pts = np.concatenate([np.concatenate([np.full((len(f), 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
-    return {"points": torch.from_numpy(pts).to(device), "gt_boxes": torch.from_numpy(gt_boxes(B, rng)).to(device), "batch_size": B}
+    return {"points": torch.from_numpy(pts).to(device), "gt_boxes": torch.from_numpy(gt_boxes(B, rng, n_class=n_class)).to(device), "batch_size": B}
 
 
 def main():
@@ -39,6 +43,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cfg", choices=["car", "3class"], default="car", help="car = config 3, 3class = config 4 of SURVEY.md §8d")
     args = ap.parse_args()
     rank, local_rank, world = distributed.env_rank()
     if not torch.cuda.is_available():
@@ -46,7 +51,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed.init("nccl", device)
-    cfg = hvpr_car_cfg()
+    cfg = hvpr_car_cfg() if args.cfg == "car" else hvpr_3class_cfg()
     model = detector.build_network(cfg.MODEL, len(cfg.CLASS_NAMES), detector.SyntheticDataset(cfg, training=True))
     synthetic_weights.load_synthetic(model, seed=0, cls_bias=-4.59511985013459)
     model = distributed.wrap_ddp(model.to(device), device)
@@ -54,7 +59,7 @@ def main():
     sched, _ = optim.build_scheduler(opt, total_iters_each_epoch=args.steps + args.warmup, total_epochs=1, last_epoch=-1,
                                      optim_cfg=cfg.OPTIMIZATION)
     rng = np.random.default_rng(rank)
-    pool = [make_batch(rank * 1000 + 100 * i, args.batch, device, rng) for i in range(2)]
+    pool = [make_batch(rank * 1000 + 100 * i, args.batch, device, rng, len(cfg.CLASS_NAMES)) for i in range(2)]
     losses = []
     for it in range(args.warmup):
         optim.train_step(model, opt, sched, dict(pool[it % 2]), it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
@@ -72,7 +77,7 @@ def main():
                           "unit": "steps/s", "frames_per_s": round(world * args.batch * args.steps / dt, 2), "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 1),
                           "dtype": "f32", "data": "synthetic", "scaling": "weak",
-                          "config": {"workload": f"hvpr_car.yaml full train step a1..a15, batch={args.batch}/GPU, 8 GT boxes/frame",
+                          "config": {"workload": f"hvpr_{args.cfg}.yaml full train step a1..a15, batch={args.batch}/GPU, 8 GT boxes/frame",
                                      "parallelism": f"dp{world}" if world > 1 else "single"},
                           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}), flush=True)
