@@ -472,6 +472,98 @@ def g11_preprocess(R):
     print("g11 ok: range keeps", int(mask.sum()), "fov keeps", int(fov.sum()))
 
 
+def synthetic_kitti_annos(seed=1212, n_frames=24):
+    """Small random KITTI-style annotation sets (camera frame): ground truth with all the ignore cases (Van, Person_sitting,
+    DontCare, occlusion / truncation / height levels) and detections = jittered ground truth + false positives."""
+    rng = np.random.default_rng(seed)
+    names = ["Car", "Car", "Car", "Pedestrian", "Cyclist", "Van", "Person_sitting", "DontCare", "Truck"]
+    dims_of = {"Car": (3.9, 1.56, 1.6), "Van": (5.0, 2.2, 1.9), "Pedestrian": (0.8, 1.73, 0.6), "Person_sitting": (0.8, 1.3, 0.6),
+               "Cyclist": (1.76, 1.73, 0.6), "Truck": (8.0, 3.0, 2.5), "DontCare": (-1, -1, -1)}
+    gts, dts = [], []
+
+    def bbox_of(loc, dims):
+        u = 620 + 720 * loc[0] / loc[2]
+        v = 180 + 720 * (loc[1] - dims[1] / 2) / loc[2]
+        hw, hh = 360 * max(dims[0], dims[2]) / loc[2], 360 * dims[1] / loc[2]
+        return [u - hw, v - hh, u + hw, v + hh]
+    for f in range(n_frames):
+        n = int(rng.integers(2, 11)) if f != 3 else 0          # one frame without ground truth
+        g = {k: [] for k in ("name", "truncated", "occluded", "alpha", "bbox", "dimensions", "location", "rotation_y")}
+        d = {k: [] for k in ("name", "truncated", "occluded", "alpha", "bbox", "dimensions", "location", "rotation_y", "score")}
+        for _ in range(n):
+            nm = names[int(rng.integers(0, len(names)))]
+            loc = np.array([rng.uniform(-12, 12), rng.uniform(1.4, 1.9), rng.uniform(6, 45)])
+            dims = np.array(dims_of[nm]) * (rng.uniform(0.9, 1.1, 3) if nm != "DontCare" else 1)
+            ry = rng.uniform(-np.pi, np.pi)
+            bb = bbox_of(loc, np.abs(dims)) if nm != "DontCare" else [rng.uniform(0, 600), rng.uniform(100, 200), rng.uniform(650, 1200), rng.uniform(220, 370)]
+            g["name"].append(nm); g["truncated"].append(rng.choice([0.0, 0.0, 0.0, 0.1, 0.2, 0.4, 0.6])); g["occluded"].append(int(rng.choice([0, 0, 0, 1, 2, 3])))
+            g["alpha"].append(ry - np.arctan2(loc[0], loc[2])); g["bbox"].append(bb); g["dimensions"].append(dims); g["location"].append(loc)
+            g["rotation_y"].append(ry)
+            if nm not in ("DontCare",) and rng.random() < 0.85:      # a detection near this object, sometimes of another class
+                j = rng.normal(0, 1, 3) * np.array([0.06, 0.02, 0.08]) * rng.choice([1, 1, 1, 4])
+                dn = nm if rng.random() < 0.9 else "Car"
+                dn = {"Van": "Car", "Person_sitting": "Pedestrian", "Truck": "Car"}.get(dn, dn)
+                dd = dims * rng.uniform(0.97, 1.03, 3)
+                dry = ry + rng.normal(0, 0.03) + (np.pi if rng.random() < 0.1 else 0)
+                d["name"].append(dn); d["truncated"].append(0.0); d["occluded"].append(0); d["alpha"].append(dry - np.arctan2(loc[0] + j[0], loc[2] + j[2]))
+                d["bbox"].append((np.array(bb) + rng.normal(0, 2, 4)).tolist()); d["dimensions"].append(dd); d["location"].append(loc + j)
+                d["rotation_y"].append(dry); d["score"].append(float(np.round(rng.uniform(0.1, 1.0), 3)))
+        for _ in range(int(rng.integers(0, 4))):               # false positives
+            nm = ["Car", "Pedestrian", "Cyclist"][int(rng.integers(0, 3))]
+            loc = np.array([rng.uniform(-12, 12), rng.uniform(1.4, 1.9), rng.uniform(6, 60)])
+            dims = np.array(dims_of[nm]) * rng.uniform(0.9, 1.1, 3)
+            ry = rng.uniform(-np.pi, np.pi)
+            d["name"].append(nm); d["truncated"].append(0.0); d["occluded"].append(0); d["alpha"].append(ry - np.arctan2(loc[0], loc[2]))
+            d["bbox"].append(bbox_of(loc, dims)); d["dimensions"].append(dims); d["location"].append(loc); d["rotation_y"].append(ry)
+            d["score"].append(float(np.round(rng.uniform(0.1, 0.9), 3)))
+
+        def pack(a, with_score):
+            out = {"name": np.array(a["name"], dtype="<U16"), "truncated": np.array(a["truncated"], np.float64), "occluded": np.array(a["occluded"], np.int64),
+                   "alpha": np.array(a["alpha"], np.float64), "bbox": np.array(a["bbox"], np.float64).reshape(-1, 4),
+                   "dimensions": np.array(a["dimensions"], np.float64).reshape(-1, 3), "location": np.array(a["location"], np.float64).reshape(-1, 3),
+                   "rotation_y": np.array(a["rotation_y"], np.float64)}
+            if with_score:
+                out["score"] = np.array(a["score"], np.float64)
+            return out
+        gts.append(pack(g, False)); dts.append(pack(d, True))
+    return gts, dts
+
+
+def g12_kitti_eval(R):
+    """AP through the reference's eval.py, run as plain Python: numba.jit -> identity, the ABSENT rotate_iou.py -> a stub
+    over the build's CPU rotated-intersection (oracle/iou3d_nms_ref.c, angle negated: rotation_y is clockwise in x-z).  Pins
+    the evaluator's filtering / matching / PR / AP logic; the rotated intersection itself stays unpinned."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import hvpr_oracle as O
+
+    def jit(*a, **k):
+        return a[0] if (len(a) == 1 and callable(a[0]) and not k) else (lambda f: f)
+    nb = _stub("numba"); nb.jit = jit; nb.prange = range
+
+    def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
+        def as7(b):
+            t = np.zeros((len(b), 7), np.float32)
+            t[:, 0:2], t[:, 3:5], t[:, 5], t[:, 6] = b[:, 0:2], b[:, 2:4], 1.0, -b[:, 4]
+            return t
+        inter = O.boxes_overlap_bev(as7(boxes), as7(query_boxes)).astype(np.float64) if len(boxes) and len(query_boxes) else \
+            np.zeros((len(boxes), len(query_boxes)))
+        a1, a2 = (boxes[:, 2] * boxes[:, 3])[:, None], (query_boxes[:, 2] * query_boxes[:, 3])[None, :]
+        ua = {-1: a1 + a2 - inter, 0: a1 + 0 * a2, 1: a2 + 0 * a1}.get(criterion)
+        return inter.astype(np.float32) if ua is None else np.where(inter > 0, inter / ua, 0.0).astype(np.float32)
+    _stub("pcdet.datasets", os.path.join(REF, "pcdet/datasets"))
+    _stub("pcdet.datasets.kitti", os.path.join(REF, "pcdet/datasets/kitti"))
+    _stub("pcdet.datasets.kitti.kitti_object_eval_python", os.path.join(REF, "pcdet/datasets/kitti/kitti_object_eval_python"))
+    _stub("pcdet.datasets.kitti.kitti_object_eval_python.rotate_iou").rotate_iou_gpu_eval = rotate_iou_gpu_eval
+    ev = _load("pcdet.datasets.kitti.kitti_object_eval_python.eval", "pcdet/datasets/kitti/kitti_object_eval_python/eval.py")
+    gts, dts = synthetic_kitti_annos()
+    detail = {}
+    text, ret = ev.get_official_eval_result(gts, dts, ["Car", "Pedestrian", "Cyclist"], PR_detail_dict=detail)
+    keys = sorted(ret)
+    np.savez_compressed(os.path.join(OUT, "g12_kitti_eval.npz"), keys=np.array(keys), values=np.array([ret[k] for k in keys], np.float64),
+                        prec_bbox=detail["bbox"], prec_bev=detail["bev"], prec_3d=detail["3d"], prec_aos=detail["aos"], text=np.array(text))
+    print("g12 ok:", {k: round(float(ret[k]), 3) for k in keys if "moderate" in k and "3d" in k})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     R = load_reference()
@@ -484,6 +576,7 @@ if __name__ == "__main__":
     g9_onecycle(R)
     g10_train_memory(R)
     g11_preprocess(R)
+    g12_kitti_eval(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")
