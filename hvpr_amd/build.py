@@ -11,6 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libhvpr_amd.so")
+OUT_CPU = os.path.join(HERE, "libhvpr_cpu.so")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # geometry that has to agree bit-for-bit with the CPU oracle: no FMA contraction (oracle/Makefile does the same)
@@ -50,7 +51,19 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs)
+    build_cpu(force, verbose)
     return OUT
+
+
+def build_cpu(force=False, verbose=False):
+    """libhvpr_cpu.so: the host-side natives of the data pipeline (g++, no GPU code)."""
+    src = os.path.join(HERE, "csrc_cpu", "gt_sampling.cpp")
+    if force or _stale(OUT_CPU, [src, os.path.join(os.path.dirname(HERE), "include", "hvpr_cpu.h")]):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-o", OUT_CPU, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT_CPU
 
 
 if __name__ == "__main__":
