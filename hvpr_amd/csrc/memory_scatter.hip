@@ -98,59 +98,64 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         float4 bf[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bf[g] = *(const float4 *)(s_f + l15 * kC + 16 * g + 4 * q);
-        constexpr int kTiles = kItemsPad / 16;
-        constexpr int TI = 2;                       // item tiles in flight per wave: independent accumulator chains
+        // items past n_items never win: their logits are -inf (written once, not tested per tile)
+        for (int i = tid; i < kPillars * (kItemsPad - n_items); i += kThreads)
+            s_logit[(i / (kItemsPad - n_items)) * kItemsPad + n_items + i % (kItemsPad - n_items)] = -INFINITY;
+        // The fp32 MFMA runs on the vector ALU lanes: every VALU instruction of a wave costs its SIMD one MFMA slot, and four
+        // waves share a SIMD.  The tile loop therefore carries no vector arithmetic: the tile index is a scalar (SGPR base
+        // + fixed per-lane offset addressing), registers ping-pong instead of being copied, bounds are handled outside.
+        const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wid);
         constexpr int kWaves = kThreads / 64;
-        auto load_a = [&](int tile, float4 (&a)[4]) {
-            const int item = min(tile * 16 + l15, n_items - 1);
-            const float4 *row = (const float4 *)(bank + (size_t)item * kC + 4 * q);
+        const int n_full = n_items / 16;                           // whole 16-item tiles
+        const int lane_elem = l15 * kC + 4 * q;                    // this lane's float offset inside a tile of the bank
+        float *const lrow = s_logit + l15 * kItemsPad + 4 * q;     // this lane's logits slot inside tile 0
+        const int rot = (int)((blockIdx.x * 7u) % (unsigned)(n_full > 0 ? n_full : 1));   // de-phase the workgroups' bank streams
+        auto tile_of = [&](int j) { int t = j + rot; return t >= n_full ? t - n_full : t; };
+        auto load_a = [&](int t, float4 (&a)[4]) {
+            const float *tb = bank + (size_t)t * (16 * kC);        // wave-uniform
 #pragma unroll
-            for (int g = 0; g < 4; ++g) a[g] = row[4 * g];
+            for (int g = 0; g < 4; ++g) a[g] = *(const float4 *)(tb + lane_elem + 16 * g);
         };
-        // wave w owns super-tiles w, w + kWaves, ...; a super-tile is TI consecutive item tiles
-        float4 a_cur[TI][4], a_nxt[TI][4];
-        // every workgroup streams the whole bank: rotate the start by the workgroup id so that the 200+ workgroups do
-        // not all hit the same L2 channel at the same moment
-        constexpr int kSuper = kTiles / TI;
-        const int rot = (blockIdx.x * 7) % kSuper;
-#pragma unroll
-        for (int u = 0; u < TI; ++u) load_a(((wid + rot) % kSuper) * TI + u, a_cur[u]);
-        for (int sti = wid; sti < kSuper; sti += kWaves) {
-            const int st = (sti + rot) % kSuper;
-            const int nst = (sti + kWaves + rot) % kSuper;
-            if (sti + kWaves < kSuper) {
-#pragma unroll
-                for (int u = 0; u < TI; ++u) load_a(nst * TI + u, a_nxt[u]);
-            }
-            f32x4 acc[TI];
-#pragma unroll
-            for (int u = 0; u < TI; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mul_store = [&](int t, const float4 (&a)[4]) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int u = 0; u < TI; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][g].x, bf[g].x, acc[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < TI; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][g].y, bf[g].y, acc[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < TI; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][g].z, bf[g].z, acc[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < TI; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][g].w, bf[g].w, acc[u], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, bf[g].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, bf[g].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].z, bf[g].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].w, bf[g].w, acc, 0, 0, 0);
             }
             // C/D map of 16x16x4: column (pillar) = lane & 15, row (item) = 4 * (lane >> 4) + reg
+            *(float4 *)(lrow + t * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        };
+        // wave w owns tiles w, w + 16, w + 32, ... (rotated); two register sets alternate, the next tile's loads are in flight
+        // while the current one multiplies
+        float4 a0[4], a1[4];
+        int j = (int)wave_u;
+        if (j < n_full) load_a(tile_of(j), a0);
+        for (; j < n_full; j += 2 * kWaves) {
+            const int j1 = j + kWaves, j2 = j + 2 * kWaves;
+            if (j1 < n_full) load_a(tile_of(j1), a1);
+            mul_store(tile_of(j), a0);
+            if (j1 < n_full) {
+                if (j2 < n_full) load_a(tile_of(j2), a0);
+                mul_store(tile_of(j1), a1);
+            }
+        }
+        if ((n_items & 15) && wave_u == 0) {                       // the partial last tile: rows clamped, tail stays -inf
+            const int item = min(n_full * 16 + l15, n_items - 1);
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < TI; ++u) {
-                const int item0 = (st * TI + u) * 16 + 4 * q;
-                float4 o;
-                o.x = item0 + 0 < n_items ? acc[u][0] : -INFINITY;
-                o.y = item0 + 1 < n_items ? acc[u][1] : -INFINITY;
-                o.z = item0 + 2 < n_items ? acc[u][2] : -INFINITY;
-                o.w = item0 + 3 < n_items ? acc[u][3] : -INFINITY;
-                *(float4 *)(s_logit + l15 * kItemsPad + item0) = o;
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = *(const float4 *)(bank + (size_t)item * kC + 4 * q + 16 * g);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[g].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[g].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[g].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[g].w, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < TI; ++u)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) a_cur[u][g] = a_nxt[u][g];
+            for (int r = 0; r < 4; ++r)
+                if (n_full * 16 + 4 * q + r < n_items) lrow[n_full * 16 + r] = acc[r];
         }
     }
     __syncthreads();
@@ -168,26 +173,40 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         for (int t = 0; t < kItemsPad / 64; ++t) { v[t] = row[lane + 64 * t]; lmax = fmaxf(lmax, v[t]); }
         // tau = k-th largest of the 64 lane maxima: a lower bound of the k-th largest logit
         const unsigned tau_bits = wave_kth_largest_u32(ord_bits(lmax), k);
-        // compact the candidates (>= tau) into LDS, wave-uniform counter
-        int cnt = 0;
+        const unsigned tb = (tau_bits & 0x80000000u) ? (tau_bits & 0x7fffffffu) : ~tau_bits;
+        const float tau = __uint_as_float(tb);                    // > -inf whenever at least k lanes hold a finite logit
+        // candidates (>= tau) per lane as a bit mask (float compares only), then compacted rank by rank: rank r of every
+        // lane with more than r candidates goes to LDS at a ballot-prefix position.  ~23 candidates, at most a few per lane.
+        unsigned hits = 0u;
 #pragma unroll
-        for (int t = 0; t < kItemsPad / 64; ++t) {
-            const bool hit = ord_bits(v[t]) >= tau_bits && v[t] > -INFINITY;
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                if (hit && pos < 64)
-                    cand[pos] = ((unsigned long long)ord_bits(v[t]) << 32) | (unsigned)(0xffffffffu - (unsigned)(lane + 64 * t));
-                cnt += __popcll(m);
-            }
+        for (int t = 0; t < kItemsPad / 64; ++t) hits |= (v[t] >= tau && v[t] > -INFINITY) ? (1u << t) : 0u;
+        int cnt = 0;
+        for (unsigned left = hits; __ballot(left != 0u) != 0ull;) {
+            const bool has = left != 0u;
+            const unsigned long long m = __ballot(has);
+            const int t = has ? __ffs((int)left) - 1 : 0;
+            left &= left - 1u;
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (has && pos < 64)
+                cand[pos] = ((unsigned long long)ord_bits(row[lane + 64 * t]) << 32) | (unsigned)(0xffffffffu - (unsigned)(lane + 64 * t));
+            cnt += __popcll(m);
         }
         // the k largest keys (value desc, index asc; keys are unique) end up in lanes [0,k), in no particular order
         unsigned long long key = 0ull;
         bool sel;
         if (cnt <= 64) {
             key = lane < cnt ? cand[lane] : 0ull;
-            const unsigned long long kth = wave_kth_largest_u64(key, min(k, cnt));
-            sel = key != 0ull && key >= kth;
+            const int kk = min(k, cnt);
+            // select on the 32 value bits; the 32 index bits only matter when equal values straddle the k-th place
+            const unsigned hi = (unsigned)(key >> 32);
+            const unsigned kth_hi = wave_kth_largest_u32(hi, kk);
+            const int n_gt = __popcll(__ballot(hi > kth_hi)), n_eq = __popcll(__ballot(key != 0ull && hi == kth_hi));
+            if (n_gt + n_eq == kk) {
+                sel = key != 0ull && hi >= kth_hi;
+            } else {
+                const unsigned long long kth = wave_kth_largest_u64(key, kk);
+                sel = key != 0ull && key >= kth;
+            }
         } else {
             // exact slow path (mass ties): k rounds of wave arg-max with (value desc, index asc) order
             unsigned long long prev = ~0ull;
