@@ -311,6 +311,101 @@ __global__ void __launch_bounds__(64) k_nms_sweep(const unsigned long long *__re
     if (lane == 0) *keep_count = kept;
 }
 
+// The greedy sweep for n <= 4096 candidates (nb <= 64 mask words per row).  The sweep is serial over the 64-box blocks and
+// needs, per block, the mask rows of the boxes it keeps: read on demand that is one dependent L2 round trip per block
+// (64 x ~3.5 us).  Here one workgroup of 8 waves streams ALL rows through a double-buffered LDS ring, two blocks (128
+// rows x nb words, 64 KB) per phase: waves 1-7 load phase p+1 while wave 0 resolves phase p out of LDS — the resolve
+// never waits for memory.  Same greedy order, same result.
+constexpr int kRingThreads = 512;
+constexpr int kRingBlocks = 2;                       // 64-box blocks per phase
+constexpr int kRingWords = 64;                       // words per row in LDS (nb <= 64)
+
+__global__ void __launch_bounds__(kRingThreads) k_nms_sweep_ring(const unsigned long long *__restrict__ mask, int nb_stride,
+                                                                 const int *__restrict__ n_device, int n_max,
+                                                                 const int *__restrict__ order, int map_through_order,
+                                                                 int max_keep, int *__restrict__ keep, int *__restrict__ keep_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_rows[];   // [2][kRingBlocks * 64][kRingWords]
+    __shared__ int s_done;
+    const int n = n_device ? min(*n_device, n_max) : n_max;
+    const int nb = (n + 63) / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int phases = (nb + kRingBlocks - 1) / kRingBlocks;
+    constexpr int kPhaseRows = kRingBlocks * 64;
+    // 16-byte pieces: row r of the phase, words 2c, 2c+1
+    auto load_phase = [&](int ph, int first_thread, int n_threads) {
+        unsigned long long *dst = s_rows + (size_t)(ph & 1) * kPhaseRows * kRingWords;
+        constexpr int kPieces = kPhaseRows * (kRingWords / 2);
+        constexpr int kUnroll = (kPieces + (kRingThreads - 64) - 1) / (kRingThreads - 64);   // enough for the 7 loader waves
+        ulonglong2 v[kUnroll];
+        // every load of the phase is issued before the first LDS store: one L2 round trip per phase, not one per piece
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = tid - first_thread + u * n_threads;
+            const int r = i / (kRingWords / 2), c = i % (kRingWords / 2);
+            const int row = ph * kPhaseRows + r;
+            v[u] = make_ulonglong2(0ull, 0ull);
+            if (i < kPieces && row < n && 2 * c < nb_stride) {
+                const unsigned long long *src = mask + (size_t)row * nb_stride + 2 * c;
+                if (!(nb_stride & 1)) v[u] = *(const ulonglong2 *)src;            // even stride: 16-byte aligned, both words exist
+                else { v[u].x = src[0]; if (2 * c + 1 < nb_stride) v[u].y = src[1]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = tid - first_thread + u * n_threads;
+            if (i < kPieces) *(ulonglong2 *)(dst + (size_t)(i / (kRingWords / 2)) * kRingWords + 2 * (i % (kRingWords / 2))) = v[u];
+        }
+    };
+    if (tid == 0) s_done = 0;
+    load_phase(0, 0, kRingThreads);
+    __syncthreads();
+    unsigned long long remv = 0ull;                  // wave 0: lane w owns suppression word w
+    int kept = 0;
+    for (int ph = 0; ph < phases; ++ph) {
+        if (wid != 0) {
+            if (ph + 1 < phases && !s_done) load_phase(ph + 1, 64, kRingThreads - 64);
+        } else if (kept < max_keep) {
+            const unsigned long long *rows = s_rows + (size_t)(ph & 1) * kPhaseRows * kRingWords;
+            for (int bb = 0; bb < kRingBlocks && kept < max_keep; ++bb) {
+                const int b = ph * kRingBlocks + bb;
+                if (b >= nb) break;
+                const unsigned long long diag = rows[(size_t)(bb * 64 + lane) * kRingWords + b];   // row `lane` of block b, word b
+                unsigned long long rw;
+                {
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(remv & 0xffffffffull), b);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(remv >> 32), b);
+                    rw = ((unsigned long long)hi << 32) | lo;
+                }
+                const int lim = min(64, n - b * 64);
+                const unsigned long long valid = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
+                unsigned long long kbits = 0ull;
+                unsigned long long avail = ~rw & valid;
+                while (avail && kept < max_keep) {                 // only unsuppressed candidates are visited
+                    const int i = __ffsll((long long)avail) - 1;
+                    kbits |= 1ull << i;
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffull), i);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), i);
+                    rw |= ((unsigned long long)hi << 32) | lo;
+                    ++kept;
+                    avail = ~rw & valid & ~((2ull << i) - 1ull);
+                }
+                const int base = kept - __popcll(kbits);
+                if ((kbits >> lane) & 1ull) {
+                    const int pos = b * 64 + lane;
+                    keep[base + __popcll(kbits & ((1ull << lane) - 1ull))] = (order && map_through_order) ? order[pos] : pos;
+                }
+                for (unsigned long long kb = kbits; kb; kb &= kb - 1) {   // rows of the kept boxes, straight from LDS
+                    const int i = __ffsll((long long)kb) - 1;
+                    remv |= rows[(size_t)(bb * 64 + i) * kRingWords + lane];
+                }
+            }
+            if (kept >= max_keep && lane == 0) s_done = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *keep_count = kept;
+}
+
 }  // namespace
 
 extern "C" int hvpr_boxes_pairwise_f32(const float *boxes_a, int n, const float *boxes_b, int m, int mode, float *out,
@@ -347,8 +442,20 @@ extern "C" int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_
     Box *prepared = (Box *)((char *)workspace + (((size_t)n_max * nb * sizeof(unsigned long long) + 255) / 256) * 256);
     hipLaunchKernelGGL(k_nms_prep, dim3(hvpr_cdiv(n_max, 256)), dim3(256), 0, s, boxes, box_stride, order, n_device, n_max, prepared);
     hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, s, prepared, n_device, n_max, thresh, mask, nb);
-    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, nb, n_device, n_max, order, map_through_order, max_keep,
-                       keep, keep_count);
+    if (nb <= kRingWords) {
+        const size_t lds = (size_t)2 * kRingBlocks * 64 * kRingWords * sizeof(unsigned long long);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)k_nms_sweep_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return HVPR_ERR_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_nms_sweep_ring, dim3(1), dim3(kRingThreads), lds, s, mask, nb, n_device, n_max, order, map_through_order,
+                           max_keep, keep, keep_count);
+    } else {
+        hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, s, mask, nb, n_device, n_max, order, map_through_order, max_keep,
+                           keep, keep_count);
+    }
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
