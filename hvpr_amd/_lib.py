@@ -34,6 +34,7 @@ SIGNATURES = {
     "hvpr_score_topk_f32": (_I, [_P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "hvpr_nms_workspace_bytes": (_Z, [_I]),
     "hvpr_nms_bev_f32": (_I, [_P, _I, _P, _P, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    "hvpr_gather_predictions_f32": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "hvpr_boxes_pairwise_f32": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "hvpr_furthest_point_sample_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "hvpr_ball_query_f32": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P]),

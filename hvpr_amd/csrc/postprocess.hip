@@ -339,7 +339,37 @@ __global__ void __launch_bounds__(256) k_rank_place(const unsigned long long *__
     }
 }
 
+// The tail of post_processing (detector3d_template.py:255-259): selected boxes / scores / labels of one frame in one launch
+// (five small torch gathers otherwise).  Rows past *keep_count read keep[] as it is (the caller zero-fills it: anchor 0).
+__global__ void __launch_bounds__(256) k_gather_predictions(const float *__restrict__ boxes, int box_stride, const float *__restrict__ scores,
+                                                            const int *__restrict__ labels, const int *__restrict__ keep, int max_keep,
+                                                            float *__restrict__ out_boxes, float *__restrict__ out_scores,
+                                                            long long *__restrict__ out_labels, long long *__restrict__ out_selected) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= max_keep * 8) return;
+    const int r = t >> 3, c = t & 7;
+    const int src = keep[r];
+    if (c < 7) out_boxes[(size_t)r * 7 + c] = boxes[(size_t)src * box_stride + c];
+    else {
+        out_scores[r] = scores[src];
+        out_labels[r] = (long long)labels[src];
+        out_selected[r] = (long long)src;
+    }
+}
+
 }  // namespace
+
+extern "C" int hvpr_gather_predictions_f32(const float *boxes, int box_stride, const float *scores, const int32_t *labels,
+                                           const int32_t *keep, int max_keep, float *out_boxes, float *out_scores,
+                                           int64_t *out_labels, int64_t *out_selected, hvpr_stream_t stream) {
+    if (max_keep < 0 || box_stride < 7) return HVPR_ERR_INVALID_ARG;
+    if (max_keep == 0) return HVPR_OK;
+    if (!boxes || !scores || !labels || !keep || !out_boxes || !out_scores || !out_labels || !out_selected) return HVPR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_gather_predictions, dim3(hvpr_cdiv(max_keep * 8, 256)), dim3(256), 0, (hipStream_t)stream, boxes, box_stride,
+                       scores, labels, keep, max_keep, out_boxes, out_scores, (long long *)out_labels, (long long *)out_selected);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
 
 extern "C" int hvpr_spatial_gate_f32(const float *y, int N, int H, int W, int C, const float *w18, float conv_bias,
                                      float bn_scale, float bn_shift, float *gate, hvpr_stream_t stream) {

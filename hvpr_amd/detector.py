@@ -171,10 +171,14 @@ class Detector3DTemplate(nn.Module):
         for b in range(B):
             keep, kc = kernels.nms_bev(boxes_all[b], order[b], counts[b:b + 1], pre, float(ncfg.NMS_THRESH), post,
                                        self._post_ws.nms)
-            sel = keep.long()
-            rec = {"pred_boxes": boxes_all[b].index_select(0, sel), "pred_labels": labels[b].index_select(0, sel).long(),
-                   "pred_scores": (cls_all[b].max(dim=-1)[0] if cfg.OUTPUT_RAW_SCORE else scores[b]).index_select(0, sel),
-                   "selected": sel, "pred_count": kc}
+            if labels.dtype == torch.int32 and not cfg.OUTPUT_RAW_SCORE and boxes_all[b].is_contiguous():
+                pb, ps, pl, sel = kernels.gather_predictions(boxes_all[b], scores[b].contiguous(), labels[b].contiguous(), keep)
+                rec = {"pred_boxes": pb, "pred_labels": pl, "pred_scores": ps, "selected": sel, "pred_count": kc}
+            else:
+                sel = keep.long()
+                rec = {"pred_boxes": boxes_all[b].index_select(0, sel), "pred_labels": labels[b].index_select(0, sel).long(),
+                       "pred_scores": (cls_all[b].max(dim=-1)[0] if cfg.OUTPUT_RAW_SCORE else scores[b]).index_select(0, sel),
+                       "selected": sel, "pred_count": kc}
             if sync:
                 n = int(kc.item())
                 rec = {k: (v[:n] if k != "pred_count" else v) for k, v in rec.items()}

@@ -346,6 +346,21 @@ def nms_bev(boxes, order, n_device, n_max, thresh, max_keep, ws_nms, map_through
     return keep, kc
 
 
+def gather_predictions(boxes, scores, labels, keep):
+    """boxes (A,>=7), scores (A,), labels (A,) i32, keep (K,) i32 -> pred_boxes (K,7), pred_scores (K,), pred_labels (K,) i64,
+    selected (K,) i64 in one launch."""
+    K = keep.shape[0]
+    dev = boxes.device
+    ob = torch.empty((K, 7), dtype=torch.float32, device=dev)
+    os_ = torch.empty((K,), dtype=torch.float32, device=dev)
+    ol = torch.empty((K,), dtype=torch.int64, device=dev)
+    osel = torch.empty((K,), dtype=torch.int64, device=dev)
+    check(lib().hvpr_gather_predictions_f32(_ptr(boxes, torch.float32, "boxes"), boxes.shape[1], _ptr(scores, torch.float32, "scores"),
+                                            _ptr(labels, torch.int32, "labels"), _ptr(keep, torch.int32, "keep"), K, ob.data_ptr(),
+                                            os_.data_ptr(), ol.data_ptr(), osel.data_ptr(), _stream()), "hvpr_gather_predictions_f32")
+    return ob, os_, ol, osel
+
+
 def boxes_pairwise(a, b, mode):
     """mode 0: BEV overlap area, 1: BEV IoU, 2: 3D IoU.  a (N,7), b (M,7) -> (N,M)."""
     a = a[:, :7].contiguous()

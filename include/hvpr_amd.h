@@ -194,6 +194,11 @@ size_t hvpr_nms_workspace_bytes(int n_max);
 int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_t *order, const int32_t *n_device, int n_max,
                      float thresh, int max_keep, int map_through_order, int32_t *keep, int32_t *keep_count,
                      void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+/* tail of post_processing (detector3d_template.py:255-259): out_*[r] = *[keep[r]] for r < max_keep (boxes 7 columns; labels and
+ * the selected ids widened to int64 as the reference returns them); keep[] rows past the live count must hold valid ids */
+int hvpr_gather_predictions_f32(const float *boxes, int box_stride, const float *scores, const int32_t *labels,
+                                const int32_t *keep, int max_keep, float *out_boxes, float *out_scores, int64_t *out_labels,
+                                int64_t *out_selected, hvpr_stream_t stream);
 int hvpr_boxes_pairwise_f32(const float *boxes_a, int n, const float *boxes_b, int m, int mode, float *out,
                             hvpr_stream_t stream);
 
