@@ -173,3 +173,41 @@ def test_bf16x3_convolution_mode_stays_within_tolerance(model_and_params):
             common, len(sel_ref)))
     finally:
         model.backbone_2d.set_conv_precision("fp32")
+
+
+def test_config5_dense_scene_encode_group_batch4():
+    """BASELINE.json configs[4]: ~200 k uniform points per frame, nuScenes-scale 512 x 512 grid, 20
+    points / pillar, the 60 000-pillar cap hit, batch 4 — voxelize + pillar VFE + memory read-out + scatter (671 MB of canvases)
+    through the detector's modules against the oracle, stage by stage."""
+    import copy
+    cfg = copy.deepcopy(hvpr_car_cfg())
+    rng = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    cfg.DATA_CONFIG.POINT_CLOUD_RANGE = rng
+    for p in cfg.DATA_CONFIG.DATA_PROCESSOR:
+        if p.NAME == "transform_points_to_voxels":
+            p.VOXEL_SIZE, p.MAX_POINTS_PER_VOXEL, p.MAX_NUMBER_OF_VOXELS = [0.2, 0.2, 8.0], 20, {"train": 60000, "test": 60000}
+    model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg))
+    params = synthetic_weights.load_synthetic(model, seed=9, cls_bias=-2.0)
+    model = model.to(DEV).eval()
+    B = 4
+    frames = [synthetic.uniform_frame(70 + b, 200000 - 1000 * b, rng) for b in range(B)]
+    with torch.no_grad():
+        bd = model.stage_encode(_batch(frames))
+    assert bd["spatial_features"].shape == (B, 128, 512, 512) and bd["spatial_scale_features"].shape == (B, 32, 512, 512)
+    vo = bd["voxel_offsets"].cpu().numpy()
+    assert (np.diff(vo) == 60000).all()                                   # the V2 cap is hit in every frame
+    W = params["map_to_bev_module.memory.weight"]
+    for b in (0, B - 1):                                                  # first and last frame against the oracle
+        v, c, n = O.voxelize(frames[b], [0.2, 0.2, 8.0], rng, 20, 60000)
+        s, e = vo[b], vo[b + 1]
+        np.testing.assert_array_equal(bd["voxel_coords"][s:e, 1:].cpu().numpy(), c)
+        np.testing.assert_array_equal(bd["voxel_num_points"][s:e].cpu().numpy(), n)
+        np.testing.assert_array_equal(bd["voxels"][s:e].cpu().numpy(), v)
+        coords = np.concatenate([np.zeros((len(c), 1), np.float32), c.astype(np.float32)], 1)
+        pf, sf, _ = O.pillar_vfe_scale(v, n.astype(np.float32), coords, O._sub(params, "vfe."), [0.2, 0.2, 8.0], rng)
+        assert _rel(bd["pillar_features"][s:e].cpu().numpy(), pf.numpy()) < 1e-3
+        assert _rel(bd["pillar_scale_features"][s:e].cpu().numpy(), sf.numpy()) < 1e-3
+        mem = torch.cat([O.memory_readout_eval(pf[i:i + 15000], W, 20)[0] for i in range(0, len(pf), 15000)])
+        sp, sc = O.scatter_eval(pf, mem, sf, coords, 1, 512, 512)
+        assert _rel(bd["spatial_features"][b].cpu().numpy(), sp[0].numpy()) < 1e-3
+        assert _rel(bd["spatial_scale_features"][b].cpu().numpy(), sc[0].numpy()) < 1e-3
