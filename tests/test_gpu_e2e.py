@@ -115,18 +115,19 @@ def _snapshot(rec):
     return {k: rec[k][:n].cpu().numpy().copy() for k in ("pred_boxes", "pred_scores", "pred_labels", "selected")}
 
 
-def test_graph_replay_and_frame_pipeline_equal_the_serial_forward(model_and_params):
+@pytest.mark.parametrize("per_batch", [1, 2])
+def test_graph_replay_and_frame_pipeline_equal_the_serial_forward(model_and_params, per_batch):
     """One hipGraph per frame (GraphedForward) and the three-stage frame pipeline (PipelinedForward: encode of frame k,
     convolutions of frame k-1, top-k + NMS of frame k-2 in one replay) return exactly what the eager forward returns."""
     cfg, model, params = model_and_params
-    frames = [synthetic.hvpr_frame(30 + i) for i in range(5)]
-    batches = [_batch([f]) for f in frames]
+    frames = [synthetic.hvpr_frame(30 + i) for i in range(5 * per_batch)]
+    batches = [_batch(frames[i * per_batch:(i + 1) * per_batch]) for i in range(5)]
     with torch.no_grad():
-        want = [_snapshot(model(dict(b), sync=False)[0][0]) for b in batches]
+        want = [_snapshot(model(dict(b), sync=False)[0][per_batch - 1]) for b in batches]
     assert len(want[0]["selected"]) > 0
     graphed = detector.GraphedForward(model, batches[0])
     for b, w in zip(batches, want):
-        got = _snapshot(graphed(b)[0][0])
+        got = _snapshot(graphed(b)[0][per_batch - 1])
         for k in w:
             np.testing.assert_array_equal(got[k], w[k])
     pipe = detector.PipelinedForward(model, batches[0])
@@ -134,15 +135,16 @@ def test_graph_replay_and_frame_pipeline_equal_the_serial_forward(model_and_para
     for b in batches:
         out = pipe(b)
         if out is not None:
-            got.append(_snapshot(out[0]))
+            got.append(_snapshot(out[per_batch - 1]))
     for out in pipe.flush():
-        got.append(_snapshot(out[0]))
+        got.append(_snapshot(out[per_batch - 1]))
     assert len(got) == len(want)
     for g, w in zip(got, want):
         for k in w:
             np.testing.assert_array_equal(g[k], w[k])
     # a second pass through the same pipeline (steady state, both lanes warm)
-    got = [_snapshot(o[0]) for o in (pipe(b) for b in batches) if o is not None] + [_snapshot(o[0]) for o in pipe.flush()]
+    last = per_batch - 1
+    got = [_snapshot(o[last]) for o in (pipe(b) for b in batches) if o is not None] + [_snapshot(o[last]) for o in pipe.flush()]
     for g, w in zip(got[-5:], want):
         for k in w:
             np.testing.assert_array_equal(g[k], w[k])
