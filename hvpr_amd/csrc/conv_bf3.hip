@@ -5,6 +5,10 @@
 // fp32 kernel (conv_igemm.hip) stays the default and the parity reference.  Same implicit-GEMM structure as k_conv:
 // NHWC, LDS-DMA double buffer, persistent XCD-aware tile walk, weights as the MFMA "A" operand.
 //
+// NPL = number of bf16 planes per value: 2 = "bf16x3" above; 3 = "bf16x6": x = x_hi + x_mid + x_lo EXACTLY (3 x 8 mantissa
+// bits), six products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi — the dropped terms are <= 2^-23 relative, the accuracy of
+// the fp32 matrix-core kernel itself (fp32 emulation on the bf16 matrix cores).
+//
 // Split-bf16 NHWC: every group of 8 channels of a pixel is stored as [8 x bf16 hi | 8 x bf16 lo] = 32 bytes — the same
 // footprint and addressing as 8 fp32 channels, so staging moves the same 16-byte pieces.  One MFMA consumes K = 16 channels:
 // lanes 0-31 supply the 8 channels of the even chunk, lanes 32-63 those of the odd chunk.
@@ -33,12 +37,17 @@ __device__ __forceinline__ bf16x8 as_bf(float4 v) {
     u.f = v;
     return u.b;
 }
-// x -> (hi, lo): hi = rne_bf16(x), lo = rne_bf16(x - hi); returned as the 16 bits of each
-__device__ __forceinline__ void split1(float x, unsigned &hi, unsigned &lo) {
-    const __bf16 h = (__bf16)x;
-    const __bf16 l = (__bf16)(x - (float)h);
-    hi = (unsigned)__builtin_bit_cast(unsigned short, h);
-    lo = (unsigned)__builtin_bit_cast(unsigned short, l);
+// x -> NPL bf16 planes by successive round-to-nearest residuals (p0 = rne(x), p1 = rne(x - p0), p2 = rne(x - p0 - p1));
+// returned as the 16 bits of each
+template <int NPL>
+__device__ __forceinline__ void split1(float x, unsigned (&pl)[NPL]) {
+    float r = x;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const __bf16 h = (__bf16)r;
+        pl[k] = (unsigned)__builtin_bit_cast(unsigned short, h);
+        r -= (float)h;
+    }
 }
 
 struct Conv3Args {
@@ -53,7 +62,7 @@ struct Conv3Args {
 };
 
 // WGM x WGN = the 4 waves of a workgroup along pixels x channels (2 x 2, or 4 x 1 for the 256-pixel tile)
-template <int TH, int TW, int BN, int S, int WGM>
+template <int TH, int TW, int BN, int S, int WGM, int NPL>
 __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
     constexpr int TAPS = 9, HALO = 2, NSUB = 2, KSTAGE = KC * NSUB;
     constexpr int WGN = 4 / WGM;
@@ -68,11 +77,11 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
     // slots of the 256-byte bank row.  A 32-lane half covers 2 rows of 16 pixels (pitch 32) or 4 rows of 8 pixels (pitch 24):
     // with these pitches every group sees all 16 slots, for every tap offset; the natural pitch PW (18 / 10) is 2-3 way
     // conflicted (SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE before).
-    constexpr int PITCH = S != 1 ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));
+    constexpr int PITCH = (S != 1 || NPL == 3) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));   // three planes: no LDS left for the pad
     static_assert(PITCH >= PW, "pitch must hold a patch row");
     constexpr int PPAD = (PH * PITCH + 63) / 64 * 64;
-    constexpr int PATCH_V4 = NSUB * 2 * PPAD;          // patch   [sub][hi|lo][PPAD]
-    constexpr int W_V4 = TAPS * NSUB * 2 * BN;         // weights [tap][sub][hi|lo][BN]
+    constexpr int PATCH_V4 = NSUB * NPL * PPAD;        // patch   [sub][plane][PPAD]
+    constexpr int W_V4 = TAPS * NSUB * NPL * BN;       // weights [tap][sub][plane][BN]
     constexpr int NLD_P = (PATCH_V4 + 255) / 256, NLD_W = (W_V4 + 255) / 256;
     constexpr int PATCH_PAD = NLD_P * 256, W_PAD = NLD_W * 256;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -89,20 +98,20 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
 #pragma unroll
     for (int i = 0; i < NLD_P; ++i) {
         const int v = tid + i * 256;
-        const int part = v / PPAD, pix = v % PPAD;     // part = sub * 2 + (hi|lo): 16-byte piece `part` of the stage's 64 bytes
+        const int part = v / PPAD, pix = v % PPAD;     // part = sub * NPL + plane: 16-byte piece `part` of the stage's bytes
         p_py[i] = pix / PITCH; p_px[i] = pix % PITCH; p_part[i] = part;
         p_live[i] = v < PATCH_V4 && pix < PH * PITCH && pix % PITCH < PW;
     }
     unsigned woff0[NLD_W];
     bool wok[NLD_W];
-    const size_t w_chunk_stride = (size_t)a.cout_pad * 2;              // float4 units between cin chunks
+    const size_t w_chunk_stride = (size_t)a.cout_pad * NPL;            // float4 units between cin chunks
     const size_t w_tap_stride = (size_t)(a.Cin / KC) * w_chunk_stride;
 #pragma unroll
     for (int i = 0; i < NLD_W; ++i) {
-        const int v = tid + i * 256;                                   // = ((tap*NSUB + sub)*2 + hl)*BN + co_local
+        const int v = tid + i * 256;                                   // = ((tap*NSUB + sub)*NPL + plane)*BN + co_local
         wok[i] = v < W_V4;
         const int co_l = v % BN, r = v / BN;
-        const int hl = r & 1, sub = (r >> 1) % NSUB, tap = (r >> 1) / NSUB;
+        const int hl = r % NPL, sub = (r / NPL) % NSUB, tap = (r / NPL) / NSUB;
         woff0[i] = wok[i] ? (unsigned)(((size_t)tap * w_tap_stride + (size_t)sub * w_chunk_stride + (size_t)hl * a.cout_pad + co_l) * 16) : 0u;
     }
     int a_off[MB];
@@ -110,11 +119,11 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
     for (int mb = 0; mb < MB; ++mb) {
         const int q = mb * 32 + l31;
         const int py = wm * (TH / WGM) + q / TW, px = q % TW;
-        a_off[mb] = (half * 2) * PPAD + (py * S) * PITCH + px * S;     // hi plane of this lane's chunk; lo plane = + PPAD
+        a_off[mb] = (half * NPL) * PPAD + (py * S) * PITCH + px * S;   // plane 0 of this lane's chunk; plane k = + k * PPAD
     }
     int b_off[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b_off[nb] = (half * 2) * BN + wn * WN + nb * 32 + l31;   // hi; lo = + BN; next tap = + NSUB*2*BN
+    for (int nb = 0; nb < NB; ++nb) b_off[nb] = (half * NPL) * BN + wn * WN + nb * 32 + l31;   // plane k = + k*BN; next tap = + NSUB*NPL*BN
     const unsigned lds_patch0 = lds_addr_of(s_patch) + wave_s * 1024u;
     const unsigned lds_w0 = lds_addr_of(s_w) + wave_s * 1024u;
 
@@ -139,13 +148,13 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
     for (int i = 0; i < NLD_P; ++i) {
         const int iy = iy0 + p_py[i], ix = ix0 + p_px[i];
         pok[i] = p_live[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        poff[i] = pok[i] ? (unsigned)(((iy * a.W + ix) * (a.Cin / 4) + p_part[i]) * 16) : 0u;   // Cin/8 groups x 2 pieces
+        poff[i] = pok[i] ? (unsigned)(((iy * a.W + ix) * (a.Cin / 8 * NPL) + p_part[i]) * 16) : 0u;   // Cin/8 groups x NPL pieces
     }
     const unsigned w_co0 = (unsigned)(co0 * 16);
-    const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * (a.Cin / 4));
+    const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * (a.Cin / 8 * NPL));
 
     auto stage = [&](int chunk, int buf) {
-        const char *pbase = in_n + (size_t)chunk * (NSUB * 32);
+        const char *pbase = in_n + (size_t)chunk * (NSUB * NPL * 16);
         const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * 16;
 #pragma unroll
         for (int i = 0; i < NLD_P; ++i)
@@ -178,19 +187,17 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
         const float4 *sp = s_patch + BUF * PATCH_PAD;
         const float4 *sw = s_w + BUF * W_PAD;
         constexpr int PF = 2;
-        float4 ah[PF + 1][MB], al[PF + 1][MB], bh[PF + 1][NB], bl[PF + 1][NB];
+        float4 av[PF + 1][MB][NPL], bv[PF + 1][NB][NPL];
         auto lds_load = [&](int tap, int slot) {
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                ah[slot][mb] = sp[a_off[mb] + ky * PITCH + kx];
-                al[slot][mb] = sp[a_off[mb] + ky * PITCH + kx + PPAD];
-            }
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                bh[slot][nb] = sw[b_off[nb] + tap * NSUB * 2 * BN];
-                bl[slot][nb] = sw[b_off[nb] + tap * NSUB * 2 * BN + BN];
-            }
+                for (int k = 0; k < NPL; ++k) av[slot][mb][k] = sp[a_off[mb] + ky * PITCH + kx + k * PPAD];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) bv[slot][nb][k] = sw[b_off[nb] + tap * NSUB * NPL * BN + k * BN];
         };
 #pragma unroll
         for (int t = 0; t < PF; ++t) lds_load(t, t);
@@ -199,23 +206,19 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
             if (tap + PF < TAPS) lds_load(tap + PF, (tap + PF) % (PF + 1));
             __builtin_amdgcn_sched_barrier(0);
             const int cur = tap % (PF + 1);
-            // three passes over the blocks, so that consecutive MFMAs write different accumulators (independent issue); small
-            // terms first, the dominant hi*hi last
+            // plane pairs (weight plane, activation plane), smallest terms first; every pass walks all blocks so that
+            // consecutive MFMAs write different accumulators
+            constexpr int NPAIR = NPL == 2 ? 3 : 6;
+            constexpr int PW_[6] = {NPL == 2 ? 1 : 2, NPL == 2 ? 0 : 0, NPL == 2 ? 0 : 1, 1, 0, 0};
+            constexpr int PA_[6] = {NPL == 2 ? 0 : 0, NPL == 2 ? 1 : 2, NPL == 2 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+            for (int pr = 0; pr < NPAIR; ++pr)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(bl[cur][nb]), as_bf(ah[cur][mb]), acc[mb][nb], 0, 0, 0);
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(bh[cur][nb]), as_bf(al[cur][mb]), acc[mb][nb], 0, 0, 0);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(bh[cur][nb]), as_bf(ah[cur][mb]), acc[mb][nb], 0, 0, 0);
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(bv[cur][nb][PW_[pr]]), as_bf(av[cur][mb][PA_[pr]]),
+                                                                              acc[mb][nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -247,22 +250,26 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
                 }
-                if (a.gate) {       // residual in split form: group (col/8), 4 channels at position 4*half
-                    const uint2 *rp = (const uint2 *)(a.resid + (pix * (a.resid_cstride / 8) + col / 8) * 2);
-                    const uint2 rh = rp[half], rl = rp[2 + half];
-                    const unsigned hw[4] = {rh.x << 16, rh.x & 0xffff0000u, rh.y << 16, rh.y & 0xffff0000u};
-                    const unsigned lw[4] = {rl.x << 16, rl.x & 0xffff0000u, rl.y << 16, rl.y & 0xffff0000u};
+                if (a.gate) {       // residual in split form: group (col/8), 4 channels at position 4*half of every plane
+                    const uint2 *rp = (const uint2 *)(a.resid + (pix * (a.resid_cstride / 8) + col / 8) * NPL);
+                    float rs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = fmaf(gate, y[e], __uint_as_float(hw[e]) + __uint_as_float(lw[e]));
+                    for (int k = NPL - 1; k >= 0; --k) {            // smallest plane first
+                        const uint2 r = rp[2 * k + half];
+                        rs[0] += __uint_as_float(r.x << 16); rs[1] += __uint_as_float(r.x & 0xffff0000u);
+                        rs[2] += __uint_as_float(r.y << 16); rs[3] += __uint_as_float(r.y & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = fmaf(gate, y[e], rs[e]);
                 }
                 if (a.out_split) {
-                    unsigned h[4], l[4];
+                    unsigned pl[4][NPL];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) split1(y[e], h[e], l[e]);
+                    for (int e = 0; e < 4; ++e) split1<NPL>(y[e], pl[e]);
                     const int oc = a.out_coff + col;
-                    uint2 *op = (uint2 *)((float4 *)a.out + (pix * (a.out_cstride / 8) + oc / 8) * 2);
-                    op[half] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                    op[2 + half] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                    uint2 *op = (uint2 *)((float4 *)a.out + (pix * (a.out_cstride / 8) + oc / 8) * NPL);
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) op[2 * k + half] = make_uint2(pl[0][k] | (pl[1][k] << 16), pl[2][k] | (pl[3][k] << 16));
                 } else {
                     *(float4 *)((float *)a.out + pix * a.out_cstride + a.out_coff + col) = make_float4(y[0], y[1], y[2], y[3]);
                 }
@@ -274,55 +281,103 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
 }
 
 // fp32 NHWC -> split-bf16 NHWC (one thread per 8-channel group)
-__global__ void __launch_bounds__(256) k_split(const float4 *__restrict__ src, long long groups, float4 *__restrict__ dst) {
+template <int NPL>
+__global__ void __launch_bounds__(256) k_split(const float4 *__restrict__ src, long long groups, uint4 *__restrict__ dst) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups) return;
     const float4 a = src[g * 2], b = src[g * 2 + 1];
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    unsigned h[8], l[8];
+    unsigned pl[8][NPL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split1(x[e], h[e], l[e]);
-    uint4 hv = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    uint4 lv = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-    ((uint4 *)dst)[g * 2] = hv;
-    ((uint4 *)dst)[g * 2 + 1] = lv;
+    for (int e = 0; e < 8; ++e) split1<NPL>(x[e], pl[e]);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k)
+        dst[g * NPL + k] = make_uint4(pl[0][k] | (pl[1][k] << 16), pl[2][k] | (pl[3][k] << 16), pl[4][k] | (pl[5][k] << 16),
+                                      pl[6][k] | (pl[7][k] << 16));
 }
 
-template <int TH, int TW, int BN, int S, int WGM>
+template <int TH, int TW, int BN, int S, int WGM, int NPL>
 int launch3(Conv3Args a, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
     a.n_ct = a.cout_pad / BN;
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-    constexpr int PITCH = S != 1 ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));
+    constexpr int PITCH = (S != 1 || NPL == 3) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));
     constexpr int PPAD = (PH * PITCH + 63) / 64 * 64;
-    constexpr int NLD_P = (4 * PPAD + 255) / 256, NLD_W = (9 * 4 * BN + 255) / 256;
+    constexpr int NLD_P = (2 * NPL * PPAD + 255) / 256, NLD_W = (9 * 2 * NPL * BN + 255) / 256;
     const size_t lds = (size_t)2 * (NLD_P + NLD_W) * 256 * 16;
     const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
     static int resident = 0;
     if (resident == 0) {
-        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM, NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return HVPR_ERR_LAUNCH;
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM, NPL>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         resident = per_cu * cus;
     }
     long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
     if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
-    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM, NPL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     return HVPR_OK;
+}
+
+// split-bf16 NHWC -> fp32 NHWC: sum of the planes, smallest first
+template <int NPL>
+__global__ void __launch_bounds__(256) k_unsplit(const uint4 *__restrict__ src, long long groups, float4 *__restrict__ dst) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = NPL - 1; k >= 0; --k) {
+        const uint4 v = src[g * NPL + k];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[2 * e] += __uint_as_float(w[e] << 16);
+            x[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
+    }
+    dst[g * 2] = make_float4(x[0], x[1], x[2], x[3]);
+    dst[g * 2 + 1] = make_float4(x[4], x[5], x[6], x[7]);
+}
+
+template <int NPL>
+int dispatch_conv3(Conv3Args a, int stride, int tile_cfg, hipStream_t s) {
+    if (a.cout_pad % 64) return HVPR_ERR_INVALID_ARG;
+    if (NPL == 3 && stride != 1) return HVPR_ERR_UNSUPPORTED;       // the three-plane stride-2 stages do not fit the LDS
+    if (tile_cfg == 0)              // 128 px x 64 ch
+        return stride == 1 ? launch3<8, 16, 64, 1, 2, NPL>(a, s) : launch3<8, 16, 64, 2, 2, NPL == 3 ? 2 : NPL>(a, s);
+    if (tile_cfg == 1)              // 64 px x 64 ch
+        return stride == 1 ? launch3<8, 8, 64, 1, 2, NPL>(a, s) : launch3<8, 8, 64, 2, 2, NPL == 3 ? 2 : NPL>(a, s);
+    if (tile_cfg == 2) {            // 256 px x 64 ch, waves 4 x 1 (each 64 px x 64 ch): stride 1, two planes only
+        if (stride != 1 || NPL == 3) return HVPR_ERR_UNSUPPORTED;
+        return launch3<16, 16, 64, 1, 4, 2>(a, s);
+    }
+    return HVPR_ERR_INVALID_ARG;
 }
 
 }  // namespace
 
-extern "C" int hvpr_split_bf16_f32(const float *src, long long n_floats, void *dst, hvpr_stream_t stream) {
-    if (!src || !dst || n_floats < 0 || n_floats % 8 != 0) return HVPR_ERR_INVALID_ARG;
+extern "C" int hvpr_split_bf16_f32(const float *src, long long n_floats, int n_planes, void *dst, hvpr_stream_t stream) {
+    if (!src || !dst || n_floats < 0 || n_floats % 8 != 0 || (n_planes != 2 && n_planes != 3)) return HVPR_ERR_INVALID_ARG;
     if (n_floats == 0) return HVPR_OK;
     const long long groups = n_floats / 8;
-    hipLaunchKernelGGL(k_split, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, groups,
-                       (float4 *)dst);
+    const dim3 grid((unsigned)((groups + 255) / 256));
+    if (n_planes == 2) hipLaunchKernelGGL(k_split<2>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)src, groups, (uint4 *)dst);
+    else hipLaunchKernelGGL(k_split<3>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)src, groups, (uint4 *)dst);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_unsplit_bf16_f32(const void *src, long long n_floats, int n_planes, float *dst, hvpr_stream_t stream) {
+    if (!src || !dst || n_floats < 0 || n_floats % 8 != 0 || (n_planes != 2 && n_planes != 3)) return HVPR_ERR_INVALID_ARG;
+    if (n_floats == 0) return HVPR_OK;
+    const long long groups = n_floats / 8;
+    const dim3 grid((unsigned)((groups + 255) / 256));
+    if (n_planes == 2) hipLaunchKernelGGL(k_unsplit<2>, grid, dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, groups, (float4 *)dst);
+    else hipLaunchKernelGGL(k_unsplit<3>, grid, dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, groups, (float4 *)dst);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
@@ -330,9 +385,9 @@ extern "C" int hvpr_split_bf16_f32(const float *src, long long n_floats, void *d
 extern "C" int hvpr_conv2d_nhwc_bf16x3(const void *in_split, int N, int H, int W, int Cin, const void *w_split,
                                        const float *bias, int stride, int cout, int cout_pad, int relu, const float *gate,
                                        const void *resid_split, int resid_cstride, void *out, int out_split,
-                                       int out_cstride, int out_coff, int tile_cfg, hvpr_stream_t stream) {
+                                       int out_cstride, int out_coff, int tile_cfg, int n_planes, hvpr_stream_t stream) {
     if (!in_split || !w_split || !bias || !out || N < 1 || H < 1 || W < 1 || cout < 1) return HVPR_ERR_INVALID_ARG;
-    if ((gate == nullptr) != (resid_split == nullptr)) return HVPR_ERR_INVALID_ARG;
+    if ((gate == nullptr) != (resid_split == nullptr) || (n_planes != 2 && n_planes != 3)) return HVPR_ERR_INVALID_ARG;
     if (Cin % 16 != 0 || (stride != 1 && stride != 2)) return HVPR_ERR_UNSUPPORTED;
     if (cout % 4 != 0 || out_cstride % 8 != 0 || out_coff % 8 != 0 || (resid_split && resid_cstride % 8 != 0)) return HVPR_ERR_UNSUPPORTED;
     Conv3Args a;
@@ -342,19 +397,8 @@ extern "C" int hvpr_conv2d_nhwc_bf16x3(const void *in_split, int N, int H, int W
     a.OH = (H + 2 - 3) / stride + 1; a.OW = (W + 2 - 3) / stride + 1;
     a.cout_gemm = cout; a.cout_pad = cout_pad; a.out_cstride = out_cstride; a.out_coff = out_coff; a.resid_cstride = resid_cstride;
     a.relu = relu; a.out_split = out_split;
-    hipStream_t s = (hipStream_t)stream;
-    int st;
-    if (tile_cfg == 0) {            // 128 px x 64 ch
-        if (cout_pad % 64) return HVPR_ERR_INVALID_ARG;
-        st = stride == 1 ? launch3<8, 16, 64, 1, 2>(a, s) : launch3<8, 16, 64, 2, 2>(a, s);
-    } else if (tile_cfg == 1) {     // 64 px x 64 ch
-        if (cout_pad % 64) return HVPR_ERR_INVALID_ARG;
-        st = stride == 1 ? launch3<8, 8, 64, 1, 2>(a, s) : launch3<8, 8, 64, 2, 2>(a, s);
-    } else if (tile_cfg == 2) {     // 256 px x 64 ch, waves 4 x 1 (each 64 px x 64 ch): stride 1 only
-        if (cout_pad % 64) return HVPR_ERR_INVALID_ARG;
-        if (stride != 1) return HVPR_ERR_UNSUPPORTED;
-        st = launch3<16, 16, 64, 1, 4>(a, s);
-    } else return HVPR_ERR_INVALID_ARG;
+    const int st = n_planes == 2 ? dispatch_conv3<2>(a, stride, tile_cfg, (hipStream_t)stream)
+                                 : dispatch_conv3<3>(a, stride, tile_cfg, (hipStream_t)stream);
     if (st != HVPR_OK) return st;
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;

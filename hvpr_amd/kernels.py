@@ -130,53 +130,73 @@ def scatter_bev_fwd(pillar, memory, scale, coords, batch, nx, ny, workspace, m_d
     return spatial, spatial_scale
 
 
-# ------------------------------------------------------------------------------------------------ bf16x3 convolutions
+# ------------------------------------------------------------------------------------------------ split-bf16 convolutions
 class PackedConvBf3:
-    """3x3 conv weights split into bf16 hi/lo, layout [9, Cin/8, 2, cout_pad, 8] (BatchNorm scale folded), bias fp32."""
+    """3x3 conv weights split into `planes` bf16 planes, layout [9, Cin/8, planes, cout_pad, 8] (BatchNorm scale folded)."""
 
-    def __init__(self, w, bias, cin, cout, cout_pad, stride, relu, tile_cfg):
+    def __init__(self, w, bias, cin, cout, cout_pad, stride, relu, tile_cfg, planes):
         self.w, self.bias, self.cin, self.cout, self.cout_pad = w, bias, cin, cout, cout_pad
-        self.stride, self.relu, self.tile_cfg = stride, relu, tile_cfg
+        self.stride, self.relu, self.tile_cfg, self.planes = stride, relu, tile_cfg, planes
 
 
-def pack_conv_bf3(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=0):
+def _planes_of(x, planes):
+    out, r = [], x
+    for _ in range(planes):
+        h = r.to(torch.bfloat16)
+        out.append(h)
+        r = r - h.float()
+    return out
+
+
+def pack_conv_bf3(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=0, planes=2):
     cout, cin, kh, kw = weight.shape
-    assert kh == kw == 3 and cin % 16 == 0 and cout % 4 == 0
+    assert kh == kw == 3 and cin % 16 == 0 and cout % 4 == 0 and planes in (2, 3)
     w = weight.detach().float()
     if scale is not None:
         w = w * scale.view(-1, 1, 1, 1)
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
     cout_pad = (cout + 63) // 64 * 64
-    wp = torch.zeros((9, cin // 8, 2, cout_pad, 8), dtype=torch.bfloat16, device=w.device)
-    for k, part in enumerate((hi, lo)):       # (Cout, Cin, 3, 3) -> tap, chunk, ci, co -> tap, chunk, co, ci
+    wp = torch.zeros((9, cin // 8, planes, cout_pad, 8), dtype=torch.bfloat16, device=w.device)
+    for k, part in enumerate(_planes_of(w, planes)):       # (Cout, Cin, 3, 3) -> tap, chunk, ci, co -> tap, chunk, co, ci
         wp[:, :, k, :cout, :] = part.permute(2, 3, 1, 0).reshape(9, cin // 8, 8, cout).permute(0, 1, 3, 2)
     b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
     if shift is not None:
         b[:cout] = shift.detach().float()
-    return PackedConvBf3(wp.contiguous(), b, cin, cout, cout_pad, stride, relu, tile_cfg)
+    return PackedConvBf3(wp.contiguous(), b, cin, cout, cout_pad, stride, relu, tile_cfg, planes)
 
 
-def split_bf16(x):
-    """fp32 NHWC (C % 8 == 0) -> split-bf16 NHWC, returned as an fp32-typed tensor of the same shape (opaque bytes)."""
-    assert x.is_contiguous() and x.shape[-1] % 8 == 0
-    out = torch.empty_like(x)
-    check(lib().hvpr_split_bf16_f32(_ptr(x, torch.float32, "activations"), x.numel(), out.data_ptr(), _stream()), "hvpr_split_bf16_f32")
+def split_bf16(x, planes=2):
+    """fp32 NHWC (..., C), C % 8 == 0 -> split-bf16 NHWC as a bf16 tensor (..., C/8, planes, 8)."""
+    assert x.is_contiguous() and x.shape[-1] % 8 == 0 and x.dtype == torch.float32
+    out = torch.empty((*x.shape[:-1], x.shape[-1] // 8, planes, 8), dtype=torch.bfloat16, device=x.device)
+    check(lib().hvpr_split_bf16_f32(_ptr(x, torch.float32, "activations"), x.numel(), planes, out.data_ptr(), _stream()),
+          "hvpr_split_bf16_f32")
     return out
 
 
-def conv2d_nhwc_bf3(xs, pc, out_split=True, gate=None, resid=None, out=None, out_coff=0):
-    """xs: split-bf16 NHWC (N,H,W,Cin).  Returns split-bf16 NHWC (out_split) or fp32 NHWC."""
-    N, H, W, cin = xs.shape
-    assert cin == pc.cin
+def unsplit_bf16(xs):
+    """split-bf16 NHWC (..., C/8, planes, 8) -> fp32 NHWC (..., C)."""
+    assert xs.is_contiguous() and xs.dtype == torch.bfloat16 and xs.shape[-1] == 8
+    planes = xs.shape[-2]
+    out = torch.empty((*xs.shape[:-3], xs.shape[-3] * 8), dtype=torch.float32, device=xs.device)
+    check(lib().hvpr_unsplit_bf16_f32(xs.data_ptr(), out.numel(), planes, out.data_ptr(), _stream()), "hvpr_unsplit_bf16_f32")
+    return out
+
+
+def conv2d_nhwc_bf3(xs, pc, out_split=True, gate=None, resid=None):
+    """xs: split-bf16 NHWC (N,H,W,Cin/8,planes,8).  Returns split-bf16 NHWC (out_split) or fp32 NHWC (N,OH,OW,Cout)."""
+    N, H, W, groups, planes, _ = xs.shape
+    cin = groups * 8
+    assert cin == pc.cin and planes == pc.planes and xs.is_contiguous()
     OH, OW = (H + 2 - 3) // pc.stride + 1, (W + 2 - 3) // pc.stride + 1
-    if out is None:
+    if out_split:
+        assert pc.cout % 8 == 0
+        out = torch.empty((N, OH, OW, pc.cout // 8, planes, 8), dtype=torch.bfloat16, device=xs.device)
+    else:
         out = torch.empty((N, OH, OW, pc.cout), dtype=torch.float32, device=xs.device)
-    assert out.shape[:3] == (N, OH, OW) and out.is_contiguous()
-    check(lib().hvpr_conv2d_nhwc_bf16x3(_ptr(xs, torch.float32, "conv input"), N, H, W, cin, pc.w.data_ptr(), pc.bias.data_ptr(),
-                                        pc.stride, pc.cout, pc.cout_pad, 1 if pc.relu else 0, _ptr(gate, torch.float32, "gate"),
-                                        _ptr(resid, torch.float32, "resid"), 0 if resid is None else resid.shape[-1],
-                                        out.data_ptr(), 1 if out_split else 0, out.shape[-1], out_coff, pc.tile_cfg, _stream()),
+    check(lib().hvpr_conv2d_nhwc_bf16x3(xs.data_ptr(), N, H, W, cin, pc.w.data_ptr(), pc.bias.data_ptr(), pc.stride, pc.cout,
+                                        pc.cout_pad, 1 if pc.relu else 0, _ptr(gate, torch.float32, "gate"),
+                                        None if resid is None else resid.data_ptr(), 0 if resid is None else resid.shape[3] * 8,
+                                        out.data_ptr(), 1 if out_split else 0, pc.cout, 0, pc.tile_cfg, planes, _stream()),
           "hvpr_conv2d_nhwc_bf16x3")
     return out
 

@@ -218,21 +218,24 @@ int hvpr_three_nn_f32(const float *unknown, const float *known, int B, int n, in
                       hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * a5 optional precision mode: 3x3 convolutions on the bf16 matrix cores with 3-term split operands ("bf16x3":
- *     x*w ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi, fp32 accumulation; error ~2^-16 relative per product).  SURVEY.md §8d allows a
- *     reduced-precision path evidenced within the 1e-3 tolerance; hvpr_conv2d_nhwc_f32 stays the default and the parity
- *     reference.  Split-bf16 NHWC: each group of 8 channels of a pixel is [8 x bf16 hi | 8 x bf16 lo] (32 bytes).
- *     hvpr_split_bf16_f32: fp32 NHWC (n_floats % 8 == 0) -> split-bf16 NHWC (same byte count).
- *     hvpr_conv2d_nhwc_bf16x3: in_split [N,H,W,Cin] split, w_split [9, Cin/8, 2, cout_pad] x 16 B, bias [cout_pad] f32;
+ * a5 optional precision modes: 3x3 convolutions on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation)
+ *     with split operands.  n_planes = 2 ("bf16x3"): x = hi + lo, x*w ~= hi*hi + hi*lo + lo*hi, error ~2^-16 relative per
+ *     product — SURVEY.md §8d allows a reduced-precision path evidenced within the 1e-3 tolerance.  n_planes = 3 ("bf16x6"):
+ *     x = hi + mid + lo exactly, six products, dropped terms <= 2^-23 relative = the accuracy of the fp32 matrix-core kernel
+ *     (fp32 emulation).  hvpr_conv2d_nhwc_f32 stays the parity reference.
+ *     Split-bf16 NHWC: each group of 8 channels of a pixel is n_planes x [8 x bf16] (16 bytes per plane).
+ *     hvpr_split_bf16_f32 / hvpr_unsplit_bf16_f32: fp32 NHWC (n_floats % 8 == 0) <-> split-bf16 NHWC.
+ *     hvpr_conv2d_nhwc_bf16x3: in_split [N,H,W,Cin] split, w_split [9, Cin/8, n_planes, cout_pad] x 16 B, bias [cout_pad] f32;
  *     out fp32 NHWC (out_split = 0) or split NHWC (1) with out_cstride channels at channel offset out_coff; optional fused
  *     y = gate*y + resid with resid in split form.  Cin % 16 == 0, cout % 4 == 0, strides/offsets % 8 == 0.
- *     tile_cfg 0 = 128 px x 64 ch, 1 = 64 px x 64 ch.
+ *     tile_cfg 0 = 128 px x 64 ch, 1 = 64 px x 64 ch, 2 = 256 px x 64 ch (stride 1, two planes); three planes: stride 1 only.
  * ------------------------------------------------------------------------------------------- */
-int hvpr_split_bf16_f32(const float *src, long long n_floats, void *dst, hvpr_stream_t stream);
+int hvpr_split_bf16_f32(const float *src, long long n_floats, int n_planes, void *dst, hvpr_stream_t stream);
+int hvpr_unsplit_bf16_f32(const void *src, long long n_floats, int n_planes, float *dst, hvpr_stream_t stream);
 int hvpr_conv2d_nhwc_bf16x3(const void *in_split, int N, int H, int W, int Cin, const void *w_split, const float *bias,
                             int stride, int cout, int cout_pad, int relu, const float *gate, const void *resid_split,
                             int resid_cstride, void *out, int out_split, int out_cstride, int out_coff, int tile_cfg,
-                            hvpr_stream_t stream);
+                            int n_planes, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f2 ("next" row)  KITTI point pre-processing in front of the voxelizer, on the device.

@@ -150,9 +150,11 @@ def test_graph_replay_and_frame_pipeline_equal_the_serial_forward(model_and_para
             np.testing.assert_array_equal(g[k], w[k])
 
 
-def test_bf16x3_convolution_mode_stays_within_tolerance(model_and_params):
-    """Optional precision mode: trunk + SFM convolutions as 3-term split bf16 on the bf16 matrix cores.  Features and box
-    regressions must stay within the 1e-3 relative tolerance of the fp32 path (north_star); observed ~1e-5."""
+@pytest.mark.parametrize("mode,feat_tol", [("bf16x3", 1e-3), ("bf16x6", 2e-5)])
+def test_split_bf16_convolution_modes_stay_within_tolerance(model_and_params, mode, feat_tol):
+    """Optional precision modes: trunk + SFM convolutions on the bf16 matrix cores with split operands.  bf16x3 must stay within
+    the 1e-3 relative tolerance of the fp32 path (north_star; observed ~1e-5); bf16x6 (fp32 emulation) within the run-to-run
+    noise of two fp32 summation orders."""
     cfg, model, params = model_and_params
     b = _batch([synthetic.hvpr_frame(40)])
     try:
@@ -160,17 +162,17 @@ def test_bf16x3_convolution_mode_stays_within_tolerance(model_and_params):
             ref, _, bd = model(dict(b), sync=False)
             f_ref, box_ref, sc_ref = bd["spatial_features_2d"].clone(), bd["batch_box_preds"].clone(), bd["batch_max_scores"].clone()
             sel_ref = ref[0]["selected"][: int(ref[0]["pred_count"])].cpu().numpy()
-            model.backbone_2d.set_conv_precision("bf16x3")
+            model.backbone_2d.set_conv_precision(mode)
             got, _, bd = model(dict(b), sync=False)
             sel = got[0]["selected"][: int(got[0]["pred_count"])].cpu().numpy()
-        assert _rel(bd["spatial_features_2d"].cpu().numpy(), f_ref.cpu().numpy()) < 1e-3
-        assert _rel(bd["batch_box_preds"].cpu().numpy(), box_ref.cpu().numpy()) < 1e-3
+        assert _rel(bd["spatial_features_2d"].cpu().numpy(), f_ref.cpu().numpy()) < feat_tol
+        assert _rel(bd["batch_box_preds"].cpu().numpy(), box_ref.cpu().numpy()) < feat_tol
         assert float((bd["batch_max_scores"] - sc_ref).abs().max()) < 1e-3
         # the synthetic head (conv_box std 0.001, one shared cls bias) gives thousands of scores within 1e-5 of each other, so a
         # 1e-6 perturbation reorders candidates: the survivor SET is compared loosely, the tensors above strictly
         common = len(set(sel.tolist()) & set(sel_ref.tolist()))
         assert common >= 0.9 * max(len(sel_ref), 1), (common, len(sel_ref), len(sel))
-        print("bf16x3: feature rel err %.2e, box rel err %.2e, survivors %d/%d common" % (
+        print(mode + ": feature rel err %.2e, box rel err %.2e, survivors %d/%d common" % (
             _rel(bd["spatial_features_2d"].cpu().numpy(), f_ref.cpu().numpy()), _rel(bd["batch_box_preds"].cpu().numpy(), box_ref.cpu().numpy()),
             common, len(sel_ref)))
     finally:

@@ -4,43 +4,12 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hvpr_amd import kernels
-from hvpr_amd._lib import check, lib
 
 DEV = "cuda:0"
 
 
-def split_np(w):
-    """fp32 array -> (hi, lo) uint16 arrays of bf16 bits, round to nearest even."""
-    t = torch.from_numpy(np.ascontiguousarray(w, np.float32))
-    hi = t.to(torch.bfloat16)
-    lo = (t - hi.float()).to(torch.bfloat16)
-    return hi.view(torch.int16).numpy().view(np.uint16), lo.view(torch.int16).numpy().view(np.uint16)
-
-
-def pack_w(weight, scale, cout_pad):
-    """(Cout, Cin, 3, 3) -> [9, Cin/8, 2, cout_pad, 8] uint16."""
-    cout, cin = weight.shape[:2]
-    w = (weight * scale.view(-1, 1, 1, 1)).cpu().numpy()
-    hi, lo = split_np(w)
-    out = np.zeros((9, cin // 8, 2, cout_pad, 8), np.uint16)
-    for k, part in enumerate((hi, lo)):
-        p = part.transpose(2, 3, 1, 0).reshape(9, cin // 8, 8, cout)      # tap, chunk, ci, co
-        out[:, :, k, :cout, :] = p.transpose(0, 1, 3, 2)
-    return torch.from_numpy(out.view(np.int16)).to(DEV)
-
-
-def split_dev(x):
-    out = torch.empty_like(x)
-    check(lib().hvpr_split_bf16_f32(x.data_ptr(), x.numel(), out.data_ptr(), kernels._stream()), "split")
-    return out
-
-
-def conv3(xs, N, H, W, cin, wp, bias, stride, cout, cout_pad, cfg, out_split=False):
-    OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-    out = torch.empty((N, OH, OW, cout), dtype=torch.float32, device=DEV)
-    check(lib().hvpr_conv2d_nhwc_bf16x3(xs.data_ptr(), N, H, W, cin, wp.data_ptr(), bias.data_ptr(), stride, cout, cout_pad, 1, None,
-                                        None, 0, out.data_ptr(), 1 if out_split else 0, cout, 0, cfg, kernels._stream()), "conv3")
-    return out
+def conv3(xs, pc):
+    return kernels.conv2d_nhwc_bf3(xs, pc, out_split=False)
 
 
 def timeit(fn, iters=20):
@@ -65,15 +34,15 @@ for name, cin, cout, H, W, stride in SHAPES:
     ref = kernels.conv2d_nhwc(x, pc)
     t_ref = timeit(lambda: kernels.conv2d_nhwc(x, pc, out=ref))
     ref64 = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), stride=stride, padding=1).relu().permute(0, 2, 3, 1)
-    cout_pad = (cout + 63) // 64 * 64
-    wp = pack_w(w, scale, cout_pad)
-    bias = torch.zeros(cout_pad, device=DEV)
-    xs = split_dev(x)
-    line = f"{name:28s} fp32 {t_ref:7.1f} us (err vs f64 {float((ref.cpu().double() - ref64).abs().max() / ref64.abs().max()):.1e})"
-    for cfg in ((0, 1, 2) if stride == 1 else (0, 1)):
-        y = conv3(xs, 1, H, W, cin, wp, bias, stride, cout, cout_pad, cfg)
-        err = float((y.cpu().double() - ref64).abs().max() / ref64.abs().max())
-        t = timeit(lambda: conv3(xs, 1, H, W, cin, wp, bias, stride, cout, cout_pad, cfg))
-        fl = 2 * cin * cout * 9 * y.shape[1] * y.shape[2]
-        line += f" | cfg{cfg}: {t:7.1f} us {fl / t / 1e6:6.1f} TF/s-eq err {err:.1e}"
+    line = f"{name:28s} fp32 {t_ref:7.1f} us (err {float((ref.cpu().double() - ref64).abs().max() / ref64.abs().max()):.1e})"
+    for planes in (2, 3):
+        if planes == 3 and stride == 2:
+            continue
+        xs = kernels.split_bf16(x, planes)
+        for cfg in (0, 1):
+            pc3 = kernels.pack_conv_bf3(w, scale, shift, stride=stride, tile_cfg=cfg, planes=planes)
+            y = conv3(xs, pc3)
+            err = float((y.cpu().double() - ref64).abs().max() / ref64.abs().max())
+            t = timeit(lambda: conv3(xs, pc3))
+            line += f" | x{3 if planes == 2 else 6} cfg{cfg}: {t:6.1f} us err {err:.1e}"
     print(line, flush=True)
