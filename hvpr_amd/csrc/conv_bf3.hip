@@ -61,11 +61,14 @@ struct Conv3Args {
     int tiles_x, tiles_y, n_ct;
 };
 
-// WGM x WGN = the 4 waves of a workgroup along pixels x channels (2 x 2, or 4 x 1 for the 256-pixel tile)
-template <int TH, int TW, int BN, int S, int WGM, int NPL>
-__global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
+// WGM x WGN = the waves of a workgroup along pixels x channels: 4 waves as 2 x 2 (or 4 x 1 for the 256-pixel tile), or 8 waves
+// as 4 x 2.  Eight waves = two per SIMD: an LDS-DMA piece blocks the issuing wave for ~100-180 cycles, and with one wave per SIMD
+// (98+ KB of LDS stages = one workgroup per CU) nothing else can issue MFMAs meanwhile — the second wave does.
+template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4>
+__global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
     constexpr int TAPS = 9, HALO = 2, NSUB = 2, KSTAGE = KC * NSUB;
-    constexpr int WGN = 4 / WGM;
+    constexpr int NT = 64 * NWAVES;
+    constexpr int WGN = NWAVES / WGM;
     constexpr int BM = TH * TW;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MB = WM / 32, NB = WN / 32;
@@ -82,8 +85,8 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
     constexpr int PPAD = (PH * PITCH + 63) / 64 * 64;
     constexpr int PATCH_V4 = NSUB * NPL * PPAD;        // patch   [sub][plane][PPAD]
     constexpr int W_V4 = TAPS * NSUB * NPL * BN;       // weights [tap][sub][plane][BN]
-    constexpr int NLD_P = (PATCH_V4 + 255) / 256, NLD_W = (W_V4 + 255) / 256;
-    constexpr int PATCH_PAD = NLD_P * 256, W_PAD = NLD_W * 256;
+    constexpr int NLD_P = (PATCH_V4 + NT - 1) / NT, NLD_W = (W_V4 + NT - 1) / NT;
+    constexpr int PATCH_PAD = NLD_P * NT, W_PAD = NLD_W * NT;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4 *s_patch = smem;                            // [2][PATCH_PAD]
     float4 *s_w = smem + 2 * PATCH_PAD;                // [2][W_PAD]
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
     bool p_live[NLD_P];
 #pragma unroll
     for (int i = 0; i < NLD_P; ++i) {
-        const int v = tid + i * 256;
+        const int v = tid + i * NT;
         const int part = v / PPAD, pix = v % PPAD;     // part = sub * NPL + plane: 16-byte piece `part` of the stage's bytes
         p_py[i] = pix / PITCH; p_px[i] = pix % PITCH; p_part[i] = part;
         p_live[i] = v < PATCH_V4 && pix < PH * PITCH && pix % PITCH < PW;
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
     const size_t w_tap_stride = (size_t)(a.Cin / KC) * w_chunk_stride;
 #pragma unroll
     for (int i = 0; i < NLD_W; ++i) {
-        const int v = tid + i * 256;                                   // = ((tap*NSUB + sub)*NPL + plane)*BN + co_local
+        const int v = tid + i * NT;                                    // = ((tap*NSUB + sub)*NPL + plane)*BN + co_local
         wok[i] = v < W_V4;
         const int co_l = v % BN, r = v / BN;
         const int hl = r % NPL, sub = (r / NPL) % NSUB, tap = (r / NPL) / NSUB;
@@ -158,17 +161,17 @@ __global__ void __launch_bounds__(256) k_conv3(Conv3Args a) {
         const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * 16;
 #pragma unroll
         for (int i = 0; i < NLD_P; ++i)
-            if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * 256) * 16u);
+            if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * NT) * 16u);
 #pragma unroll
         for (int i = 0; i < NLD_W; ++i)
-            if (wok[i]) lds_dma16(wbase, woff0[i] + w_co0, lds_w0 + (unsigned)(buf * W_PAD + i * 256) * 16u);
+            if (wok[i]) lds_dma16(wbase, woff0[i] + w_co0, lds_w0 + (unsigned)(buf * W_PAD + i * NT) * 16u);
     };
     const bool border = iy0 < 0 || ix0 < 0 || iy0 + PH > a.H || ix0 + PW > a.W;
     if (border) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < NLD_P; ++i) s_patch[b * PATCH_PAD + tid + i * 256] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < NLD_P; ++i) s_patch[b * PATCH_PAD + tid + i * NT] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
     f32x16 acc[MB][NB];
@@ -296,7 +299,7 @@ __global__ void __launch_bounds__(256) k_split(const float4 *__restrict__ src, l
                                       pl[6][k] | (pl[7][k] << 16));
 }
 
-template <int TH, int TW, int BN, int S, int WGM, int NPL>
+template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4>
 int launch3(Conv3Args a, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
@@ -304,22 +307,23 @@ int launch3(Conv3Args a, hipStream_t s) {
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
     constexpr int PITCH = (S != 1 || NPL == 3) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));
     constexpr int PPAD = (PH * PITCH + 63) / 64 * 64;
-    constexpr int NLD_P = (2 * NPL * PPAD + 255) / 256, NLD_W = (9 * 2 * NPL * BN + 255) / 256;
-    const size_t lds = (size_t)2 * (NLD_P + NLD_W) * 256 * 16;
+    constexpr int NT = 64 * NWAVES;
+    constexpr int NLD_P = (2 * NPL * PPAD + NT - 1) / NT, NLD_W = (9 * 2 * NPL * BN + NT - 1) / NT;
+    const size_t lds = (size_t)2 * (NLD_P + NLD_W) * NT * 16;
     const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
     static int resident = 0;
     if (resident == 0) {
-        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM, NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return HVPR_ERR_LAUNCH;
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM, NPL>, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         resident = per_cu * cus;
     }
     long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
     if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
-    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM, NPL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
     return HVPR_OK;
 }
 
@@ -354,6 +358,10 @@ int dispatch_conv3(Conv3Args a, int stride, int tile_cfg, hipStream_t s) {
     if (tile_cfg == 2) {            // 256 px x 64 ch, waves 4 x 1 (each 64 px x 64 ch): stride 1, two planes only
         if (stride != 1 || NPL == 3) return HVPR_ERR_UNSUPPORTED;
         return launch3<16, 16, 64, 1, 4, 2>(a, s);
+    }
+    if (tile_cfg == 3) {            // 128 px x 64 ch, EIGHT waves 4 x 2 (each 32 px x 32 ch): stride 1
+        if (stride != 1) return HVPR_ERR_UNSUPPORTED;
+        return launch3<8, 16, 64, 1, 4, NPL, 8>(a, s);
     }
     return HVPR_ERR_INVALID_ARG;
 }
