@@ -95,7 +95,7 @@ class BaseBEVBackbone_Scale(nn.Module):
         self.overlap_branches = os.environ.get("HVPR_BEV_STREAMS", "2") != "1"
         # "fp32": exact fp32 matrix-core kernel (default, the parity reference).  "bf16x3" / "bf16x6": trunk and SFM 3x3
         # convolutions on the bf16 matrix cores with operands split into 2 / 3 bf16 planes (kernels.conv2d_nhwc_bf3):
-        # ~5e-6 relative error per layer / the fp32 kernel's own ~1.5e-6 (fp32 emulation; stride-2 layers stay on the fp32 kernel)
+        # ~5e-6 relative error per layer / the fp32 kernel's own ~1.5e-6 (fp32 emulation)
         self.conv_precision = os.environ.get("HVPR_CONV_PRECISION", model_cfg.get("CONV_PRECISION", "fp32"))
         assert self.conv_precision in self.PRECISIONS
 
@@ -138,12 +138,10 @@ class BaseBEVBackbone_Scale(nn.Module):
             lv["sfm"] = kernels.pack_conv(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=cfg)
             planes = self.PRECISIONS[self.conv_precision]
             if planes:
-                c3 = 1 if h * w < 20000 else 0        # 64-pixel tiles on the small levels, 128-pixel tiles on level 0
+                c3 = 4                                # 64 px x 64 ch tiles, weights staged per kernel row (2-3 workgroups per CU)
                 lv["convs3"] = []
                 sc, sh = bn_scale_shift(blk[2])
-                # three planes: the stride-2 stages do not fit the LDS — that layer stays on the fp32 kernel (None here)
-                lv["convs3"].append(None if (planes == 3 and s != 1) else
-                                    kernels.pack_conv_bf3(blk[1].weight, sc, sh, stride=s, tile_cfg=c3, planes=planes))
+                lv["convs3"].append(kernels.pack_conv_bf3(blk[1].weight, sc, sh, stride=s, tile_cfg=c3, planes=planes))
                 for k in range(self.layer_nums[i]):
                     sc, sh = bn_scale_shift(blk[5 + 3 * k])
                     lv["convs3"].append(kernels.pack_conv_bf3(blk[4 + 3 * k].weight, sc, sh, tile_cfg=c3, planes=planes))
@@ -211,11 +209,8 @@ class BaseBEVBackbone_Scale(nn.Module):
             x = kernels.split_bf16(x, planes)  # the trunk runs in split-bf16 form from here on
         for i, lv in enumerate(P["levels"]):
             if bf3:
-                for k, pc in enumerate(lv["convs3"]):
-                    if pc is None:             # stride-2 layer of the three-plane mode: fp32 kernel between two conversions
-                        x = kernels.split_bf16(kernels.conv2d_nhwc(kernels.unsplit_bf16(x), lv["convs"][k]), planes)
-                    else:
-                        x = kernels.conv2d_nhwc_bf3(x, pc)
+                for pc in lv["convs3"]:
+                    x = kernels.conv2d_nhwc_bf3(x, pc)
             else:
                 for pc in lv["convs"]:
                     x = kernels.conv2d_nhwc(x, pc)

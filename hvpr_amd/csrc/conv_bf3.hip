@@ -64,9 +64,13 @@ struct Conv3Args {
 // WGM x WGN = the waves of a workgroup along pixels x channels: 4 waves as 2 x 2 (or 4 x 1 for the 256-pixel tile), or 8 waves
 // as 4 x 2.  Eight waves = two per SIMD: an LDS-DMA piece blocks the issuing wave for ~100-180 cycles, and with one wave per SIMD
 // (98+ KB of LDS stages = one workgroup per CU) nothing else can issue MFMAs meanwhile — the second wave does.
-template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4>
+// ROWS: the weight slab is staged one kernel row (3 taps) at a time instead of all 9 taps per K=16 step: stages of 20-30 KB
+// instead of 45-73 KB, so that 2-3 workgroups fit a CU and hide each other's LDS-DMA issue stalls and barrier waits (the regime
+// the fp32 kernel lives in); the patch of a K step is staged with its first row and kept for the three rows.
+template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4, bool ROWS = false>
 __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
     constexpr int TAPS = 9, HALO = 2, NSUB = 2, KSTAGE = KC * NSUB;
+    constexpr int STAPS = ROWS ? 3 : 9;                // taps per weight stage
     constexpr int NT = 64 * NWAVES;
     constexpr int WGN = NWAVES / WGM;
     constexpr int BM = TH * TW;
@@ -80,11 +84,11 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
     // slots of the 256-byte bank row.  A 32-lane half covers 2 rows of 16 pixels (pitch 32) or 4 rows of 8 pixels (pitch 24):
     // with these pitches every group sees all 16 slots, for every tap offset; the natural pitch PW (18 / 10) is 2-3 way
     // conflicted (SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE before).
-    constexpr int PITCH = (S != 1 || NPL == 3) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));   // three planes: no LDS left for the pad
+    constexpr int PITCH = (S != 1 || NPL == 3 || ROWS) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));   // pad only where LDS allows
     static_assert(PITCH >= PW, "pitch must hold a patch row");
     constexpr int PPAD = (PH * PITCH + 63) / 64 * 64;
     constexpr int PATCH_V4 = NSUB * NPL * PPAD;        // patch   [sub][plane][PPAD]
-    constexpr int W_V4 = TAPS * NSUB * NPL * BN;       // weights [tap][sub][plane][BN]
+    constexpr int W_V4 = STAPS * NSUB * NPL * BN;      // weights [tap of the stage][sub][plane][BN]
     constexpr int NLD_P = (PATCH_V4 + NT - 1) / NT, NLD_W = (W_V4 + NT - 1) / NT;
     constexpr int PATCH_PAD = NLD_P * NT, W_PAD = NLD_W * NT;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -156,15 +160,19 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
     const unsigned w_co0 = (unsigned)(co0 * 16);
     const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * (a.Cin / 8 * NPL));
 
-    auto stage = [&](int chunk, int buf) {
+    // one stage: the weights of kernel row `ky` (all rows when !ROWS) of K step `chunk` into weight slot wbuf and, if asked,
+    // the patch of that K step into patch slot pbuf
+    auto stage = [&](int chunk, int ky, int wbuf, int pbuf, bool with_patch) {
         const char *pbase = in_n + (size_t)chunk * (NSUB * NPL * 16);
-        const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * 16;
+        const char *wbase = (const char *)a.wpk + ((size_t)chunk * NSUB * w_chunk_stride + (size_t)ky * 3 * w_tap_stride) * 16;
+        if (with_patch) {
 #pragma unroll
-        for (int i = 0; i < NLD_P; ++i)
-            if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * NT) * 16u);
+            for (int i = 0; i < NLD_P; ++i)
+                if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(pbuf * PATCH_PAD + i * NT) * 16u);
+        }
 #pragma unroll
         for (int i = 0; i < NLD_W; ++i)
-            if (wok[i]) lds_dma16(wbase, woff0[i] + w_co0, lds_w0 + (unsigned)(buf * W_PAD + i * NT) * 16u);
+            if (wok[i]) lds_dma16(wbase, woff0[i] + w_co0, lds_w0 + (unsigned)(wbuf * W_PAD + i * NT) * 16u);
     };
     const bool border = iy0 < 0 || ix0 < 0 || iy0 + PH > a.H || ix0 + PW > a.W;
     if (border) {
@@ -182,31 +190,38 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
-    auto chunk_step = [&](int c, auto buf_tag) {
-        constexpr int BUF = decltype(buf_tag)::value;
+    // one stage of multiplies: wait for it, let the next stage stream in, multiply.  Slots are compile-time constants (the loops
+    // below are unrolled over them) so that every LDS address is an immediate offset.
+    auto step = [&](int c, int ky, auto wbuf_tag, auto pbuf_tag) {
+        constexpr int WBUF = decltype(wbuf_tag)::value, PBUF = decltype(pbuf_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
-        const float4 *sp = s_patch + BUF * PATCH_PAD;
-        const float4 *sw = s_w + BUF * W_PAD;
+        if (ROWS) {
+            if (ky < 2) stage(c, ky + 1, WBUF ^ 1, PBUF, false);
+            else if (c + 1 < n_chunks) stage(c + 1, 0, WBUF ^ 1, PBUF ^ 1, true);
+        } else if (c + 1 < n_chunks) {
+            stage(c + 1, 0, WBUF ^ 1, PBUF ^ 1, true);
+        }
+        const float4 *sp = s_patch + PBUF * PATCH_PAD;
+        const float4 *sw = s_w + WBUF * W_PAD;
         constexpr int PF = 2;
         float4 av[PF + 1][MB][NPL], bv[PF + 1][NB][NPL];
-        auto lds_load = [&](int tap, int slot) {
-            const int ky = tap / 3, kx = tap % 3;
+        auto lds_load = [&](int t, int slot) {            // t = tap inside the stage
+            const int row = ROWS ? ky : t / 3, kx = ROWS ? t : t % 3;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) av[slot][mb][k] = sp[a_off[mb] + ky * PITCH + kx + k * PPAD];
+                for (int k = 0; k < NPL; ++k) av[slot][mb][k] = sp[a_off[mb] + row * PITCH + kx + k * PPAD];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) bv[slot][nb][k] = sw[b_off[nb] + tap * NSUB * NPL * BN + k * BN];
+                for (int k = 0; k < NPL; ++k) bv[slot][nb][k] = sw[b_off[nb] + t * NSUB * NPL * BN + k * BN];
         };
 #pragma unroll
         for (int t = 0; t < PF; ++t) lds_load(t, t);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            if (tap + PF < TAPS) lds_load(tap + PF, (tap + PF) % (PF + 1));
+        for (int tap = 0; tap < STAPS; ++tap) {
+            if (tap + PF < STAPS) lds_load(tap + PF, (tap + PF) % (PF + 1));
             __builtin_amdgcn_sched_barrier(0);
             const int cur = tap % (PF + 1);
             // plane pairs (weight plane, activation plane), smallest terms first; every pass walks all blocks so that
@@ -225,12 +240,22 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    stage(0, 0);
-    for (int c = 0; c + 1 < n_chunks; c += 2) {
-        chunk_step(c, std::integral_constant<int, 0>{});
-        chunk_step(c + 1, std::integral_constant<int, 1>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    stage(0, 0, 0, 0, true);
+    if (ROWS) {     // six stages per pair of K steps: weight slots 0,1,0,1,0,1, patch slots 0,0,0,1,1,1
+        for (int c = 0; c + 1 < n_chunks; c += 2) {
+            step(c, 0, I0{}, I0{}); step(c, 1, I1{}, I0{}); step(c, 2, I0{}, I0{});
+            step(c + 1, 0, I1{}, I1{}); step(c + 1, 1, I0{}, I1{}); step(c + 1, 2, I1{}, I1{});
+        }
+        if (n_chunks & 1) { step(n_chunks - 1, 0, I0{}, I0{}); step(n_chunks - 1, 1, I1{}, I0{}); step(n_chunks - 1, 2, I0{}, I0{}); }
+    } else {
+        for (int c = 0; c + 1 < n_chunks; c += 2) {
+            step(c, 0, I0{}, I0{});
+            step(c + 1, 0, I1{}, I1{});
+        }
+        if (n_chunks & 1) step(n_chunks - 1, 0, I0{}, I0{});
     }
-    if (n_chunks & 1) chunk_step(n_chunks - 1, std::integral_constant<int, 0>{});
 
     // epilogue: a lane holds one pixel x 16 channels in four runs of four consecutive channels (8g + 4*half + 0..3)
 #pragma unroll
@@ -299,31 +324,31 @@ __global__ void __launch_bounds__(256) k_split(const float4 *__restrict__ src, l
                                       pl[6][k] | (pl[7][k] << 16));
 }
 
-template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4>
+template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4, bool ROWS = false>
 int launch3(Conv3Args a, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
     a.n_ct = a.cout_pad / BN;
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-    constexpr int PITCH = (S != 1 || NPL == 3) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));
+    constexpr int PITCH = (S != 1 || NPL == 3 || ROWS) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));
     constexpr int PPAD = (PH * PITCH + 63) / 64 * 64;
     constexpr int NT = 64 * NWAVES;
-    constexpr int NLD_P = (2 * NPL * PPAD + NT - 1) / NT, NLD_W = (9 * 2 * NPL * BN + NT - 1) / NT;
+    constexpr int NLD_P = (2 * NPL * PPAD + NT - 1) / NT, NLD_W = ((ROWS ? 3 : 9) * 2 * NPL * BN + NT - 1) / NT;
     const size_t lds = (size_t)2 * (NLD_P + NLD_W) * NT * 16;
     const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
     static int resident = 0;
     if (resident == 0) {
-        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return HVPR_ERR_LAUNCH;
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         resident = per_cu * cus;
     }
     long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
     if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
-    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
     return HVPR_OK;
 }
 
@@ -350,7 +375,7 @@ __global__ void __launch_bounds__(256) k_unsplit(const uint4 *__restrict__ src, 
 template <int NPL>
 int dispatch_conv3(Conv3Args a, int stride, int tile_cfg, hipStream_t s) {
     if (a.cout_pad % 64) return HVPR_ERR_INVALID_ARG;
-    if (NPL == 3 && stride != 1) return HVPR_ERR_UNSUPPORTED;       // the three-plane stride-2 stages do not fit the LDS
+    if (NPL == 3 && stride != 1 && tile_cfg != 4) return HVPR_ERR_UNSUPPORTED;   // three-plane stride-2 stages fit only row-staged
     if (tile_cfg == 0)              // 128 px x 64 ch
         return stride == 1 ? launch3<8, 16, 64, 1, 2, NPL>(a, s) : launch3<8, 16, 64, 2, 2, NPL == 3 ? 2 : NPL>(a, s);
     if (tile_cfg == 1)              // 64 px x 64 ch
@@ -362,6 +387,12 @@ int dispatch_conv3(Conv3Args a, int stride, int tile_cfg, hipStream_t s) {
     if (tile_cfg == 3) {            // 128 px x 64 ch, EIGHT waves 4 x 2 (each 32 px x 32 ch): stride 1
         if (stride != 1) return HVPR_ERR_UNSUPPORTED;
         return launch3<8, 16, 64, 1, 4, NPL, 8>(a, s);
+    }
+    if (tile_cfg == 4)              // 64 px x 64 ch, weights staged per kernel row (2-3 workgroups per CU)
+        return stride == 1 ? launch3<8, 8, 64, 1, 2, NPL, 4, true>(a, s) : launch3<8, 8, 64, 2, 2, NPL, 4, true>(a, s);
+    if (tile_cfg == 5) {            // 128 px x 64 ch, per kernel row
+        if (stride != 1) return HVPR_ERR_UNSUPPORTED;
+        return launch3<8, 16, 64, 1, 2, NPL, 4, true>(a, s);
     }
     return HVPR_ERR_INVALID_ARG;
 }

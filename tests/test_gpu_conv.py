@@ -89,14 +89,14 @@ def test_split_roundtrip(planes):
 
 
 @pytest.mark.parametrize("planes", [2, 3])
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 5])
 @pytest.mark.parametrize("cin,cout,stride,H,W", [(16, 32, 1, 11, 19), (32, 128, 1, 16, 24), (64, 96, 2, 17, 23),
-                                                 (128, 256, 2, 24, 36), (256, 64, 1, 9, 33)])
+                                                 (128, 256, 2, 24, 36), (256, 64, 1, 9, 33), (48, 64, 1, 20, 20)])
 def test_split_bf16_conv_vs_float64(planes, cfg, cin, cout, stride, H, W):
     """bf16x3 stays two orders of magnitude inside the 1e-3 tolerance of north_star; bf16x6 is as close to float64 as the
     exact fp32 matrix-core kernel is (a few 1e-6)."""
-    if planes == 3 and stride == 2:
-        pytest.skip("three planes: stride-1 layers only (the stride-2 stages do not fit the LDS)")
+    if stride == 2 and (cfg in (3, 5) or (planes == 3 and cfg != 4)):
+        pytest.skip("stride 2: tile configurations 0, 1, 4 (three planes: 4 only)")
     g = torch.Generator().manual_seed(cin * 1000 + cout + cfg)
     x = _rand(g, 2, cin, H, W)
     w = _rand(g, cout, cin, 3, 3) / np.sqrt(cin * 9)
@@ -112,7 +112,7 @@ def test_split_bf16_conv_vs_float64(planes, cfg, cin, cout, stride, H, W):
 
 
 @pytest.mark.parametrize("planes", [2, 3])
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 5])
 def test_split_bf16_sfm_step_gate_residual(planes, cfg):
     g = torch.Generator().manual_seed(177 + cfg)
     x = _rand(g, 1, 64, 13, 21)
