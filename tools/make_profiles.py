@@ -2,6 +2,7 @@
 
   profiles/r01_kernel_stats_single_graph.csv   rocprofv3 --kernel-trace --stats of `bench.py --no-pipeline` (serial frame graph)
   profiles/r01_kernel_stats_pipeline.csv       same of the default `bench.py` (frame pipeline; also holds the latency-mode and probe replays)
+  profiles/r01_kernel_stats_single_graph_bf16x6.csv / _bf16x3.csv   same with --conv-precision bf16x6 / bf16x3 (copied by hand)
   profiles/r01_pmc_hbm_traffic.csv             per-kernel FETCH_SIZE / WRITE_SIZE (two separate --pmc passes), per frame
   profiles/roofline_traffic.json               the two totals bench.py quotes in `roofline.traffic`
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM /
