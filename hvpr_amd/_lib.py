@@ -42,6 +42,7 @@ SIGNATURES = {
     "hvpr_split_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),
     "hvpr_unsplit_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),
     "hvpr_conv2d_nhwc_bf16x3": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "hvpr_deconv_nhwc_bf16x3": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "hvpr_point_flags_f32": (_I, [_P, _I, _I, _I, _P, _F, _P, _P, _I, _I, _P, _P]),
     "hvpr_compact_workspace_bytes": (_Z, [_I]),
     "hvpr_compact_rows_f32": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),

@@ -147,6 +147,11 @@ class BaseBEVBackbone_Scale(nn.Module):
                     lv["convs3"].append(kernels.pack_conv_bf3(blk[4 + 3 * k].weight, sc, sh, tile_cfg=c3, planes=planes))
                 sc, sh = bn_scale_shift(self.sfmblocks_down[i][1])
                 lv["sfm3"] = kernels.pack_conv_bf3(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=c3, planes=planes)
+                de = self.deblocks[i]
+                sc, sh = bn_scale_shift(de[1])
+                # two planes: the deconvolution runs split as well; three planes: its six-product 1x1 is slower than the fp32 kernel
+                lv["deconv3"] = kernels.pack_deconv_bf3(de[0].weight, sc, sh, planes=planes) \
+                    if (planes == 2 and de[0].weight.shape[0] % 64 == 0) else None
             sl = self.scale_layers[i]
             sc, sh = bn_scale_shift(sl[2])
             lv["scale"] = kernels.pack_conv(sl[1].weight, sc, sh, stride=s, tile_cfg=_tile_cfg(h, w, sl[1].weight.shape[0]))
@@ -226,13 +231,17 @@ class BaseBEVBackbone_Scale(nn.Module):
                 x_att = x
                 nsfm = self.sfm_layer_nums[i]
                 for it in range(nsfm):
-                    if bf3:     # the last step hands fp32 to the (fp32) deconvolution
-                        x_att = kernels.conv2d_nhwc_bf3(x_att, lv["sfm3"], out_split=it + 1 < nsfm, gate=gate, resid=x_att)
+                    if bf3:     # the last step hands fp32 to the deconvolution only when that one runs on the fp32 kernel
+                        x_att = kernels.conv2d_nhwc_bf3(x_att, lv["sfm3"], out_split=(it + 1 < nsfm or lv["deconv3"] is not None),
+                                                        gate=gate, resid=x_att)
                     else:
                         x_att = kernels.conv2d_nhwc(x_att, lv["sfm"], gate=gate, resid=x_att)
-                if bf3 and nsfm == 0:
-                    raise NotImplementedError("bf16x3 path needs SFM_LAYER_NUMS >= 1 on every level")
-                kernels.conv2d_nhwc(x_att, lv["deconv"], out=out, out_coff=coff)
+                if bf3 and lv["deconv3"] is not None:
+                    kernels.deconv_nhwc_bf3(x_att, lv["deconv3"], out, out_coff=coff)
+                elif bf3 and nsfm == 0:
+                    kernels.conv2d_nhwc(kernels.unsplit_bf16(x_att), lv["deconv"], out=out, out_coff=coff)
+                else:
+                    kernels.conv2d_nhwc(x_att, lv["deconv"], out=out, out_coff=coff)
                 if two_streams and not capturing:     # eager mode: keep the caching allocator from recycling early
                     for t in (x, out):
                         t.record_stream(side)

@@ -58,6 +58,7 @@ struct Conv3Args {
     const float *gate;    // [N, OH, OW] or null
     const float4 *resid;  // split-bf16 NHWC, resid_cstride channels, or null
     int N, H, W, Cin, OH, OW, cout_gemm, cout_pad, out_cstride, out_coff, resid_cstride, relu, out_split;
+    int up, cout_real;    // 1x1 kernel as ConvTranspose2d(kernel = stride = up): gemm column = (ky*up + kx) * cout_real + co
     int tiles_x, tiles_y, n_ct;
 };
 
@@ -67,10 +68,14 @@ struct Conv3Args {
 // ROWS: the weight slab is staged one kernel row (3 taps) at a time instead of all 9 taps per K=16 step: stages of 20-30 KB
 // instead of 45-73 KB, so that 2-3 workgroups fit a CU and hide each other's LDS-DMA issue stalls and barrier waits (the regime
 // the fp32 kernel lives in); the patch of a K step is staged with its first row and kept for the three rows.
-template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4, bool ROWS = false>
+// ONE: 1x1 kernel (the ConvTranspose k = s layers): no halo, and a stage holds FOUR K=16 steps ("virtual taps" at the same pixel).
+template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4, bool ROWS = false, bool ONE = false>
 __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
-    constexpr int TAPS = 9, HALO = 2, NSUB = 2, KSTAGE = KC * NSUB;
-    constexpr int STAPS = ROWS ? 3 : 9;                // taps per weight stage
+    static_assert(!ONE || (!ROWS && S == 1), "1x1: stride 1, whole stages");
+    constexpr int HALO = ONE ? 0 : 2, NSUB = 2;
+    constexpr int STAPS = ONE ? 4 : (ROWS ? 3 : 9);    // taps (1x1: K=16 steps) per weight stage
+    constexpr int KSTEPS = ONE ? 4 : 1;                // K=16 steps per stage
+    constexpr int KSTAGE = KC * NSUB * KSTEPS;         // input channels per stage
     constexpr int NT = 64 * NWAVES;
     constexpr int WGN = NWAVES / WGM;
     constexpr int BM = TH * TW;
@@ -84,10 +89,10 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
     // slots of the 256-byte bank row.  A 32-lane half covers 2 rows of 16 pixels (pitch 32) or 4 rows of 8 pixels (pitch 24):
     // with these pitches every group sees all 16 slots, for every tap offset; the natural pitch PW (18 / 10) is 2-3 way
     // conflicted (SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE before).
-    constexpr int PITCH = (S != 1 || NPL == 3 || ROWS) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));   // pad only where LDS allows
+    constexpr int PITCH = (S != 1 || NPL == 3 || ROWS || ONE) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));   // pad only where LDS allows
     static_assert(PITCH >= PW, "pitch must hold a patch row");
     constexpr int PPAD = (PH * PITCH + 63) / 64 * 64;
-    constexpr int PATCH_V4 = NSUB * NPL * PPAD;        // patch   [sub][plane][PPAD]
+    constexpr int PATCH_V4 = KSTEPS * NSUB * NPL * PPAD;   // patch   [K step][sub][plane][PPAD]
     constexpr int W_V4 = STAPS * NSUB * NPL * BN;      // weights [tap of the stage][sub][plane][BN]
     constexpr int NLD_P = (PATCH_V4 + NT - 1) / NT, NLD_W = (W_V4 + NT - 1) / NT;
     constexpr int PATCH_PAD = NLD_P * NT, W_PAD = NLD_W * NT;
@@ -119,7 +124,8 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
         wok[i] = v < W_V4;
         const int co_l = v % BN, r = v / BN;
         const int hl = r % NPL, sub = (r / NPL) % NSUB, tap = (r / NPL) / NSUB;
-        woff0[i] = wok[i] ? (unsigned)(((size_t)tap * w_tap_stride + (size_t)sub * w_chunk_stride + (size_t)hl * a.cout_pad + co_l) * 16) : 0u;
+        const size_t tap_stride = ONE ? NSUB * w_chunk_stride : w_tap_stride;      // 1x1: the next K=16 step
+        woff0[i] = wok[i] ? (unsigned)(((size_t)tap * tap_stride + (size_t)sub * w_chunk_stride + (size_t)hl * a.cout_pad + co_l) * 16) : 0u;
     }
     int a_off[MB];
 #pragma unroll
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
     const int ty = pt % a.tiles_y;
     const int n = pt / a.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int iy0 = oy0 * S - HALO / 2, ix0 = ox0 * S - HALO / 2;
     const int co0 = ct * BN;
 
     unsigned poff[NLD_P];
@@ -163,8 +169,8 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
     // one stage: the weights of kernel row `ky` (all rows when !ROWS) of K step `chunk` into weight slot wbuf and, if asked,
     // the patch of that K step into patch slot pbuf
     auto stage = [&](int chunk, int ky, int wbuf, int pbuf, bool with_patch) {
-        const char *pbase = in_n + (size_t)chunk * (NSUB * NPL * 16);
-        const char *wbase = (const char *)a.wpk + ((size_t)chunk * NSUB * w_chunk_stride + (size_t)ky * 3 * w_tap_stride) * 16;
+        const char *pbase = in_n + (size_t)chunk * (KSTEPS * NSUB * NPL * 16);
+        const char *wbase = (const char *)a.wpk + ((size_t)chunk * KSTEPS * NSUB * w_chunk_stride + (size_t)ky * 3 * w_tap_stride) * 16;
         if (with_patch) {
 #pragma unroll
             for (int i = 0; i < NLD_P; ++i)
@@ -208,10 +214,11 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
         float4 av[PF + 1][MB][NPL], bv[PF + 1][NB][NPL];
         auto lds_load = [&](int t, int slot) {            // t = tap inside the stage
             const int row = ROWS ? ky : t / 3, kx = ROWS ? t : t % 3;
+            const int shift = ONE ? t * NSUB * NPL * PPAD : row * PITCH + kx;     // 1x1: the planes of K step t, same pixel
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) av[slot][mb][k] = sp[a_off[mb] + row * PITCH + kx + k * PPAD];
+                for (int k = 0; k < NPL; ++k) av[slot][mb][k] = sp[a_off[mb] + shift + k * PPAD];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -298,6 +305,11 @@ __global__ void __launch_bounds__(64 * NWAVES) k_conv3(Conv3Args a) {
                     uint2 *op = (uint2 *)((float4 *)a.out + (pix * (a.out_cstride / 8) + oc / 8) * NPL);
 #pragma unroll
                     for (int k = 0; k < NPL; ++k) op[2 * k + half] = make_uint2(pl[0][k] | (pl[1][k] << 16), pl[2][k] | (pl[3][k] << 16));
+                } else if (a.up > 1) {      // ConvTranspose2d(kernel = stride = up): column -> (sub-pixel, channel)
+                    const int sub = col / a.cout_real, co = col - sub * a.cout_real;
+                    const int sy = sub / a.up, sx = sub % a.up;
+                    const size_t opix = ((size_t)n * a.OH * a.up + (oy * a.up + sy)) * ((size_t)a.OW * a.up) + (ox * a.up + sx);
+                    *(float4 *)((float *)a.out + opix * a.out_cstride + a.out_coff + co) = make_float4(y[0], y[1], y[2], y[3]);
                 } else {
                     *(float4 *)((float *)a.out + pix * a.out_cstride + a.out_coff + col) = make_float4(y[0], y[1], y[2], y[3]);
                 }
@@ -324,31 +336,31 @@ __global__ void __launch_bounds__(256) k_split(const float4 *__restrict__ src, l
                                       pl[6][k] | (pl[7][k] << 16));
 }
 
-template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4, bool ROWS = false>
+template <int TH, int TW, int BN, int S, int WGM, int NPL, int NWAVES = 4, bool ROWS = false, bool ONE = false>
 int launch3(Conv3Args a, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
     a.n_ct = a.cout_pad / BN;
-    constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-    constexpr int PITCH = (S != 1 || NPL == 3 || ROWS) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));
+    constexpr int PH = (TH - 1) * S + (ONE ? 1 : 3), PW = (TW - 1) * S + (ONE ? 1 : 3);
+    constexpr int PITCH = (S != 1 || NPL == 3 || ROWS || ONE) ? PW : (TW == 16 ? 32 : (TW == 8 ? 24 : PW));
     constexpr int PPAD = (PH * PITCH + 63) / 64 * 64;
     constexpr int NT = 64 * NWAVES;
-    constexpr int NLD_P = (2 * NPL * PPAD + NT - 1) / NT, NLD_W = ((ROWS ? 3 : 9) * 2 * NPL * BN + NT - 1) / NT;
+    constexpr int NLD_P = ((ONE ? 4 : 1) * 2 * NPL * PPAD + NT - 1) / NT, NLD_W = ((ONE ? 4 : (ROWS ? 3 : 9)) * 2 * NPL * BN + NT - 1) / NT;
     const size_t lds = (size_t)2 * (NLD_P + NLD_W) * NT * 16;
     const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
     static int resident = 0;
     if (resident == 0) {
-        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return HVPR_ERR_LAUNCH;
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS, ONE>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         resident = per_cu * cus;
     }
     long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
     if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
-    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((k_conv3<TH, TW, BN, S, WGM, NPL, NWAVES, ROWS, ONE>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
     return HVPR_OK;
 }
 
@@ -435,9 +447,28 @@ extern "C" int hvpr_conv2d_nhwc_bf16x3(const void *in_split, int N, int H, int W
     a.N = N; a.H = H; a.W = W; a.Cin = Cin;
     a.OH = (H + 2 - 3) / stride + 1; a.OW = (W + 2 - 3) / stride + 1;
     a.cout_gemm = cout; a.cout_pad = cout_pad; a.out_cstride = out_cstride; a.out_coff = out_coff; a.resid_cstride = resid_cstride;
-    a.relu = relu; a.out_split = out_split;
+    a.relu = relu; a.out_split = out_split; a.up = 1; a.cout_real = cout;
     const int st = n_planes == 2 ? dispatch_conv3<2>(a, stride, tile_cfg, (hipStream_t)stream)
                                  : dispatch_conv3<3>(a, stride, tile_cfg, (hipStream_t)stream);
+    if (st != HVPR_OK) return st;
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_deconv_nhwc_bf16x3(const void *in_split, int N, int H, int W, int Cin, const void *w_split, const float *bias,
+                                       int cout, int cout_pad, int up, int relu, float *out, int out_cstride, int out_coff,
+                                       int n_planes, hvpr_stream_t stream) {
+    if (!in_split || !w_split || !bias || !out || N < 1 || H < 1 || W < 1 || cout < 1 || up < 1) return HVPR_ERR_INVALID_ARG;
+    if (n_planes != 2 && n_planes != 3) return HVPR_ERR_INVALID_ARG;
+    if (Cin % 64 != 0 || cout % 4 != 0 || out_cstride % 4 != 0 || out_coff % 4 != 0 || cout_pad % 64 != 0 || cout_pad < cout * up * up)
+        return HVPR_ERR_UNSUPPORTED;
+    Conv3Args a;
+    a.in = (const float4 *)in_split; a.wpk = (const float4 *)w_split; a.bias = bias; a.out = out; a.gate = nullptr; a.resid = nullptr;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W;
+    a.cout_gemm = cout * up * up; a.cout_pad = cout_pad; a.out_cstride = out_cstride; a.out_coff = out_coff; a.resid_cstride = 0;
+    a.relu = relu; a.out_split = 0; a.up = up; a.cout_real = cout;
+    const int st = n_planes == 2 ? launch3<8, 8, 64, 1, 2, 2, 4, false, true>(a, (hipStream_t)stream)
+                                 : launch3<8, 8, 64, 1, 2, 3, 4, false, true>(a, (hipStream_t)stream);
     if (st != HVPR_OK) return st;
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;

@@ -164,6 +164,35 @@ def pack_conv_bf3(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=
     return PackedConvBf3(wp.contiguous(), b, cin, cout, cout_pad, stride, relu, tile_cfg, planes)
 
 
+def pack_deconv_bf3(weight, scale, shift, relu=True, planes=2):
+    """ConvTranspose2d weight (Cin, Cout, s, s), kernel == stride == s -> 1x1 GEMM with s*s*Cout columns, split planes."""
+    cin, cout, s, s2 = weight.shape
+    assert s == s2 and cin % 64 == 0 and cout % 4 == 0 and planes in (2, 3)
+    w = weight.detach().float() * scale.view(1, -1, 1, 1)
+    cols = s * s * cout
+    cout_pad = (cols + 63) // 64 * 64
+    g = w.permute(0, 2, 3, 1).reshape(cin, cols)                          # column = (ky*s + kx)*Cout + co
+    wp = torch.zeros((1, cin // 8, planes, cout_pad, 8), dtype=torch.bfloat16, device=w.device)
+    for k, part in enumerate(_planes_of(g, planes)):
+        wp[0, :, k, :cols, :] = part.reshape(cin // 8, 8, cols).permute(0, 2, 1)
+    b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
+    b[:cols] = shift.detach().float().repeat(s * s)
+    pc = PackedConvBf3(wp.contiguous(), b, cin, cout, cout_pad, 1, relu, 1, planes)
+    pc.up = s
+    return pc
+
+
+def deconv_nhwc_bf3(xs, pc, out, out_coff=0):
+    """xs split-bf16 NHWC (N,H,W,Cin/8,planes,8) -> fp32 into out[..., out_coff:out_coff+Cout] at pc.up x the resolution."""
+    N, H, W, groups, planes, _ = xs.shape
+    assert groups * 8 == pc.cin and planes == pc.planes and xs.is_contiguous()
+    assert out.shape[:3] == (N, H * pc.up, W * pc.up) and out.is_contiguous() and out.dtype == torch.float32
+    check(lib().hvpr_deconv_nhwc_bf16x3(xs.data_ptr(), N, H, W, pc.cin, pc.w.data_ptr(), pc.bias.data_ptr(), pc.cout, pc.cout_pad,
+                                        pc.up, 1 if pc.relu else 0, out.data_ptr(), out.shape[-1], out_coff, planes, _stream()),
+          "hvpr_deconv_nhwc_bf16x3")
+    return out
+
+
 def split_bf16(x, planes=2):
     """fp32 NHWC (..., C), C % 8 == 0 -> split-bf16 NHWC as a bf16 tensor (..., C/8, planes, 8)."""
     assert x.is_contiguous() and x.shape[-1] % 8 == 0 and x.dtype == torch.float32

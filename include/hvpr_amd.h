@@ -236,6 +236,12 @@ int hvpr_conv2d_nhwc_bf16x3(const void *in_split, int N, int H, int W, int Cin, 
                             int stride, int cout, int cout_pad, int relu, const float *gate, const void *resid_split,
                             int resid_cstride, void *out, int out_split, int out_cstride, int out_coff, int tile_cfg,
                             int n_planes, hvpr_stream_t stream);
+/* ConvTranspose2d(kernel = stride = up)+BN+ReLU of the same modes (base_bev_backbone.py:177-188): split input, w_split
+ * [1, Cin/8, n_planes, cout_pad] x 16 B with gemm column (ky*up + kx)*cout + co, fp32 output written into channels
+ * [out_coff, out_coff + cout) of an NHWC tensor of out_cstride channels at up x the resolution.  Cin % 64 == 0. */
+int hvpr_deconv_nhwc_bf16x3(const void *in_split, int N, int H, int W, int Cin, const void *w_split, const float *bias, int cout,
+                            int cout_pad, int up, int relu, float *out, int out_cstride, int out_coff, int n_planes,
+                            hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f2 ("next" row)  KITTI point pre-processing in front of the voxelizer, on the device.

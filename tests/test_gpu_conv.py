@@ -127,3 +127,19 @@ def test_split_bf16_sfm_step_gate_residual(planes, cfg):
         y = kernels.conv2d_nhwc_bf3(xs, pc, out_split=out_split, gate=gd, resid=xs)
         y = kernels.unsplit_bf16(y) if out_split else y
         _close(y.permute(0, 3, 1, 2).cpu().double(), ref, tol=TOL[planes])
+
+
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("s,cin,cout", [(1, 64, 16), (2, 128, 24), (4, 256, 128)])
+def test_split_bf16_deconv_into_concat_slice(planes, s, cin, cout):
+    g = torch.Generator().manual_seed(900 + s)
+    x = _rand(g, 2, cin, 7, 9)
+    w = _rand(g, cin, cout, s, s) / np.sqrt(cin)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, _rand(g, cout) * 0.3
+    ref = F.relu(F.conv_transpose2d(x.double(), w.double(), stride=s) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    pc = kernels.pack_deconv_bf3(w.to(DEV), scale.to(DEV), shift.to(DEV), planes=planes)
+    out = torch.full((2, 7 * s, 9 * s, cout + 40), -7.0, device=DEV)
+    xs = kernels.split_bf16(x.permute(0, 2, 3, 1).contiguous().to(DEV), planes)
+    o = kernels.deconv_nhwc_bf3(xs, pc, out, out_coff=24)
+    _close(o[..., 24:24 + cout].permute(0, 3, 1, 2).cpu().double(), ref, tol=TOL[planes])
+    assert (o[..., :24] == -7).all() and (o[..., 24 + cout:] == -7).all()

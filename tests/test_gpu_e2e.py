@@ -166,14 +166,17 @@ def test_split_bf16_convolution_modes_stay_within_tolerance(model_and_params, mo
             got, _, bd = model(dict(b), sync=False)
             sel = got[0]["selected"][: int(got[0]["pred_count"])].cpu().numpy()
         assert _rel(bd["spatial_features_2d"].cpu().numpy(), f_ref.cpu().numpy()) < feat_tol
-        assert _rel(bd["batch_box_preds"].cpu().numpy(), box_ref.cpu().numpy()) < feat_tol
+        gb, rb = bd["batch_box_preds"].cpu().numpy(), box_ref.cpu().numpy()
+        assert _rel(gb[..., :6], rb[..., :6]) < feat_tol
+        # heading: the direction bin is an argmax of two logits; a near-tie may flip it (by the period) under any perturbation
+        assert (np.abs(gb[..., 6] - rb[..., 6]) < feat_tol * np.abs(rb[..., 6]).max()).mean() > 0.9999
         assert float((bd["batch_max_scores"] - sc_ref).abs().max()) < 1e-3
         # the synthetic head (conv_box std 0.001, one shared cls bias) gives thousands of scores within 1e-5 of each other, so a
         # 1e-6 perturbation reorders candidates: the survivor SET is compared loosely, the tensors above strictly
         common = len(set(sel.tolist()) & set(sel_ref.tolist()))
         assert common >= 0.9 * max(len(sel_ref), 1), (common, len(sel_ref), len(sel))
         print(mode + ": feature rel err %.2e, box rel err %.2e, survivors %d/%d common" % (
-            _rel(bd["spatial_features_2d"].cpu().numpy(), f_ref.cpu().numpy()), _rel(bd["batch_box_preds"].cpu().numpy(), box_ref.cpu().numpy()),
+            _rel(bd["spatial_features_2d"].cpu().numpy(), f_ref.cpu().numpy()), _rel(gb[..., :6], rb[..., :6]),
             common, len(sel_ref)))
     finally:
         model.backbone_2d.set_conv_precision("fp32")
