@@ -29,11 +29,18 @@ def _batch(frames):
     return {"points": torch.from_numpy(pts).to(DEV), "batch_size": len(frames)}
 
 
-def test_forward_one_frame_matches_oracle(model_and_params):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3"])
+def test_forward_one_frame_matches_oracle(model_and_params, precision):
+    """The whole detector against the CPU oracle, with the SAME thresholds for the exact fp32 convolutions and for the two
+    split-bf16 modes (bf16x6 = fp32 emulation, bf16x3 = three products)."""
     cfg, model, params = model_and_params
     frames = [synthetic.hvpr_frame(0)]
-    with torch.no_grad():
-        preds, recall, bd = model(_batch(frames))
+    model.backbone_2d.set_conv_precision(precision)
+    try:
+        with torch.no_grad():
+            preds, recall, bd = model(_batch(frames))
+    finally:
+        model.backbone_2d.set_conv_precision("fp32")
     ref_preds, inter = O.forward_frames(frames, params, O.cfg_from_model_cfg(cfg))
     # a1: voxel indices bit-exact
     m = len(inter["voxel_coords"])
