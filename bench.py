@@ -212,19 +212,19 @@ def main():
             # reported next to the headline, never as `value`: the same pipeline with the trunk/SFM 3x3 convolutions on the bf16
             # matrix cores with split operands
             alt = []
-            for mode, what, tol in (
+            for prec, what, tol in (
                     ("bf16x6", "operands split into 3 bf16 planes (exact), 6 products, fp32 accumulate: fp32 emulation — per-layer error vs "
                                "float64 1.2e-6..1.8e-6, the same as the exact fp32 kernel (1.3e-6..1.8e-6)", "fp32-grade (tests/test_gpu_conv.py: 4e-6)"),
                     ("bf16x3", "operands split into 2 bf16 planes, 3 products, fp32 accumulate: ~2^-16 per product",
                      "features / boxes within 1e-3 relative of the fp32 path (tests/test_gpu_e2e.py), observed ~1e-5")):
-                model.backbone_2d.set_conv_precision(mode)
+                model.backbone_2d.set_conv_precision(prec)
                 p3 = detector.PipelinedForward(model, batches[0])
                 dt3 = timed(p3)
                 for _ in p3.flush():
                     pass
                 del p3
-                alt.append({"mode": mode, "what": what + "; v_mfma_f32_32x32x16_bf16; everything else as in `value` (opt-in: "
-                            "HVPR_CONV_PRECISION=" + mode + ")", "value": round(world * args.steps / dt3, 2), "unit": "frames/s",
+                alt.append({"mode": prec, "what": what + "; v_mfma_f32_32x32x16_bf16; everything else as in `value` (opt-in: "
+                            "HVPR_CONV_PRECISION=" + prec + ")", "value": round(world * args.steps / dt3, 2), "unit": "frames/s",
                             "ms_per_step": round(1e3 * dt3 / args.steps, 4), "tolerance": tol})
             model.backbone_2d.set_conv_precision("fp32")
 
