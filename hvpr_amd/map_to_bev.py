@@ -136,10 +136,28 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         # softmax (60 M elements per sample, 26 % of a training step when materialised) is skipped, and the logits are
         # formed transposed so that the top-k runs along the contiguous dimension.
         with torch.no_grad():
-            idx = torch.topk(pillars @ points.t(), self.k, dim=1)[1]              # (M, k), descending
+            idx = self._topk_points(pillars.detach(), points.detach())            # (M, k), descending
         positives = points[idx]                                                    # (M, k, C)
         w = torch.softmax(torch.bmm(pillars.unsqueeze(1), positives.transpose(1, 2)).squeeze(1), dim=1)
         return (w.detach().unsqueeze(2) * positives).sum(dim=1), positives
+
+    def _topk_points(self, pillars, points):
+        """Indices (M, k) of the k points with the largest pillar . point logits, descending.  On the GPU the (M, N) logits are
+        never materialised: the memory read-out kernel (logits on the matrix cores into LDS + exact wave-level top-k) runs
+        over the points in blocks of <= 2048 "items", and the k * blocks candidates per pillar are re-ranked exactly."""
+        k, N = self.k, points.shape[0]
+        nb = (N + 2047) // 2048                                        # blocks of (almost) equal size, each <= 2048 items
+        if not pillars.is_cuda or pillars.shape[1] != 64 or pillars.shape[0] == 0 or N < k * max(nb, 1):
+            return torch.topk(pillars @ points.t(), k, dim=1)[1]
+        bounds = [(i * N) // nb for i in range(nb + 1)]
+        pf = pillars.contiguous()
+        cand = []
+        for s, e in zip(bounds[:-1], bounds[1:]):
+            _, idx = kernels.memory_readout_fwd(pf, points[s:e].contiguous(), k, want_idx=True)
+            cand.append(idx.long() + s)
+        cand = torch.cat(cand, dim=1)                                  # (M, k * blocks): a superset of the global top-k
+        logit = (points[cand] * pf.unsqueeze(1)).sum(dim=2)            # exact re-ranking of the candidates
+        return cand.gather(1, torch.topk(logit, k, dim=1)[1])
 
     def _forward_train(self, batch_dict):
         """Training branch, pointpillar_scatter.py:87-167: three canvases (memory-fed, point-fed, scale)."""

@@ -98,3 +98,19 @@ def test_training_steps_run_and_reduce_the_loss():
     with torch.no_grad():
         preds, _, _ = model({"points": batch["points"][batch["points"][:, 0] == 0].contiguous(), "batch_size": 1})
     assert preds[0]["pred_boxes"].shape[1] == 7
+
+
+def test_get_score_topk_through_the_readout_kernel_equals_torch_topk():
+    from hvpr_amd.map_to_bev import PointPillarScatter_Agg_Memory_1_scale
+    cfg = hvpr_car_cfg()
+    mod = PointPillarScatter_Agg_Memory_1_scale(cfg.MODEL.MAP_TO_BEV, grid_size=np.array([296, 248, 1])).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    for M, N in ((3000, 16384), (257, 5000), (64, 2048 + 7), (10, 25)):
+        pillars, points = torch.randn(M, 64, generator=g).to(DEV), torch.randn(N, 64, generator=g).to(DEV)
+        got = mod._topk_points(pillars, points)
+        logits = pillars @ points.t()
+        want = torch.topk(logits, mod.k, dim=1)
+        assert got.shape == (M, mod.k)
+        # same top-k VALUES in the same (descending) order; indices equal wherever the values are distinct
+        np.testing.assert_allclose(logits.gather(1, got).cpu().numpy(), want[0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert (got == want[1]).float().mean() > 0.999
