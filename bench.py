@@ -64,6 +64,24 @@ def conv_flops(model, H, W):
     return fl
 
 
+def split_conv_flops(model, H, W, precision):
+    """2*MACs of the layers the split-bf16 modes run on the bf16 matrix cores: trunk + SFM 3x3 (and the deconvolutions in bf16x3)."""
+    bb = model.backbone_2d
+    fl = 0
+    h, w = H, W
+    for i, blk in enumerate(bb.blocks):
+        s = bb.layer_strides[i]
+        h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        for c in [m for m in blk if isinstance(m, torch.nn.Conv2d)]:
+            fl += 2 * c.in_channels * c.out_channels * 9 * h * w
+        sf = bb.sfmblocks_down[i][0]
+        fl += bb.sfm_layer_nums[i] * 2 * sf.in_channels * sf.out_channels * 9 * h * w
+        if precision == "bf16x3":
+            de = bb.deblocks[i][0]
+            fl += 2 * de.in_channels * de.out_channels * (h * w) * int(bb.upsample_strides[i]) ** 2
+    return fl
+
+
 class StagedGraphs:
     """The same forward as MixAnchor_Memory.forward(sync=False), captured as THREE hipGraphs (VFE+scatter group,
     backbone+head+decode, top-k+NMS) so that each group can be bracketed by HIP events on the launch stream without
@@ -223,9 +241,23 @@ def main():
                 for _ in p3.flush():
                     pass
                 del p3
+                sg3, bb_ms = StagedGraphs(model, batches[0]), 0.0       # backbone + head + decode alone, HIP events
+                for i in range(10):
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    sg3.run(batches[i % N_POOL], ev)
+                    torch.cuda.synchronize()
+                    bb_ms += ev[1].elapsed_time(ev[2]) / 10
+                del sg3
+                nprod = {"bf16x6": 6, "bf16x3": 3}[prec]
+                fl_all, fl_split = conv_flops(model, int(ds.grid_size[1]), int(ds.grid_size[0])), split_conv_flops(model, int(ds.grid_size[1]), int(ds.grid_size[0]), prec)
+                executed = nprod * fl_split          # bf16 products executed on the bf16 matrix cores (the rest runs on the fp32 kernel)
                 alt.append({"mode": prec, "what": what + "; v_mfma_f32_32x32x16_bf16; everything else as in `value` (opt-in: "
                             "HVPR_CONV_PRECISION=" + prec + ")", "value": round(world * args.steps / dt3, 2), "unit": "frames/s",
-                            "ms_per_step": round(1e3 * dt3 / args.steps, 4), "tolerance": tol})
+                            "ms_per_step": round(1e3 * dt3 / args.steps, 4), "tolerance": tol,
+                            "mfma": {"backbone_head_decode_ms": round(bb_ms, 4), "algorithmic_TFLOPs": round(fl_all / (bb_ms * 1e-3) / 1e12, 1),
+                                     "executed_bf16_TFLOPs": round(executed / (bb_ms * 1e-3) / 1e12, 1), "bf16_dense_peak_TFLOPs": 2500.0,
+                                     "frac_of_bf16_peak": round(executed / (bb_ms * 1e-3) / 1e12 / 2500.0, 4),
+                                     "note": "executed = products x FLOPs of the layers that run split; fp32 peak for comparison 157.3"}})
             model.backbone_2d.set_conv_precision("fp32")
 
         # ---- per-stage probe (untimed): HIP events on the launch stream ----
