@@ -100,9 +100,7 @@ class StagedGraphs:
         pool = None
         with torch.no_grad():
             with torch.cuda.graph(self.graphs[0]):
-                bd = model.voxelize_on_device(dict(self.static_in))
-                bd = model.vfe(bd)
-                bd = model.map_to_bev_module(bd)
+                bd = model.stage_encode(dict(self.static_in))
             pool = self.graphs[0].pool()
             with torch.cuda.graph(self.graphs[1], pool=pool):
                 bd = model.backbone_2d(bd)

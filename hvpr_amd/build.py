@@ -26,12 +26,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, timing=False):
+    """timing=True: a second library, libhvpr_amd_timing.so, with -DHVPR_EXP_TIMING (in-kernel cycle counters printed by a
+    few kernels; kernel experiments only — load it with HVPR_AMD_LIB=...)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "hvpr_amd.h"))
-    objdir = os.path.join(HERE, "csrc", "_obj")
+    objdir = os.path.join(HERE, "csrc", "_obj_timing" if timing else "_obj")
+    out = os.path.join(HERE, "libhvpr_amd_timing.so") if timing else OUT
+    extra = ["-DHVPR_EXP_TIMING"] if timing else []
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     objs = []
@@ -40,7 +44,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + COMMON + PER_FILE.get(s, []) + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + COMMON + extra + PER_FILE.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -49,10 +53,10 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(OUT, objs):
-        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs)
+    if force or jobs or _stale(out, objs):
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
     build_cpu(force, verbose)
-    return OUT
+    return out
 
 
 def build_cpu(force=False, verbose=False):
@@ -67,4 +71,4 @@ def build_cpu(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timing="--timing" in sys.argv))

@@ -29,16 +29,35 @@ struct hvpr_carver {
 
 __device__ __forceinline__ int hvpr_lane() { return threadIdx.x & 63; }
 
-// butterfly reductions over the full 64-lane wave or within 32-lane halves
-template <int WIDTH>
-__device__ __forceinline__ float hvpr_reduce_sum(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// All-lanes reductions over the 64-lane wave or within its 32-lane halves, without the LDS crossbar: two quad permutes, the two
+// row mirrors (after the quad steps every lane of a quad holds the same value, so mirroring combines exactly the groups an
+// xor butterfly would), then v_permlane16_swap / v_permlane32_swap (gfx950) across the 16-lane rows.  Same reduction tree as
+// the __shfl_xor butterfly — bit-identical results, commutativity aside nothing changes — at a few VALU cycles per step
+// instead of a ds_bpermute round trip (~60+ cycles each: 95 of them were 3 us of the pillar VFE).
+template <int CTRL>
+__device__ __forceinline__ float hvpr_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+struct hvpr_op_sum { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct hvpr_op_max { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+template <int WIDTH, typename Op>
+__device__ __forceinline__ float hvpr_reduce(float v, Op op) {
+    static_assert(WIDTH == 32 || WIDTH == 64, "wave halves or the whole wave");
+    v = op(v, hvpr_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = op(v, hvpr_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = op(v, hvpr_dpp<0x141>(v));   // row_half_mirror
+    v = op(v, hvpr_dpp<0x140>(v));   // row_mirror
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    if (WIDTH == 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
     return v;
 }
 template <int WIDTH>
-__device__ __forceinline__ float hvpr_reduce_max(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float hvpr_reduce_sum(float v) { return hvpr_reduce<WIDTH>(v, hvpr_op_sum()); }
+template <int WIDTH>
+__device__ __forceinline__ float hvpr_reduce_max(float v) { return hvpr_reduce<WIDTH>(v, hvpr_op_max()); }

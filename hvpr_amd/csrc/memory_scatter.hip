@@ -2,6 +2,7 @@
 //   a3 replaces MemoryUnit_Agg.forward eval branch, map_to_bev/memory_module.py:60-77
 //   a4 replaces PointPillarScatter_Agg_Memory_1_scale.forward eval branch, map_to_bev/pointpillar_scatter.py:169-222
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -67,7 +68,8 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                                                              const float *__restrict__ bank, int n_items, int k,
                                                              float *__restrict__ out, int *__restrict__ topk_idx,
                                                              const int4 *__restrict__ coords, int batch, int nx, int ny,
-                                                             int *__restrict__ cell_map) {
+                                                             int *__restrict__ cell_map, float *__restrict__ canvas,
+                                                             int canvas_channels, int canvas_offset) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_logit = (float *)smem;                              // [kPillars][kItemsPad]
     float *s_f = s_logit + kPillars * kItemsPad;                 // [kPillars][kC]
@@ -252,10 +254,12 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         for (int r = 0; r < 32; ++r) esum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r));
         const float a = e / esum;
         if (topk_idx && lane < k) topk_idx[(size_t)(p0 + p) * k + lane] = idx;
-        if (cell_map && lane == 0) {   // fused a3+a4: this pillar's entry of the scatter cell map (k_cell_map's job)
+        long long cell = -1;           // fused a3+a4: this pillar's BEV cell (pointpillar_scatter.py:192, nz == 1)
+        if (cell_map || canvas) {
             const int4 c = coords[p0 + p];
             if ((unsigned)c.x < (unsigned)batch && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx)
-                cell_map[((size_t)c.x * ny + c.z) * nx + c.w] = p0 + p;
+                cell = ((long long)c.x * ny + c.z) * nx + c.w;
+            if (cell_map && lane == 0 && cell >= 0) cell_map[cell] = p0 + p;   // gather-form scatter: k_cell_map's job
         }
         // lane = channel.  All 32 candidate rows are requested before the first is used (lanes >= k carry weight 0 and
         // row 0), so the gather costs one L2 round trip instead of k dependent ones.
@@ -266,6 +270,8 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
 #pragma unroll
         for (int r = 0; r < 32; ++r) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), r)), rows[r], acc);
         out[(size_t)(p0 + p) * kC + lane] = acc;
+        // fused encode path: the memory channels of this pillar's cell, straight into the pre-cleared NHWC canvas
+        if (canvas && cell >= 0) canvas[(size_t)cell * canvas_channels + canvas_offset + lane] = acc;
     }
 #ifdef HVPR_EXP_TIMING
     if (blockIdx.x == 3 && lane == 0) printf("readout wave %d: mfma phase %lld cycles, select+gather %lld cycles\n", wid, tt1 - tt0, (long long)__builtin_readcyclecounter() - tt1);
@@ -347,12 +353,17 @@ int launch_scatter(const float *pillar, const float *memory, const float *scale,
 
 namespace {
 int launch_canvas(const float *, int, const float *, int, const float *, int, long long, int *, float *, float *, hipStream_t);
-int launch_readout(const float *f, int M, const int32_t *m_device, const float *bank, int n_items, int k, float *out,
-                   int32_t *topk_idx, const int32_t *coords, int batch, int nx, int ny, int *cell_map, hvpr_stream_t stream) {
+}  // namespace
+
+int hvpr_i_readout(const float *f, int M, const int32_t *m_device, const float *bank, int n_items, int k, float *out,
+                   int32_t *topk_idx, const int32_t *coords, int batch, int nx, int ny, int *cell_map, float *canvas,
+                   int canvas_channels, int canvas_offset, hipStream_t stream) {
     if (M < 0 || n_items < 1 || k < 1) return HVPR_ERR_INVALID_ARG;
     if (k > 32 || k > n_items || n_items > kItemsPad) return HVPR_ERR_UNSUPPORTED;
     if (M == 0) return HVPR_OK;
     if (!f || !bank || !out) return HVPR_ERR_INVALID_ARG;
+    if ((cell_map || canvas) && !coords) return HVPR_ERR_INVALID_ARG;
+    if (canvas && canvas_offset + kC > canvas_channels) return HVPR_ERR_INVALID_ARG;
     const size_t lds = (size_t)kPillars * kItemsPad * 4 + kPillars * kC * 4 + (kThreads / 64) * 64 * 8;
     static bool attr_set = false;
     if (!attr_set) {
@@ -361,10 +372,18 @@ int launch_readout(const float *f, int M, const int32_t *m_device, const float *
             return HVPR_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_memory_readout, dim3(hvpr_cdiv(M, kPillars)), dim3(kThreads), lds, (hipStream_t)stream, f, M,
-                       m_device, bank, n_items, k, out, topk_idx, (const int4 *)coords, batch, nx, ny, cell_map);
+    hipLaunchKernelGGL(k_memory_readout, dim3(hvpr_cdiv(M, kPillars)), dim3(kThreads), lds, stream, f, M, m_device, bank,
+                       n_items, k, out, topk_idx, (const int4 *)coords, batch, nx, ny, cell_map, canvas, canvas_channels,
+                       canvas_offset);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
+}
+
+namespace {
+int launch_readout(const float *f, int M, const int32_t *m_device, const float *bank, int n_items, int k, float *out,
+                   int32_t *topk_idx, const int32_t *coords, int batch, int nx, int ny, int *cell_map, hvpr_stream_t stream) {
+    return hvpr_i_readout(f, M, m_device, bank, n_items, k, out, topk_idx, coords, batch, nx, ny, cell_map, nullptr, 0, 0,
+                          (hipStream_t)stream);
 }
 }  // namespace
 

@@ -13,51 +13,9 @@
 //   K3 each point appends its index to its voxel's arena segment (unordered)
 //   K4 one wave per voxel: bitonic selection of the max_points smallest indices (ascending), gather.
 #include "common.h"
+#include "internal.h"
 
 namespace {
-
-constexpr int kScanThreads = 256;
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanThreads * kScanItems;
-constexpr int kIdle = 0x7fffffff;
-
-struct VoxWs {
-    int *cell_first;   // [B*ncell]  idle: kIdle
-    int *cell_count;   // [B*ncell]  idle: 0
-    int *cell_vid;     // [B*ncell]  scratch
-    int *pt_cell;      // [N]
-    int *vox_cell;     // [N] by global rank
-    int *vox_count;    // [N]
-    int *vox_arena;    // [N]
-    int *vox_first;    // [N]
-    int *arena;        // [N]
-    int *frame_base;   // [B+1] rank of the first voxel of each frame (uncapped)
-    unsigned long long *tile_state;   // [tiles]
-    int *ticket;       // [1]
-};
-
-__host__ VoxWs carve(void *ws, int batch, int n, long long ncell) {
-    hvpr_carver c(ws);
-    VoxWs w;
-    w.cell_first = c.take<int>((size_t)batch * ncell);
-    w.cell_count = c.take<int>((size_t)batch * ncell);
-    w.cell_vid = c.take<int>((size_t)batch * ncell);
-    w.pt_cell = c.take<int>(n);
-    w.vox_cell = c.take<int>(n);
-    w.vox_count = c.take<int>(n);
-    w.vox_arena = c.take<int>(n);
-    w.vox_first = c.take<int>(n);
-    w.arena = c.take<int>(n);
-    w.frame_base = c.take<int>(batch + 1);
-    w.tile_state = c.take<unsigned long long>(hvpr_cdiv(n > 0 ? n : 1, kScanTile));
-    w.ticket = c.take<int>(1);
-    return w;
-}
-
-__host__ size_t ws_bytes(int batch, int n, long long ncell) {
-    VoxWs w = carve(nullptr, batch, n, ncell);
-    return (size_t)((char *)(w.ticket) - (char *)nullptr) + 256;
-}
 
 __device__ __forceinline__ int frame_of(const int *__restrict__ off, int batch, int i) {
     // largest b in [0,batch) with off[b] <= i
@@ -116,13 +74,15 @@ __global__ void __launch_bounds__(kScanThreads) k2_scan(int n, const int *__rest
     unsigned fl[kScanItems], ct[kScanItems];
     unsigned ta = 0, tb = 0;
 #pragma unroll
+    for (int k = 0; k < kScanItems; ++k) gcell[k] = (base + k < n) ? w.pt_cell[base + k] : -1;
+    int first[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) first[k] = gcell[k] >= 0 ? w.cell_first[gcell[k]] : -1;
+#pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        const int i = base + k;
-        gcell[k] = -1; fl[k] = 0; ct[k] = 0;
-        if (i < n) {
-            const int g = w.pt_cell[i];
-            if (g >= 0 && w.cell_first[g] == i) { gcell[k] = g; fl[k] = 1; ct[k] = (unsigned)w.cell_count[g]; }
-        }
+        fl[k] = 0; ct[k] = 0;
+        if (gcell[k] >= 0 && first[k] == base + k) { fl[k] = 1; ct[k] = (unsigned)w.cell_count[gcell[k]]; }
+        else gcell[k] = -1;
         ta += fl[k]; tb += ct[k];
     }
     // block exclusive scan of (ta, tb)
@@ -141,27 +101,38 @@ __global__ void __launch_bounds__(kScanThreads) k2_scan(int n, const int *__rest
         if (k < wid) { wa += s_wave_a[k]; wb += s_wave_b[k]; }
         tot_a += s_wave_a[k]; tot_b += s_wave_b[k];
     }
-    // decoupled look-back (one lane; the tile word is both data and flag — single 8-byte agent-scope store)
-    if (threadIdx.x == 0) {
+    // Decoupled look-back by wave 0, 64 predecessors per step (the tile word is both data and flag — one 8-byte
+    // agent-scope store).  Every tile publishes its own aggregate as soon as it has it, so a tile normally needs ONE
+    // round of loads: it adds the aggregates down to the nearest tile that already knows its inclusive prefix.
+    if (wid == 0) {
         unsigned ea = 0, eb = 0;
-        if (tile == 0) {
-            __hip_atomic_store(&w.tile_state[0], pack(2u, tot_a, tot_b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(&w.tile_state[tile], pack(1u, tot_a, tot_b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int t = tile - 1; t >= 0; --t) {
-                unsigned long long s;
-                do {
-                    s = __hip_atomic_load(&w.tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((s >> 62) == 0) __builtin_amdgcn_s_sleep(1);
-                } while ((s >> 62) == 0);
-                ea += (unsigned)((s >> 31) & 0x7fffffffu);
-                eb += (unsigned)(s & 0x7fffffffu);
-                if ((s >> 62) == 2) break;
-            }
-            __hip_atomic_store(&w.tile_state[tile], pack(2u, ea + tot_a, eb + tot_b), __ATOMIC_RELAXED,
+        if (lane == 0)
+            __hip_atomic_store(&w.tile_state[tile], pack(tile == 0 ? 2u : 1u, tot_a, tot_b), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+        for (int hi = tile - 1; hi >= 0; hi -= 64) {
+            const int t = hi - lane;
+            unsigned long long st = 0ull;
+            for (;;) {
+                if (t >= 0 && (st >> 62) == 0)
+                    st = __hip_atomic_load(&w.tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__ballot(t >= 0 && (st >> 62) == 0) == 0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned long long incl = __ballot(t >= 0 && (st >> 62) == 2);
+            const int stop = incl ? __ffsll((long long)incl) - 1 : 63;   // nearest predecessor with an inclusive prefix
+            unsigned pa = (t >= 0 && lane <= stop) ? (unsigned)((st >> 31) & 0x7fffffffu) : 0u;
+            unsigned pb = (t >= 0 && lane <= stop) ? (unsigned)(st & 0x7fffffffu) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o, 64); pb += __shfl_xor(pb, o, 64); }
+            ea += pa; eb += pb;
+            if (incl) break;
         }
-        s_excl_a = ea; s_excl_b = eb;
+        if (lane == 0) {
+            if (tile != 0)
+                __hip_atomic_store(&w.tile_state[tile], pack(2u, ea + tot_a, eb + tot_b), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_excl_a = ea; s_excl_b = eb;
+        }
     }
     __syncthreads();
     unsigned ra = s_excl_a + wa + (ia - ta);   // exclusive prefix of this thread's first item
@@ -176,10 +147,7 @@ __global__ void __launch_bounds__(kScanThreads) k2_scan(int n, const int *__rest
                 for (int bb = b; bb >= 0 && foff[bb] == i; --bb) w.frame_base[bb] = (int)ra;
             if (fl[k]) {
                 w.cell_vid[gcell[k]] = (int)ra;
-                w.vox_cell[ra] = gcell[k];
-                w.vox_count[ra] = (int)ct[k];
-                w.vox_arena[ra] = (int)rb;
-                w.vox_first[ra] = i;
+                w.vox_rec[ra] = make_int4(gcell[k], (int)ct[k], (int)rb, i);
             }
             if (i == n - 1) {
                 const int total = (int)(ra + fl[k]);
@@ -191,7 +159,7 @@ __global__ void __launch_bounds__(kScanThreads) k2_scan(int n, const int *__rest
 }
 
 __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ foff, int batch, int max_voxels, VoxWs w,
-                                               int *__restrict__ voxel_offsets) {
+                                               int *__restrict__ voxel_offsets, int keep_cell_first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         int acc = 0;
@@ -209,8 +177,8 @@ __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ fo
     const int b = frame_of(foff, batch, i);
     const int local = r - w.frame_base[b];
     const int slot = atomicSub(&w.cell_count[g], 1) - 1;   // returns the map to its idle 0
-    w.cell_first[g] = kIdle;                               // idle again (benign same-value race)
-    if (local < max_voxels) w.arena[w.vox_arena[r] + slot] = i;
+    if (!keep_cell_first) w.cell_first[g] = kIdle;         // idle again (benign same-value race)
+    if (local < max_voxels) w.arena[w.vox_rec[r].z + slot] = i;
 }
 
 __device__ __forceinline__ int bitonic64_asc(int v, int lane) {
@@ -247,10 +215,11 @@ __global__ void __launch_bounds__(256) k4_gather(const float *__restrict__ pts, 
         int cutoff = kIdle;
         if (cap_mode == 1) {
             const int rc = w.frame_base[b] + max_voxels;
-            if (rc < w.frame_base[b + 1]) cutoff = w.vox_first[rc];
+            if (rc < w.frame_base[b + 1]) cutoff = w.vox_rec[rc].w;
         }
-        const int cnt = w.vox_count[r];
-        const int a0 = w.vox_arena[r];
+        const int4 rec = w.vox_rec[r];
+        const int cnt = rec.y;
+        const int a0 = rec.z;
         // the max_points smallest indices, ascending, in lanes [0, max_points)
         int v = lane < cnt ? w.arena[a0 + lane] : kIdle;
         v = bitonic64_asc(v, lane);
@@ -274,7 +243,7 @@ __global__ void __launch_bounds__(256) k4_gather(const float *__restrict__ pts, 
             }
         }
         if (lane == 0) {
-            const int g = w.vox_cell[r];
+            const int g = rec.x;
             const int cx = g % nx, cy = (g / nx) % ny, cz = (g / (nx * ny)) % nz;
             reinterpret_cast<int4 *>(coords)[o] = make_int4(b, cz, cy, cx);
             num_points[o] = num;
@@ -284,17 +253,29 @@ __global__ void __launch_bounds__(256) k4_gather(const float *__restrict__ pts, 
 
 }  // namespace
 
+int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool keep_cell_first, hipStream_t s) {
+    const int tiles = hvpr_cdiv(a.n_points, kScanTile);
+    const int pblocks = hvpr_cdiv(a.n_points, 256);
+    hipLaunchKernelGGL(k1_keys, dim3(pblocks), dim3(256), 0, s, a.points, a.n_points, a.point_stride, a.xyz_col, a.frame_offsets,
+                       a.batch, a.lo_x, a.lo_y, a.lo_z, a.vs_x, a.vs_y, a.vs_z, a.nx, a.ny, a.nz, w, tiles);
+    hipLaunchKernelGGL(k2_scan, dim3(tiles), dim3(kScanThreads), 0, s, a.n_points, a.frame_offsets, a.batch, w);
+    hipLaunchKernelGGL(k3_fill, dim3(pblocks), dim3(256), 0, s, a.n_points, a.frame_offsets, a.batch, a.max_voxels, w,
+                       voxel_offsets, keep_cell_first ? 1 : 0);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
 extern "C" size_t hvpr_voxelize_workspace_bytes(int batch, int n_points, int nx, int ny, int nz) {
     if (batch < 1 || n_points < 0 || nx < 1 || ny < 1 || nz < 1) return 0;
-    return ws_bytes(batch, n_points > 0 ? n_points : 1, (long long)nx * ny * nz);
+    return hvpr_vox_ws_bytes(batch, n_points > 0 ? n_points : 1, (long long)nx * ny * nz);
 }
 
 extern "C" int hvpr_voxelize_workspace_reset(void *workspace, size_t workspace_bytes, int batch, int n_points, int nx,
                                              int ny, int nz, hvpr_stream_t stream) {
     if (!workspace || batch < 1 || n_points < 0 || nx < 1 || ny < 1 || nz < 1) return HVPR_ERR_INVALID_ARG;
     const long long ncell = (long long)nx * ny * nz;
-    if (workspace_bytes < ws_bytes(batch, n_points > 0 ? n_points : 1, ncell)) return HVPR_ERR_WORKSPACE;
-    VoxWs w = carve(workspace, batch, n_points > 0 ? n_points : 1, ncell);
+    if (workspace_bytes < hvpr_vox_ws_bytes(batch, n_points > 0 ? n_points : 1, ncell)) return HVPR_ERR_WORKSPACE;
+    VoxWs w = hvpr_vox_carve(workspace, batch, n_points > 0 ? n_points : 1, ncell);
     hipLaunchKernelGGL(k_reset, dim3(1024), dim3(256), 0, (hipStream_t)stream, w.cell_first, w.cell_count, batch * ncell);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
@@ -315,20 +296,17 @@ extern "C" int hvpr_voxelize_f32(const float *points, int n_points, int point_st
     const long long ncell = (long long)nx * ny * nz;
     // the workspace is carved with the dimensions it was sized and reset for, not with this call's
     if (ws_max_batch < batch || ws_max_points < n_points || ws_max_points < 1) return HVPR_ERR_WORKSPACE;
-    if (workspace_bytes < ws_bytes(ws_max_batch, ws_max_points, ncell)) return HVPR_ERR_WORKSPACE;
+    if (workspace_bytes < hvpr_vox_ws_bytes(ws_max_batch, ws_max_points, ncell)) return HVPR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (n_points == 0) {
         if (hipMemsetAsync(voxel_offsets, 0, sizeof(int) * (batch + 1), s) != hipSuccess) return HVPR_ERR_LAUNCH;
         return HVPR_OK;
     }
-    VoxWs w = carve(workspace, ws_max_batch, ws_max_points, ncell);
-    const int tiles = hvpr_cdiv(n_points, kScanTile);
-    const int pblocks = hvpr_cdiv(n_points, 256);
-    hipLaunchKernelGGL(k1_keys, dim3(pblocks), dim3(256), 0, s, points, n_points, point_stride, xyz_col, frame_offsets,
-                       batch, lo_x, lo_y, lo_z, vs_x, vs_y, vs_z, nx, ny, nz, w, tiles);
-    hipLaunchKernelGGL(k2_scan, dim3(tiles), dim3(kScanThreads), 0, s, n_points, frame_offsets, batch, w);
-    hipLaunchKernelGGL(k3_fill, dim3(pblocks), dim3(256), 0, s, n_points, frame_offsets, batch, max_voxels, w,
-                       voxel_offsets);
+    VoxWs w = hvpr_vox_carve(workspace, ws_max_batch, ws_max_points, ncell);
+    const VoxelizeArgs a{points, n_points, point_stride, xyz_col, n_feat, frame_offsets, batch, lo_x, lo_y, lo_z, vs_x, vs_y, vs_z,
+                         nx, ny, nz, max_points, max_voxels, cap_mode};
+    const int st = hvpr_i_voxel_index(a, w, voxel_offsets, false, s);
+    if (st != HVPR_OK) return st;
     int gblocks = hvpr_cdiv(n_points, 4);
     if (gblocks > 2048) gblocks = 2048;
     hipLaunchKernelGGL(k4_gather, dim3(gblocks), dim3(256), 0, s, points, point_stride, xyz_col, n_feat, batch, nx, ny,

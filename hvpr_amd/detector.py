@@ -1,6 +1,8 @@
 """Detector layer with the reference's model API (pcdet/models/detectors/, pcdet/models/__init__.py [absent upstream file],
 pcdet/models/model_utils/model_nms_utils.py): module registries keyed by the yaml NAME, the constructor-kwarg contract of
 Detector3DTemplate.build_*, ordered module_list, forward(batch_dict) -> batch_dict, post_processing -> pred_dicts."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -241,17 +243,26 @@ class _VoxelizingDetector(Detector3DTemplate):
                 return p
         raise KeyError("transform_points_to_voxels")
 
-    def voxelize_on_device(self, batch_dict):
-        pts = batch_dict["points"]
-        B = batch_dict["batch_size"]
+    def _voxel_generator(self, device):
         if self._voxgen is None:
             vc = self._voxel_cfg()
             self._voxgen = VoxelGenerator(vc.VOXEL_SIZE, self.dataset.point_cloud_range, vc.MAX_POINTS_PER_VOXEL,
-                                          vc.MAX_NUMBER_OF_VOXELS["train" if self.training else "test"], device=pts.device)
+                                          vc.MAX_NUMBER_OF_VOXELS["train" if self.training else "test"], device=device)
+        return self._voxgen
+
+    @staticmethod
+    def _frame_offsets(batch_dict):
         offs = batch_dict.get("point_frame_offsets")
         if offs is None:   # frames are contiguous and ordered (dataset.py:161-166); count per frame on device
+            pts, B = batch_dict["points"], batch_dict["batch_size"]
             offs = torch.searchsorted(pts[:, 0].contiguous(), torch.arange(B + 1, device=pts.device, dtype=pts.dtype)).to(torch.int32)
-        v, c, n, vo = self._voxgen.generate_batch(pts, offs, B, xyz_col=1, n_feat=pts.shape[1] - 1)
+        return offs
+
+    def voxelize_on_device(self, batch_dict):
+        pts = batch_dict["points"]
+        B = batch_dict["batch_size"]
+        offs = self._frame_offsets(batch_dict)
+        v, c, n, vo = self._voxel_generator(pts.device).generate_batch(pts, offs, B, xyz_col=1, n_feat=pts.shape[1] - 1)
         batch_dict["voxels"], batch_dict["voxel_coords"], batch_dict["voxel_num_points"] = v, c, n
         batch_dict["voxel_offsets"] = vo
         batch_dict["voxel_count_device"] = vo[B:B + 1]     # live row count, read on device by the next kernels
@@ -272,9 +283,43 @@ class MixAnchor_Memory(_VoxelizingDetector):
         tb_dict = {"loss_rpn": rpn.detach(), **tb_dict}
         return loss, tb_dict, {"items": items}
 
+    def _can_fuse_encode(self, batch_dict):
+        """The fused a1..a4 entry point covers the hvpr.yaml shapes: raw (N,5) points in, PillarVFE_Scale 10->16, 32->64 with the
+        5->16->32 scale stream, a 64-wide memory bank, nz == 1, <= 32 points per voxel.  Anything else takes the module
+        chain (three C-ABI calls) — same kernels' arithmetic, same results.  HVPR_ENCODE=modular forces the chain."""
+        if self.training or "voxels" in batch_dict or os.environ.get("HVPR_ENCODE", "fused") != "fused":
+            return False
+        v, m = getattr(self, "vfe", None), getattr(self, "map_to_bev_module", None)
+        if not isinstance(v, vfe.PillarVFE_Scale) or not isinstance(m, map_to_bev.PointPillarScatter_Agg_Memory_1_scale):
+            return False
+        pts = batch_dict["points"]
+        return (pts.is_cuda and pts.dim() == 2 and pts.shape[1] == 5 and v.num_filters == [32, 64] and
+                v.num_scale_features == [16, 32] and tuple(m.memory.weight.shape[1:]) == (64,) and m.nz == 1 and
+                int(self._voxel_cfg().MAX_POINTS_PER_VOXEL) <= 32 and m.memory.weight.shape[0] <= 2048 and m.k <= 32)
+
+    def encode_fused(self, batch_dict):
+        """a1-a4 through hvpr_encode_fwd_f32 (five launches): fills every batch_dict key the module chain
+        voxelize_on_device -> vfe -> map_to_bev_module would."""
+        pts, B = batch_dict["points"].contiguous(), batch_dict["batch_size"]
+        vg = self._voxel_generator(pts.device)
+        m = self.map_to_bev_module
+        r = kernels.encode_fwd(pts, self._frame_offsets(batch_dict), B, vg.point_cloud_range, vg.voxel_size, vg.grid_size,
+                               vg.max_num_points, vg.max_voxels, vg._workspace(B, pts.shape[0]),
+                               self.vfe._fold.get(pts.device, self.vfe._build_folded), self.vfe.offsets,
+                               m.memory.weight.detach().contiguous(), m.k, xyz_col=1, cap_mode=vg.cap_mode,
+                               out=batch_dict.get("_out_spatial"))
+        vo = r["voxel_offsets"]
+        batch_dict.update(voxels=r["voxels"], voxel_coords=r["coords"], voxel_num_points=r["num_points"], voxel_offsets=vo,
+                          voxel_count_device=vo[B:B + 1], pillar_features=r["pillar_features"],
+                          pillar_scale_features=r["pillar_scale_features"], pillar_mask=r["pillar_mask"],
+                          spatial_features=r["spatial"], spatial_scale_features=r["spatial_scale"])
+        return batch_dict
+
     # the eval forward in the three stages a frame pipeline overlaps (PipelinedForward)
     def stage_encode(self, batch_dict):
         """a1-a4: points -> BEV canvases."""
+        if self._can_fuse_encode(batch_dict):
+            return self.encode_fused(batch_dict)
         if "voxels" not in batch_dict:
             batch_dict = self.voxelize_on_device(batch_dict)
         return self.map_to_bev_module(self.vfe(batch_dict))
@@ -284,7 +329,10 @@ class MixAnchor_Memory(_VoxelizingDetector):
         return self.dense_head(self.backbone_2d(batch_dict))
 
     def forward(self, batch_dict, sync=True):
-        if "voxels" not in batch_dict:
+        fused = self._can_fuse_encode(batch_dict)
+        if fused:
+            batch_dict = self.encode_fused(batch_dict)
+        elif "voxels" not in batch_dict:
             batch_dict = self.voxelize_on_device(batch_dict)
         if self.training:
             for m in self.module_list:            # point stream first (module_topology), then the pillar stream
@@ -294,7 +342,7 @@ class MixAnchor_Memory(_VoxelizingDetector):
         # eval skips the point stream: module_list[1:] in the reference (pointpillar.py:54); here the point stream is
         # only put in module_list when it exists, so skip it by type
         for m in self.module_list:
-            if m is getattr(self, "backbone_3d", None):
+            if m is getattr(self, "backbone_3d", None) or (fused and (m is self.vfe or m is self.map_to_bev_module)):
                 continue
             batch_dict = m(batch_dict)
         return self.post_processing(batch_dict, sync=sync)

@@ -254,6 +254,55 @@ def memory_scatter_fwd(pillar, scale, coords, bank, k, batch, nx, ny, workspace,
     return mem, spatial.permute(0, 3, 1, 2), spatial_scale.permute(0, 3, 1, 2)
 
 
+def encode_fwd(points, frame_offsets, batch, point_cloud_range, voxel_size, grid, max_points, max_voxels, workspace, folded,
+               offsets, bank, k, xyz_col=0, cap_mode=0, capacity=None, want_voxels=True, want_mask=True, out=None):
+    """a1..a4 fused (hvpr_encode_fwd_f32): raw points -> canvases in five launches, bit-identical to voxelize ->
+    pillar_vfe_fwd -> memory_scatter_fwd.  Returns a dict with voxels|None, coords, num_points, voxel_offsets,
+    pillar_features, pillar_scale_features, pillar_mask|None, memory_features, spatial (B,128,ny,nx), spatial_scale
+    (B,32,ny,nx) (channels_last).  `out` = (spatial, spatial_scale) of an earlier call: write into those canvases."""
+    n, stride = points.shape
+    n_feat = stride - xyz_col
+    if capacity is None:
+        capacity = min(n, batch * max_voxels)
+    dev = points.device
+    nx, ny, nz = [int(g) for g in grid]
+    voxels = torch.empty((capacity, max_points, n_feat), dtype=torch.float32, device=dev) if want_voxels else None
+    coords = torch.empty((capacity, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((capacity,), dtype=torch.int32, device=dev)
+    offs = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
+    pf = torch.empty((capacity, 64), dtype=torch.float32, device=dev)
+    sf = torch.empty((capacity, 32), dtype=torch.float32, device=dev)
+    mem = torch.empty((capacity, 64), dtype=torch.float32, device=dev)
+    mask = torch.empty((capacity, max_points, 1), dtype=torch.float32, device=dev) if want_mask else None
+    if out is not None:
+        spatial, spatial_scale = (o.permute(0, 2, 3, 1) for o in out)
+        if spatial.shape != (batch, ny, nx, 128) or spatial_scale.shape != (batch, ny, nx, 32) or not spatial.is_contiguous() \
+                or not spatial_scale.is_contiguous():
+            raise ValueError("encode_fwd: `out` canvases do not match this call")
+    else:
+        spatial = torch.empty((batch, ny, nx, 128), dtype=torch.float32, device=dev)
+        spatial_scale = torch.empty((batch, ny, nx, 32), dtype=torch.float32, device=dev)
+    if bank.shape[1] != 64:
+        raise ValueError("encode_fwd is specialised for 64 pillar / 64 memory / 32 scale channels")
+    lo = [float(torch.tensor(v, dtype=torch.float32)) for v in point_cloud_range[:3]]
+    vs = [float(torch.tensor(v, dtype=torch.float32)) for v in voxel_size]
+    if workspace.key[0] < batch or workspace.key[1] < n:
+        raise ValueError("voxelize workspace too small for this call")
+    check(lib().hvpr_encode_fwd_f32(
+        _ptr(points, torch.float32, "points"), n, stride, xyz_col, n_feat, _ptr(frame_offsets, torch.int32, "frame_offsets"),
+        batch, lo[0], lo[1], lo[2], vs[0], vs[1], vs[2], nx, ny, nz, int(max_points), int(max_voxels), int(cap_mode),
+        float(offsets[0]), float(offsets[1]), float(offsets[2]),
+        _ptr(folded["w0"], torch.float32), _ptr(folded["b0"], torch.float32), _ptr(folded["w1"], torch.float32),
+        _ptr(folded["b1"], torch.float32), _ptr(folded["ws0"], torch.float32), _ptr(folded["bs0"], torch.float32),
+        _ptr(folded["ws1"], torch.float32), _ptr(folded["bs1"], torch.float32), _ptr(bank, torch.float32, "memory.weight"),
+        bank.shape[0], int(k), _ptr(voxels), coords.data_ptr(), num.data_ptr(), offs.data_ptr(), capacity, pf.data_ptr(),
+        sf.data_ptr(), _ptr(mask), mem.data_ptr(), spatial.data_ptr(), spatial_scale.data_ptr(), workspace.buf.data_ptr(),
+        workspace.buf.numel(), workspace.key[0], workspace.key[1], _stream()), "hvpr_encode_fwd_f32")
+    return {"voxels": voxels, "coords": coords, "num_points": num, "voxel_offsets": offs, "pillar_features": pf,
+            "pillar_scale_features": sf, "pillar_mask": mask, "memory_features": mem,
+            "spatial": spatial.permute(0, 3, 1, 2), "spatial_scale": spatial_scale.permute(0, 3, 1, 2)}
+
+
 # ------------------------------------------------------------------------------------------------ convolutions
 class PackedConv:
     """Weights of one conv layer in the kernel's layout [taps, Cin/8, 2, cout_pad, 4] with BatchNorm folded."""

@@ -120,6 +120,25 @@ int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale
                                 float *memory_features, float *spatial, float *spatial_scale, void *workspace,
                                 size_t workspace_bytes, hvpr_stream_t stream);
 
+/* a1..a4 fused — points to BEV canvases in five launches, the form the detector's eval forward uses when it is handed raw
+ *     points.  Same results, bit for bit, as hvpr_voxelize_f32 -> hvpr_pillar_vfe_fwd_f32 -> hvpr_memory_scatter_fwd_f32
+ *     (data_processor.py:43-75, pillar_vfe.py:184-221, memory_module.py:60-77, pointpillar_scatter.py:169-222) with
+ *       - the voxel gather fused into the VFE (the padded `voxels` tensor becomes an optional OUTPUT, may be NULL),
+ *       - the pillar / scale / memory cells of the canvases written by the VFE and the read-out themselves, and every other
+ *         cell cleared by extra workgroups of the (latency-bound) VFE launch: no scatter pass, no cell map.
+ *     Arguments as in the three separate calls; n_feat must be 4, nz 1, max_points <= 32, channels 64 + 64 + 32.
+ *     voxel_offsets[batch] is the live pillar count M (device word); rows >= M of the per-pillar outputs are unspecified.
+ *     pillar_mask may be NULL.  workspace: hvpr_voxelize_workspace_bytes / _reset, as for hvpr_voxelize_f32. */
+int hvpr_encode_fwd_f32(const float *points, int n_points, int point_stride, int xyz_col, int n_feat,
+                        const int32_t *frame_offsets, int batch, float lo_x, float lo_y, float lo_z, float vs_x, float vs_y,
+                        float vs_z, int nx, int ny, int nz, int max_points, int max_voxels, int cap_mode, float off_x,
+                        float off_y, float off_z, const float *w0, const float *b0, const float *w1, const float *b1,
+                        const float *ws0, const float *bs0, const float *ws1, const float *bs1, const float *bank,
+                        int n_items, int k, float *voxels, int32_t *coords, int32_t *num_points, int32_t *voxel_offsets,
+                        int capacity, float *pillar_features, float *pillar_scale_features, float *pillar_mask,
+                        float *memory_features, float *spatial, float *spatial_scale, void *workspace,
+                        size_t workspace_bytes, int ws_max_batch, int ws_max_points, hvpr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a5/a6  BEV backbone + head convolutions: implicit GEMM on the fp32 matrix cores, NHWC.
  *     Replaces the cuDNN convolutions behind BaseBEVBackbone_Scale.forward (eval),

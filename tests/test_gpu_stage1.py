@@ -272,3 +272,53 @@ def test_fused_memory_scatter_equals_the_two_calls():
     _, sp0, sc0 = kernels.memory_scatter_fwd(e, torch.empty((0, 32), device=DEV), torch.empty((0, 4), dtype=torch.int32, device=DEV),
                                              W, 20, 1, 296, 248, kernels.scatter_workspace(1, 296, 248, DEV))
     assert float(sp0.abs().sum()) == 0.0 and float(sc0.abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- a1..a4 fused
+def _encode_both(frames, max_voxels, cap_mode=0, seed=40):
+    """hvpr_encode_fwd_f32 against the three separate C-ABI calls on the same inputs (points as (N,5) [b,x,y,z,r])."""
+    pts = np.concatenate([np.concatenate([np.full((len(f), 1), b, np.float32), f], 1) for b, f in enumerate(frames)], 0)
+    offs = torch.from_numpy(np.cumsum([0] + [len(f) for f in frames]).astype(np.int32)).to(DEV)
+    B = len(frames)
+    tp = torch.from_numpy(pts).to(DEV)
+    folded = _folded_from(_vfe_params(seed))
+    vfe_off = [VS[0] / 2 + RNG[0], VS[1] / 2 + RNG[1], VS[2] / 2 + RNG[2]]
+    W = torch.from_numpy(np.random.default_rng(seed).uniform(-0.125, 0.125, (2000, 64)).astype(np.float32)).to(DEV)
+    ws = kernels.VoxelizeWorkspace(B, max(len(pts), 1), GRID, DEV)
+    v, c, n, vo = kernels.voxelize(tp, offs, B, RNG, VS, GRID, 32, max_voxels, ws, xyz_col=1, cap_mode=cap_mode)
+    md = vo[B:B + 1]
+    pf, sf, mask = kernels.pillar_vfe_fwd(v, n, c, folded, VS, vfe_off, m_device=md)
+    mem, sp, sc = kernels.memory_scatter_fwd(pf, sf, c, W, 20, B, GRID[0], GRID[1], kernels.scatter_workspace(B, GRID[0], GRID[1], DEV),
+                                             m_device=md)
+    outs = []
+    for _ in range(2):   # the second call proves the voxelizer workspace came back to idle and stale canvases are cleared
+        r = kernels.encode_fwd(tp, offs, B, RNG, VS, GRID, 32, max_voxels, ws, folded, vfe_off, W, 20, xyz_col=1, cap_mode=cap_mode,
+                               out=None if not outs else (outs[0]["spatial"], outs[0]["spatial_scale"]))
+        torch.cuda.synchronize()
+        outs.append(r)
+        m = int(vo[B])
+        assert torch.equal(r["voxel_offsets"], vo)
+        for key, ref in (("voxels", v), ("coords", c), ("num_points", n), ("pillar_features", pf), ("pillar_scale_features", sf),
+                         ("pillar_mask", mask), ("memory_features", mem)):
+            assert torch.equal(r[key][:m], ref[:m]), key
+        assert torch.equal(r["spatial"], sp) and torch.equal(r["spatial_scale"], sc)
+    return m
+
+
+def test_encode_fused_equals_the_three_calls():
+    assert _encode_both([synthetic.hvpr_frame(0)], 40000) > 3000
+    _encode_both([synthetic.hvpr_frame(1, shuffle=True)], 16000)
+    # ragged batch with an empty frame, then frames whose pillars hold far more than 32 points (64-lane selection path)
+    _encode_both([synthetic.hvpr_frame(2)[:5000], np.zeros((0, 4), np.float32), synthetic.hvpr_frame(3)[:777],
+                  synthetic.hvpr_frame(4, shuffle=True)], 40000)
+    dense = synthetic.hvpr_frame(5).copy()
+    dense[:3000, 0] = 10.0 + 0.3 * np.random.default_rng(0).random(3000).astype(np.float32)     # ~2 x 1 cells x 1500 points
+    dense[:3000, 1] = 0.05
+    _encode_both([dense, synthetic.hvpr_frame(6)[:1]], 40000)
+
+
+@pytest.mark.parametrize("cap_mode", [0, 1])
+def test_encode_fused_with_the_voxel_cap(cap_mode):
+    f = synthetic.uniform_frame(11, 16384, RNG)
+    for cap in (100, 4000):
+        assert _encode_both([f, f[::-1].copy()], cap, cap_mode=cap_mode) == 2 * cap

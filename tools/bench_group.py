@@ -17,7 +17,8 @@ DEV = "cuda:0"
 
 def batch_of(frames):
     pts = np.concatenate([np.concatenate([np.full((len(f), 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
-    return {"points": torch.from_numpy(pts).to(DEV), "batch_size": len(frames)}
+    offs = np.cumsum([0] + [len(f) for f in frames]).astype(np.int32)
+    return {"points": torch.from_numpy(pts).to(DEV), "point_frame_offsets": torch.from_numpy(offs).to(DEV), "batch_size": len(frames)}
 
 
 def run(name, cfg, frames, iters=50):
@@ -54,6 +55,8 @@ def run(name, cfg, frames, iters=50):
 if __name__ == "__main__":
     car = hvpr_car_cfg()
     run("hvpr_car batch 1", car, [synthetic.hvpr_frame(0)])
+    if "--car1" in sys.argv:
+        sys.exit(0)
     run("hvpr_car batch 16", car, [synthetic.hvpr_frame(i) for i in range(16)])
     dense = copy.deepcopy(car)
     rng = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
