@@ -17,7 +17,8 @@ struct VoxWs {
     int *cell_vid;     // [B*ncell]  scratch
     int *pt_cell;      // [N]
     int4 *vox_rec;     // [N] by global rank: {cell, point count, arena offset, first point index} — one 16-byte load per voxel
-    int *arena;        // [N]
+    int *arena;        // [N]  point indices, grouped by voxel (unordered inside a voxel)
+    float4 *arena_pt;  // [N]  the points themselves next to their indices (fused encode path only: one load level less)
     int *frame_base;   // [B+1] rank of the first voxel of each frame (uncapped)
     unsigned long long *tile_state;   // [tiles]
     int *ticket;       // [1]
@@ -32,6 +33,7 @@ static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell) 
     w.pt_cell = c.take<int>(n);
     w.vox_rec = c.take<int4>(n);
     w.arena = c.take<int>(n);
+    w.arena_pt = c.take<float4>(n);
     w.frame_base = c.take<int>(batch + 1);
     w.tile_state = c.take<unsigned long long>(hvpr_cdiv(n > 0 ? n : 1, kScanTile));
     w.ticket = c.take<int>(1);
@@ -57,9 +59,10 @@ struct VfeWeights {
     const float *w0, *b0, *w1, *b1, *ws0, *bs0, *ws1, *bs1;
 };
 
-// K1-K3 of the voxelizer (cell keys, rank scan, arena fill) + voxel_offsets.  keep_cell_first: K3 does not return the
-// cell_first map to idle — the caller's next kernel reads the occupancy from it and resets it (hvpr_i_vfe_gather does).
-HVPR_INTERNAL int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool keep_cell_first,
+// K1-K3 of the voxelizer (cell keys, rank scan, arena fill) + voxel_offsets.  for_encode: K3 also copies each point (4
+// floats) next to its index in the arena, and does not return the cell_first map to idle — the caller's next kernel reads
+// the occupancy from it and resets it (hvpr_i_vfe_gather does both).
+HVPR_INTERNAL int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode,
                                      hipStream_t s);
 // K4 fused into the pillar VFE: selects each voxel's points straight from the arena, writes voxels (optional) / coords /
 // num_points, the pillar and scale features and the pillar + scale cells of the NHWC canvases; extra workgroups of the same

@@ -2,21 +2,21 @@
 // Replaces the ~10 PyTorch ops of PillarVFE_Scale.forward (pcdet/models/backbones_3d/vfe/pillar_vfe.py:184-221)
 // and the two PFNLayer.forward calls (:29-49) with one launch.
 //
-// Mapping (wave64): one wave works on two pillars at a time.
-//   phase A  lane = slot (32 lanes per pillar): load the point, pillar mean by a 32-lane butterfly,
-//            10-d decoration, masked; layer 0 (10->16) in registers; 32-lane max.
-//   phase B  lane = output channel (64 lanes = 64 channels), one pillar after the other: layer 1 over the
-//            DISTINCT slots only — the n valid points plus, when n < 32, ONE virtual zero-input slot
-//            (pillar_vfe.py masks the input, not the output, so every padded slot yields the same
-//            ReLU(folded bias) and takes part in both maxes).  The x_max half of
-//            the concat is a per-pillar constant and is folded into the bias once.
-//   scale    5 -> 16 -> 32 on lanes 0..15 / 0..31.
+// Mapping (wave64): one wave per pillar, both PFN layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+//   decoration  lane = slot (both 32-lane halves hold the pillar's 32 slots): pillar mean by a DPP reduction, 10-d
+//               decoration, masked INPUT (pillar_vfe.py:205-208 masks the input, not the output, so a padded slot yields
+//               ReLU(folded bias) and takes part in both maxes; SURVEY.md §8a a2 quirk — it falls out of the matrix form).
+//   layer 0     D0^T (16 ch x 32 slots) = W0 (A operand) . F^T (B operand), 5 MFMAs; bias, ReLU; max over the slots.
+//   layer 1     D1^T (64 ch x 32 slots) = [W1a | W1b] . [y0 ; max y0], 2 x 16 MFMAs — the layer-0 output is already in the
+//               B-operand layout; max over the slots by a transposing DPP reduction, then bias + ReLU (monotone, so they
+//               commute with the max).  The cost no longer depends on the point count of the pillar.
+//   scale       5 -> 16 -> 32 on lanes 0..15 / 0..31.
 //
-// k_vfe<true> is the fused encode form (hvpr_encode_fwd_f32): the wave first does the voxelizer's K4 for its two pillars
-// — the max_points smallest point indices of the voxel's arena segment, ascending, by a 32-lane bitonic network (a
-// 64-lane one with chunked merging for the ~1 % of voxels with more than 32 points) — and reads the points straight
+// k_vfe<true> is the fused encode form (hvpr_encode_fwd_f32): the wave first does the voxelizer's K4 for its pillar — the
+// max_points smallest point indices of the voxel's arena segment, ascending, by a 32-lane bitonic network (for the ~1 % of
+// voxels with more than 32 points: a ballot radix select of the 32nd smallest index first) — and reads the points straight
 // from the point array, so the padded `voxels` tensor is an optional output instead of an intermediate; it also writes
-// the pillar / scale cells of the pre-cleared NHWC canvases (no scatter pass).
+// the pillar / scale cells of the NHWC canvases, whose other cells are cleared by extra workgroups of the same launch.
 #include "common.h"
 #include "internal.h"
 
@@ -41,7 +41,8 @@ struct GatherSrc {
     float *spatial;         // NHWC canvas, 128 channels per cell: pillar features in [0, 64), memory read-out in [64, 128)
     int spatial_channels;
     float *spatial_scale;   // NHWC canvas, 32 channels per cell
-    int work_blocks;        // workgroups >= work_blocks clear the canvases (see canvas_clear)
+    int work_blocks;        // the LAST work_blocks workgroups of the grid encode pillars, the ones before clear the canvases
+    int idx_bits;           // bits of the largest point index
 };
 
 // The dense canvases are cleared by extra workgroups of this latency-bound launch (47 MB at hvpr_car, hidden under the
@@ -49,34 +50,33 @@ struct GatherSrc {
 // is skipped — the voxelizer's cell maps still say which cells are occupied (K3 leaves cell_first alone on this path) and
 // this pass returns them to idle while it is there.
 __device__ __forceinline__ void canvas_clear(const GatherSrc &g, int blk, int nblk) {
-    constexpr int CELLS = 8, V = 32, VS = 8;   // cells per wave step, float4 per cell of the main / scale canvas
+    constexpr int V = 32, VS = 8;   // float4 per cell of the main / scale canvas; a wave clears 64 cells (40 KB) per step
     const int lane = threadIdx.x & 63;
     const long long n_cells = (long long)g.batch * g.nx * g.ny;
     const long long wave = ((long long)blk * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)nblk * blockDim.x) >> 6;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long c0 = wave * CELLS; c0 < n_cells; c0 += n_waves * CELLS) {
-        int emitted = 0;
-        if (lane < CELLS && c0 + lane < n_cells) {
-            const long long c = c0 + lane;
-            if (g.w.cell_first[c] != kIdle) {
-                g.w.cell_first[c] = kIdle;
-                const int b = (int)(c / ((long long)g.nx * g.ny));
-                const int local = g.w.cell_vid[c] - g.w.frame_base[b];
-                emitted = local < g.max_voxels && g.voxel_offsets[b] + local < g.capacity;
-            }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long long c0 = wave * 64; c0 < n_cells; c0 += n_waves * 64) {
+        const long long c = c0 + lane;
+        bool emitted = false;
+        if (c < n_cells && g.w.cell_first[c] != kIdle) {
+            g.w.cell_first[c] = kIdle;
+            const int b = (int)(c / ((long long)g.nx * g.ny));
+            const int local = g.w.cell_vid[c] - g.w.frame_base[b];
+            emitted = local < g.max_voxels && g.voxel_offsets[b] + local < g.capacity;
         }
-        const unsigned skip = (unsigned)__ballot(emitted != 0);   // bit i: cell c0 + i belongs to a pillar
-#pragma unroll
-        for (int i = lane; i < CELLS * V; i += 64) {
-            const int cell = i / V;
-            if (c0 + cell < n_cells && !((skip >> cell) & 1u))
-                reinterpret_cast<float4 *>(g.spatial)[(c0 + cell) * V + i % V] = zero;
-        }
-        {
-            const int cell = lane / VS;
-            if (c0 + cell < n_cells && !((skip >> cell) & 1u))
-                reinterpret_cast<float4 *>(g.spatial_scale)[(c0 + cell) * VS + lane % VS] = zero;
-        }
+        const unsigned long long skip = __ballot(emitted);   // bit i: cell c0 + i belongs to a pillar
+        // streaming stores: 47 MB of zeros must not push the voxelizer's arrays, which the pillar waves of this launch are
+        // reading, out of the L2
+        f32x4 *const main = reinterpret_cast<f32x4 *>(g.spatial) + c0 * V;
+        f32x4 *const side = reinterpret_cast<f32x4 *>(g.spatial_scale) + c0 * VS;
+        const int cells = (int)min(64ll, n_cells - c0);
+#pragma unroll 8
+        for (int i = lane; i < cells * V; i += 64)
+            if (!((skip >> (i / V)) & 1ull)) __builtin_nontemporal_store(zero, main + i);
+#pragma unroll 8
+        for (int i = lane; i < cells * VS; i += 64)
+            if (!((skip >> (i / VS)) & 1ull)) __builtin_nontemporal_store(zero, side + i);
     }
 }
 
@@ -92,8 +92,22 @@ __device__ __forceinline__ int bitonic_asc(int v, int lane, int width) {
     return v;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// one step of a transposing max-reduction: lanes whose bit `LBIT` is clear keep register `a` and receive the partner
+// lane's `a`, the others keep `b` and receive the partner's `b`; CTRL is the DPP pattern that reaches lane ^ (1 << LBIT)
+template <int CTRL>
+__device__ __forceinline__ float halve_dpp(float a, float b, bool bit) {
+    const float keep = bit ? b : a, send = bit ? a : b;
+    return fmaxf(keep, hvpr_dpp<CTRL>(send));
+}
+__device__ __forceinline__ float halve_row(float a, float b) {   // partner = lane ^ 16 (v_permlane16_swap)
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 template <bool GATHER>
-__global__ void __launch_bounds__(256) k_vfe(const float4 *__restrict__ voxels, const int *__restrict__ num_points,
+__global__ void __launch_bounds__(256, 4) k_vfe(const float4 *__restrict__ voxels, const int *__restrict__ num_points,
                                              const int4 *__restrict__ coords, int M, int P,
                                              const int *__restrict__ m_device, float vsx, float vsy, float vsz,
                                              float offx, float offy, float offz, const float *__restrict__ w0,
@@ -103,82 +117,166 @@ __global__ void __launch_bounds__(256) k_vfe(const float4 *__restrict__ voxels, 
                                              const float *__restrict__ bs1, float *__restrict__ pillar_features,
                                              float *__restrict__ scale_features, float *__restrict__ pillar_mask,
                                              GatherSrc g) {
-    if (GATHER && (int)blockIdx.x >= g.work_blocks) {
-        canvas_clear(g, blockIdx.x - g.work_blocks, gridDim.x - g.work_blocks);
+    const int fill_blocks = GATHER ? (int)gridDim.x - g.work_blocks : 0;   // dispatched first: they are the bandwidth work
+    if (GATHER && (int)blockIdx.x < fill_blocks) {
+#ifdef HVPR_EXP_TIMING
+        const long long f0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        canvas_clear(g, blockIdx.x, fill_blocks);
+#ifdef HVPR_EXP_TIMING
+        if ((blockIdx.x == 0 || blockIdx.x == fill_blocks - 1 || blockIdx.x == fill_blocks / 2) && threadIdx.x == 0)
+            printf("vfe-abs fill blk %d: %lld .. %lld (x10 ns)\n", (int)blockIdx.x, f0, (long long)__builtin_amdgcn_s_memrealtime());
+#endif
         return;
     }
+    __shared__ int s_sel[4][32];
     const int lane = threadIdx.x & 63;
-    const int half = lane >> 5, slot = lane & 31;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int h = lane >> 5, slot = lane & 31;
+    const int wave = ((blockIdx.x - fill_blocks) * blockDim.x + threadIdx.x) >> 6;
     const int n_waves = ((GATHER ? g.work_blocks : (int)gridDim.x) * blockDim.x) >> 6;
+    // the live pillar count is a device word; the first pillar's voxel record is requested before it is looked at (one
+    // frame: rank == output row), so the two loads share a round trip
+    int4 rec0 = make_int4(0, 0, 0, 0);
+    if (GATHER && g.batch == 1 && wave < g.capacity) rec0 = g.w.vox_rec[wave];
     if (m_device) M = min(M, *m_device);
-    if (wave * 2 >= M) return;   // the grid is sized for the capacity, the live count is a device word
+    if (wave >= M) return;
 #ifdef HVPR_EXP_TIMING
     const long long tt0 = __builtin_readcyclecounter();
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
     long long tt1 = 0, tt2 = 0, tt3 = 0;
 #endif
 
-    // lane = channel weights, resident for the whole grid-stride loop
-    float w1a[C0], w1b[C0];
+    // ---- weights in matrix-core operand layout, resident for the whole grid-stride loop --------------------------------
+    // v_mfma_f32_32x32x2_f32: A lane (i = lane % 32, k = lane / 32), B lane (k = lane / 32, j = lane % 32), D register r of
+    // lane (j, hh) = row 8 * (r / 4) + 4 * hh + r % 4, column j.  Both layers are computed TRANSPOSED — rows = output
+    // channels (weights are the A operand), columns = the 32 point slots — so that the output of layer 0 already sits in
+    // the B-operand layout of layer 1 (the k index of an MFMA is a free permutation when A and B agree): lane (slot, hh)
+    // ends layer 0 with channels chm(r) = 8 * (r / 4) + 4 * hh + r % 4, r < 8, and feeds exactly those to layer 1.
+    float a0w[CIN / 2], b0h[8];
 #pragma unroll
-    for (int j = 0; j < C0; ++j) { w1a[j] = w1[lane * 32 + j]; w1b[j] = w1[lane * 32 + C0 + j]; }
-    const float bias1 = b1[lane];
-    float wsa[5], wsb[CS0];
+    for (int t = 0; t < CIN / 2; ++t) a0w[t] = slot < C0 ? w0[slot * CIN + 2 * t + h] : 0.f;
+    {
+        const float4 lo = *(const float4 *)(b0 + 4 * h), hi = *(const float4 *)(b0 + 8 + 4 * h);
+        b0h[0] = lo.x; b0h[1] = lo.y; b0h[2] = lo.z; b0h[3] = lo.w; b0h[4] = hi.x; b0h[5] = hi.y; b0h[6] = hi.z; b0h[7] = hi.w;
+    }
+    float aw[2][8];   // layer 1, the half that multiplies the layer-0 output: two 16-byte loads per row
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 w4 = *(const float4 *)(w1 + (32 * mb + slot) * 32 + 8 * q + 4 * h);
+            aw[mb][4 * q] = w4.x; aw[mb][4 * q + 1] = w4.y; aw[mb][4 * q + 2] = w4.z; aw[mb][4 * q + 3] = w4.w;
+        }
+    // after the transposing reduction lane l holds output channels 32 mb + 16 l4 + 8 l3 + 4 hh + 2 l1 + l0 (both mb, and
+    // twice: lanes l and l ^ 4); lane l finishes channel oc = 32 l2 + ...: bias, ReLU and the other half of layer 1 — the
+    // x_max part of the concat is the same for every slot, so it is a 16-term dot product per channel, not a matrix product
+    const int oc = 32 * ((lane >> 2) & 1) + 16 * ((lane >> 4) & 1) + 8 * ((lane >> 3) & 1) + 4 * h + (lane & 3);
+    float wb[C0];
+#pragma unroll
+    for (int q = 0; q < C0 / 4; ++q) {
+        const float4 w4 = *(const float4 *)(w1 + oc * 32 + C0 + 4 * q);
+        wb[4 * q] = w4.x; wb[4 * q + 1] = w4.y; wb[4 * q + 2] = w4.z; wb[4 * q + 3] = w4.w;
+    }
+    const float b1l = b1[oc];
+    float wsa[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) wsa[j] = ws0[(lane & 15) * 5 + j];
-#pragma unroll
-    for (int j = 0; j < CS0; ++j) wsb[j] = ws1[(lane & 31) * CS0 + j];
     const float bsa = bs0[lane & 15], bsb = bs1[lane & 31];
 
-    for (int pair = wave; pair * 2 < M; pair += n_waves) {
-        const int p = pair * 2 + half;
-        const bool pv = p < M;
+    for (int p = wave; p < M; p += n_waves) {
+        // both 32-lane halves hold the same pillar: lane (slot, hh) has point `slot`
         int n = 0;
         int4 cd = make_int4(0, 0, 0, 0);
         float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
         if (GATHER) {
-            // K4 of the voxelizer for this wave's two pillars (output rows p): rank r in the uncapped order of frame b
-            int b = 0, cnt = 0, a0 = 0, cell = 0, cutoff = kIdle;
-            if (pv) {
+            // K4 of the voxelizer for output row p: rank in the uncapped order of frame b -> {cell, count, arena, first}
+            // (one frame: rank == row, so this load does not wait for anything)
+            int b = 0, fb = 0, r = p;
+            if (g.batch > 1) {
                 for (int bb = 1; bb < g.batch; ++bb) if (g.voxel_offsets[bb] <= p) b = bb;
-                const int fb = g.w.frame_base[b];
-                const int4 rec = g.w.vox_rec[fb + (p - g.voxel_offsets[b])];   // {cell, count, arena offset, first index}
-                cell = rec.x; cnt = rec.y; a0 = rec.z;
-                if (g.cap_mode == 1) {
-                    const int rc = fb + g.max_voxels;
-                    if (rc < g.w.frame_base[b + 1]) cutoff = g.w.vox_rec[rc].w;
-                }
+                fb = g.w.frame_base[b];
+                r = fb + (p - g.voxel_offsets[b]);
             }
-            int v = slot < cnt ? g.w.arena[a0 + slot] : kIdle;
-            v = bitonic_asc(v, slot, 32);                       // both halves at once; exact when cnt <= 32
-            const unsigned long long big = __ballot(cnt > 32);
-            if (big) {                                          // rare: the 64-lane selection of K4, one pillar at a time
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {
-                    if (!((big >> (32 * h)) & 1ull)) continue;
-                    const int c = __builtin_amdgcn_readlane(cnt, 32 * h), base = __builtin_amdgcn_readlane(a0, 32 * h);
-                    int u = lane < c ? g.w.arena[base + lane] : kIdle;
+            const int4 rec = (g.batch == 1 && p == wave) ? rec0 : g.w.vox_rec[r];
+            const int cnt = rec.y, a0 = rec.z;
+            int cutoff = kIdle;
+            if (g.cap_mode == 1) {
+                const int rc = fb + g.max_voxels;
+                if (rc < g.w.frame_base[b + 1]) cutoff = g.w.vox_rec[rc].w;
+            }
+            // the P smallest point indices of the arena segment, ascending, in slots [0, P); K3 left each point next to its
+            // index, so index and point arrive in the same round trip and the point travels with the sort key
+            int v = kIdle;
+            float4 apt = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot < cnt) { v = g.w.arena[a0 + slot]; apt = g.w.arena_pt[a0 + slot]; }
+            bool from_arena = true;
+            if (cnt > 32) {   // wave-uniform, ~1 % of the pillars: select by index, fetch the points afterwards
+                from_arena = false;
+                if (cnt <= 512) {
+                    // radix select: T = the P-th smallest index (indices are distinct), bit by bit with ballots
+                    int vals[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vals[r] = (r * 64 + lane < cnt) ? g.w.arena[a0 + r * 64 + lane] : kIdle;
+                    unsigned T = 0u;
+                    for (int bit = g.idx_bits - 1; bit >= 0; --bit) {
+                        const unsigned test = T | ((1u << bit) - 1u);
+                        int c = 0;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) c += __popcll(__ballot((unsigned)vals[r] <= test));
+                        if (c < P) T |= 1u << bit;
+                    }
+                    int base = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const bool sel = (unsigned)vals[r] <= T;
+                        const unsigned long long m = __ballot(sel);
+                        if (sel) s_sel[threadIdx.x >> 6][base + __popcll(m & ((1ull << lane) - 1ull))] = vals[r];
+                        base += __popcll(m);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    v = slot < P ? ((volatile int *)s_sel[threadIdx.x >> 6])[slot] : kIdle;
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    // very dense cell: 64-lane bitonic selection with chunked merging (the form K4 uses)
+                    int u = lane < cnt ? g.w.arena[a0 + lane] : kIdle;
                     u = bitonic_asc(u, lane, 64);
                     const int chunk = 64 - P;
-                    for (int done = 64; done < c; done += chunk) {
+                    for (int done = 64; done < cnt; done += chunk) {
                         if (lane >= P) {
                             const int j = done + (lane - P);
-                            u = j < c ? g.w.arena[base + j] : kIdle;
+                            u = j < cnt ? g.w.arena[a0 + j] : kIdle;
                         }
                         u = bitonic_asc(u, lane, 64);
                     }
-                    const int moved = __shfl(u, slot, 64);      // lanes [0, 32) -> the slots of half h
-                    if (half == h) v = moved;
+                    v = __shfl(u, slot, 64);
                 }
             }
-            const bool live = pv && slot < P && v < cutoff;     // v == kIdle is never < cutoff
-            n = __popcll(__ballot(live) & (0xffffffffull << (32 * half)));
-            if (live) {
-                const float *src = g.pts + (size_t)v * g.stride + g.xyz_col;
-                pt = make_float4(src[0], src[1], src[2], src[3]);
+            if (from_arena) {   // sort (index, source slot) keys, then pull the point from its source lane
+                const int c = min(cnt, 32);
+                int key = v == kIdle ? kIdle : (v << 5) | slot;
+                if (c > 1) key = bitonic_asc(key, slot, c <= 2 ? 2 : c <= 4 ? 4 : c <= 8 ? 8 : c <= 16 ? 16 : 32);
+                v = key == kIdle ? kIdle : key >> 5;
+                const int src = (lane & 32) | (key & 31);
+                apt.x = __shfl(apt.x, src, 64); apt.y = __shfl(apt.y, src, 64);
+                apt.z = __shfl(apt.z, src, 64); apt.w = __shfl(apt.w, src, 64);
+            } else {
+                v = bitonic_asc(v, slot, 32);
             }
+            const bool live = slot < P && v < cutoff;     // v == kIdle is never < cutoff
+            n = __popcll(__ballot(live) & 0xffffffffull);
+            if (live) {
+                if (from_arena) {
+                    pt = apt;
+                } else {
+                    const float *src = g.pts + (size_t)v * g.stride + g.xyz_col;
+                    pt = make_float4(src[0], src[1], src[2], src[3]);
+                }
+            }
+            const int cell = rec.x;
             cd = make_int4(b, (cell / (g.nx * g.ny)) % g.nz, (cell / g.nx) % g.ny, cell % g.nx);
-            if (pv && p < g.capacity) {
+            if (p < g.capacity && h == 0) {
                 if (g.voxels_out && slot < P) reinterpret_cast<float4 *>(g.voxels_out)[(size_t)p * P + slot] = pt;
                 if (slot == 0) {
                     reinterpret_cast<int4 *>(g.coords_out)[p] = cd;
@@ -186,16 +284,16 @@ __global__ void __launch_bounds__(256) k_vfe(const float4 *__restrict__ voxels, 
                 }
             }
         } else {
-            n = pv ? num_points[p] : 0;
-            if (pv) cd = coords[p];
-            if (pv && slot < P) pt = voxels[(size_t)p * P + slot];
+            n = num_points[p];
+            cd = coords[p];
+            if (slot < P) pt = voxels[(size_t)p * P + slot];
         }
-        const bool valid = pv && slot < n && slot < P;
+        const bool valid = slot < n && slot < P;
 #ifdef HVPR_EXP_TIMING
         asm volatile("" ::"v"(pt.x), "v"(pt.w), "v"(n));
         tt1 = __builtin_readcyclecounter();
 #endif
-        // ---- phase A: decoration + layer 0, lane = slot -------------------------------------------------
+        // ---- decoration (pillar_vfe.py:187-208) ---------------------------------------------------------------------
         const float fn = (float)n;
         const float mx = hvpr_reduce_sum<32>(pt.x) / fn;     // padded slots are zero (pillar_vfe.py:187)
         const float my = hvpr_reduce_sum<32>(pt.y) / fn;
@@ -206,78 +304,102 @@ __global__ void __launch_bounds__(256) k_vfe(const float4 *__restrict__ voxels, 
         f[7] = pt.x - ((float)cd.w * vsx + offx);
         f[8] = pt.y - ((float)cd.z * vsy + offy);
         f[9] = pt.z - ((float)cd.y * vsz + offz);
-        if (!valid) {
-#pragma unroll
+        if (!valid) {                                        // the mask is applied to the INPUT (:205-208): a padded slot
+#pragma unroll                                               // still yields ReLU(folded bias) and takes part in both maxes
             for (int j = 0; j < CIN; ++j) f[j] = 0.f;
         }
-        float y0[C0], xmax[C0];
-#pragma unroll
-        for (int c = 0; c < C0; ++c) {
-            float a = b0[c];
-#pragma unroll
-            for (int j = 0; j < CIN; ++j) a = fmaf(w0[c * CIN + j], f[j], a);
-            y0[c] = fmaxf(a, 0.f);
-            xmax[c] = hvpr_reduce_max<32>(slot < P ? y0[c] : -INFINITY);   // all P slots take part, padded ones included
-        }
-        if (pillar_mask && pv && slot < P) pillar_mask[(size_t)p * P + slot] = valid ? 1.f : 0.f;
+        if (pillar_mask && slot < P && h == 0) pillar_mask[(size_t)p * P + slot] = valid ? 1.f : 0.f;
 
+        // ---- layer 0: (16 x 10) . (10 x 32 slots) ---------------------------------------------------------------------
+        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < CIN / 2; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0w[t], h ? f[2 * t + 1] : f[2 * t], acc0, 0, 0, 0);
+        float y0[8], xm[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            y0[r] = fmaxf(acc0[r] + b0h[r], 0.f);
+            xm[r] = hvpr_reduce_max<32>(slot < P ? y0[r] : -INFINITY);   // all P slots take part, padded ones included
+        }
 #ifdef HVPR_EXP_TIMING
-        asm volatile("" ::"v"(xmax[0]), "v"(xmax[15]));
+        asm volatile("" ::"v"(xm[0]), "v"(xm[7]));
         tt2 = __builtin_readcyclecounter();
 #endif
-        // ---- phase B: layer 1, lane = channel, one pillar of the pair after the other ------------------
+        // ---- layer 1: (64 x 16) . (y0 x 32 slots) on the matrix cores + the x_max half as a per-channel constant, then the
+        // max over the slots, bias, ReLU.  max_s relu(x_s + c) = relu(max_s x_s + c): constant, bias and ReLU move behind
+        // the reduction
+        float cst = b1l;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ph = pair * 2 + h;
-            if (ph >= M) break;
-            const int src0 = h * 32;
-            const int nh = __builtin_amdgcn_readlane(n, src0);
-            float cst = bias1;   // bias + W1[:,16:32] . xmax  (per-pillar constant)
+        for (int c = 0; c < C0; ++c)   // channel c of x_max sits in register 4 (c / 8) + c % 4 of the lanes of half (c / 4) % 2
+            cst = fmaf(wb[c], rlf(xm[4 * (c >> 3) + (c & 3)], 32 * ((c >> 2) & 1)), cst);
+        float qm[2];
 #pragma unroll
-            for (int j = 0; j < C0; ++j) cst = fmaf(w1b[j], rlf(xmax[j], src0), cst);
-            float best = -INFINITY;
-            const int n_real = min(nh, P);
-            const int n_eval = n_real < P ? n_real + 1 : n_real;   // +1 virtual zero-input slot
-            for (int s = 0; s < n_eval; ++s) {
-                // lane (src0 + s) holds y0 of slot s; slot n_real (if evaluated) is a padded slot -> ReLU(b0)
-                float a = cst;
+        for (int mb = 0; mb < 2; ++mb) {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < C0; ++j)
-                    a = fmaf(w1a[j], rlf(y0[j], src0 + s), a);
-                best = fmaxf(best, fmaxf(a, 0.f));
-            }
-            pillar_features[(size_t)ph * C1 + lane] = best;
-            size_t cell = 0;
-            if (GATHER && g.spatial) {   // the pillar cell of the pre-cleared NHWC canvas (pointpillar_scatter.py:192,207)
-                cell = ((size_t)__builtin_amdgcn_readlane(cd.x, src0) * g.ny + __builtin_amdgcn_readlane(cd.z, src0)) * g.nx +
-                       __builtin_amdgcn_readlane(cd.w, src0);
-                g.spatial[cell * g.spatial_channels + lane] = best;
-            }
+            for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[mb][t], y0[t], acc, 0, 0, 0);
+            float q[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[r] = slot < P ? acc[r] : -INFINITY;
+            // transposing reduction over the 32 slots: 16 -> 8 -> 4 -> 2 -> 1 registers along lane bits 0, 1, 3, 4 ...
+            float q8[8], q4[4], q2[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q8[i] = halve_dpp<0xB1>(q[2 * i], q[2 * i + 1], lane & 1);            // r bit 0
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q4[i] = halve_dpp<0x4E>(q8[2 * i], q8[2 * i + 1], lane & 2);          // r bit 1
+#pragma unroll
+            for (int i = 0; i < 2; ++i) q2[i] = halve_dpp<0x128>(q4[2 * i], q4[2 * i + 1], lane & 8);         // r bit 2, row_ror:8
+            qm[mb] = halve_row(q2[0], q2[1]);                                                                 // r bit 3
+        }
+        float q1 = (lane & 4) ? qm[1] : qm[0];
+        {   // ... and a plain step along lane bit 2: the partner holds this lane's channel block in its other register
+            const float other = __shfl_xor((lane & 4) ? qm[0] : qm[1], 4, 64);
+            q1 = fmaxf(q1, other);
+        }
+        const float o = fmaxf(q1 + cst, 0.f);
+        pillar_features[(size_t)p * C1 + oc] = o;
+        size_t cell = 0;
+        if (GATHER) {   // the pillar cell of the NHWC canvas (pointpillar_scatter.py:192,207)
+            cell = ((size_t)cd.x * g.ny + cd.z) * g.nx + cd.w;
+            g.spatial[cell * g.spatial_channels + oc] = o;
+        }
 
-            // scale stream: [n, |mean|, mean_x, mean_y, mean_z] -> 16 -> 32   (pillar_vfe.py:213-216)
-            const float smx = rlf(mx, src0);
-            const float smy = rlf(my, src0);
-            const float smz = rlf(mz, src0);
-            const float nrm = sqrtf(smx * smx + smy * smy + smz * smz);
-            float s1 = bsa;
-            s1 = fmaf(wsa[0], (float)nh, s1);
-            s1 = fmaf(wsa[1], nrm, s1);
-            s1 = fmaf(wsa[2], smx, s1);
-            s1 = fmaf(wsa[3], smy, s1);
-            s1 = fmaf(wsa[4], smz, s1);
-            s1 = fmaxf(s1, 0.f);   // lanes 0..15 hold channel (lane & 15)
-            float s2 = bsb;
+        // ---- scale stream: [n, |mean|, mean_x, mean_y, mean_z] -> 16 -> 32   (pillar_vfe.py:213-216) ---------------------
+        const float nrm = sqrtf(mx * mx + my * my + mz * mz);
+        float s1 = bsa;
+        s1 = fmaf(wsa[0], fn, s1);
+        s1 = fmaf(wsa[1], nrm, s1);
+        s1 = fmaf(wsa[2], mx, s1);
+        s1 = fmaf(wsa[3], my, s1);
+        s1 = fmaf(wsa[4], mz, s1);
+        s1 = fmaxf(s1, 0.f);   // lanes 0..15 hold channel (lane & 15)
+        float s2 = bsb;
+        {
+            // second scale layer: the 16 weights of this lane's channel are re-read per pillar (L1-resident) instead of
+            // living in registers — with them the kernel does not fit 128 VGPRs = four workgroups per CU
+            int opaque = 0;
+            asm volatile("" : "+v"(opaque));
+            const float4 *wp = (const float4 *)(ws1 + (lane & 31) * CS0 + opaque);
 #pragma unroll
-            for (int j = 0; j < CS0; ++j)
-                s2 = fmaf(wsb[j], rlf(s1, j), s2);
-            if (lane < CS1) scale_features[(size_t)ph * CS1 + lane] = fmaxf(s2, 0.f);
-            if (GATHER && g.spatial_scale && lane < CS1) g.spatial_scale[cell * CS1 + lane] = fmaxf(s2, 0.f);
+            for (int q = 0; q < CS0 / 4; ++q) {
+                const float4 w4 = wp[q];
+                s2 = fmaf(w4.x, rlf(s1, 4 * q), s2);
+                s2 = fmaf(w4.y, rlf(s1, 4 * q + 1), s2);
+                s2 = fmaf(w4.z, rlf(s1, 4 * q + 2), s2);
+                s2 = fmaf(w4.w, rlf(s1, 4 * q + 3), s2);
+            }
+        }
+        s2 = fmaxf(s2, 0.f);
+        if (lane < CS1) {
+            scale_features[(size_t)p * CS1 + lane] = s2;
+            if (GATHER) g.spatial_scale[cell * CS1 + lane] = s2;
         }
 #ifdef HVPR_EXP_TIMING
         tt3 = __builtin_readcyclecounter();
-        if ((blockIdx.x == 0 || blockIdx.x == 200 || blockIdx.x == 400) && (threadIdx.x == 0 || threadIdx.x == 32))
-            printf("vfe blk %d lane %d n %d: load/select %lld, phase A %lld, phase B %lld cycles (entry->end %lld)\n", (int)blockIdx.x,
-                   (int)threadIdx.x, n, tt1 - tt0, tt2 - tt1, tt3 - tt2, tt3 - tt0);
+        if (((blockIdx.x - fill_blocks) % 100 == 0) && threadIdx.x == 0)
+            printf("vfe-abs work blk %d: %lld .. %lld (x10 ns)\n", (int)blockIdx.x - fill_blocks, rt0, (long long)__builtin_amdgcn_s_memrealtime());
+        if ((tt3 - tt0 > 30000 || blockIdx.x == fill_blocks) && lane == 0)
+            printf("vfe blk %d wave %d n %d: load/select %lld, layer 0 %lld, layer 1 %lld cycles (entry->end %lld = %lld ns)\n", (int)blockIdx.x,
+                   (int)(threadIdx.x >> 6), n, tt1 - tt0, tt2 - tt1, tt3 - tt2, tt3 - tt0, 10 * ((long long)__builtin_amdgcn_s_memrealtime() - rt0));
 #endif
     }
 }
@@ -287,13 +409,19 @@ __global__ void __launch_bounds__(256) k_vfe(const float4 *__restrict__ voxels, 
 int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxel_offsets, int capacity, const VfeWeights &v,
                       float *voxels, int32_t *coords, int32_t *num_points, float *pillar_features, float *scale_features,
                       float *pillar_mask, float *spatial, int spatial_channels, float *spatial_scale, hipStream_t s) {
-    if (a.n_feat != 4 || a.max_points > 32 || a.nz != 1) return HVPR_ERR_UNSUPPORTED;
+    if (a.n_feat != 4 || a.max_points > 32 || a.nz != 1 || a.n_points >= (1 << 26)) return HVPR_ERR_UNSUPPORTED;
     if (!spatial || !spatial_scale || spatial_channels != 2 * C1) return HVPR_ERR_INVALID_ARG;
-    int blocks = hvpr_cdiv(hvpr_cdiv(capacity, 2), 4);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = hvpr_cdiv(capacity, 4);
+    if (blocks > 1024) blocks = 1024;   // four workgroups per CU: all resident at once, next to the clearing workgroups
+    if (blocks < 1) blocks = 1;
+    int idx_bits = 1;
+    while (idx_bits < 30 && (1ll << idx_bits) < (long long)a.n_points) ++idx_bits;
     GatherSrc g{a.points, a.point_stride, a.xyz_col, a.batch, a.nx, a.ny, a.nz, a.max_voxels, a.cap_mode, capacity, w,
-                voxel_offsets, voxels, coords, num_points, spatial, spatial_channels, spatial_scale, blocks};
-    hipLaunchKernelGGL(k_vfe<true>, dim3(blocks + 768), dim3(256), 0, s, nullptr, nullptr, nullptr, capacity, a.max_points,
+                voxel_offsets, voxels, coords, num_points, spatial, spatial_channels, spatial_scale, blocks, idx_bits};
+    const long long n_cells = (long long)a.batch * a.nx * a.ny;
+    long long fill = (n_cells + 767) / 768;     // three 64-cell steps per wave: few, long-lived workgroups — they hold slots
+    if (fill > 1024) fill = 1024;               // the pillar workgroups want
+    hipLaunchKernelGGL(k_vfe<true>, dim3(blocks + (int)fill), dim3(256), 0, s, nullptr, nullptr, nullptr, capacity, a.max_points,
                        voxel_offsets + a.batch, v.vs_x, v.vs_y, v.vs_z, v.off_x, v.off_y, v.off_z, v.w0, v.b0, v.w1, v.b1, v.ws0,
                        v.bs0, v.ws1, v.bs1, pillar_features, scale_features, pillar_mask, g);
     HVPR_CHECK_LAUNCH();
@@ -313,7 +441,7 @@ extern "C" int hvpr_pillar_vfe_fwd_f32(const float *voxels, const int32_t *num_p
     if (!voxels || !num_points || !coords || !w0 || !b0 || !w1 || !b1 || !ws0 || !bs0 || !ws1 || !bs1 ||
         !pillar_features || !pillar_scale_features)
         return HVPR_ERR_INVALID_ARG;
-    int blocks = hvpr_cdiv(hvpr_cdiv(M, 2), 4);
+    int blocks = hvpr_cdiv(M, 4);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_vfe<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)voxels, num_points,
                        (const int4 *)coords, M, P, m_device, vs_x, vs_y, vs_z, off_x, off_y, off_z, w0, b0, w1, b1, ws0,

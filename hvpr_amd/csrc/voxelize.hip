@@ -159,7 +159,8 @@ __global__ void __launch_bounds__(kScanThreads) k2_scan(int n, const int *__rest
 }
 
 __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ foff, int batch, int max_voxels, VoxWs w,
-                                               int *__restrict__ voxel_offsets, int keep_cell_first) {
+                                               int *__restrict__ voxel_offsets, int for_encode,
+                                               const float *__restrict__ pts, int stride, int xyz_col) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         int acc = 0;
@@ -173,12 +174,21 @@ __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ fo
     if (i >= n) return;
     const int g = w.pt_cell[i];
     if (g < 0) return;
+    float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (for_encode) {   // requested before the dependent chain below, lands for free
+        const float *src = pts + (size_t)i * stride + xyz_col;
+        pt = make_float4(src[0], src[1], src[2], src[3]);
+    }
     const int r = w.cell_vid[g];
     const int b = frame_of(foff, batch, i);
     const int local = r - w.frame_base[b];
     const int slot = atomicSub(&w.cell_count[g], 1) - 1;   // returns the map to its idle 0
-    if (!keep_cell_first) w.cell_first[g] = kIdle;         // idle again (benign same-value race)
-    if (local < max_voxels) w.arena[w.vox_rec[r].z + slot] = i;
+    if (!for_encode) w.cell_first[g] = kIdle;              // idle again (benign same-value race)
+    if (local < max_voxels) {
+        const int pos = w.vox_rec[r].z + slot;
+        w.arena[pos] = i;
+        if (for_encode) w.arena_pt[pos] = pt;
+    }
 }
 
 __device__ __forceinline__ int bitonic64_asc(int v, int lane) {
@@ -253,14 +263,15 @@ __global__ void __launch_bounds__(256) k4_gather(const float *__restrict__ pts, 
 
 }  // namespace
 
-int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool keep_cell_first, hipStream_t s) {
+int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode, hipStream_t s) {
+    if (for_encode && a.n_feat != 4) return HVPR_ERR_UNSUPPORTED;
     const int tiles = hvpr_cdiv(a.n_points, kScanTile);
     const int pblocks = hvpr_cdiv(a.n_points, 256);
     hipLaunchKernelGGL(k1_keys, dim3(pblocks), dim3(256), 0, s, a.points, a.n_points, a.point_stride, a.xyz_col, a.frame_offsets,
                        a.batch, a.lo_x, a.lo_y, a.lo_z, a.vs_x, a.vs_y, a.vs_z, a.nx, a.ny, a.nz, w, tiles);
     hipLaunchKernelGGL(k2_scan, dim3(tiles), dim3(kScanThreads), 0, s, a.n_points, a.frame_offsets, a.batch, w);
     hipLaunchKernelGGL(k3_fill, dim3(pblocks), dim3(256), 0, s, a.n_points, a.frame_offsets, a.batch, a.max_voxels, w,
-                       voxel_offsets, keep_cell_first ? 1 : 0);
+                       voxel_offsets, for_encode ? 1 : 0, a.points, a.point_stride, a.xyz_col);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
