@@ -139,6 +139,17 @@ __global__ void __launch_bounds__(256, 4) k_vfe(const float4 *__restrict__ voxel
     int4 rec0 = make_int4(0, 0, 0, 0);
     if (GATHER && g.batch == 1 && wave < g.capacity) rec0 = g.w.vox_rec[wave];
     if (m_device) M = min(M, *m_device);
+    // The three weight matrices go through LDS once per workgroup, coalesced (every wave needs them in a gathered
+    // per-lane layout: read straight from memory, 4096 waves x ~170 cache-line requests on the same 11 KB were the
+    // longest wait of the kernel).  Rows padded to 36 / 20 floats: conflict-free 16-byte reads.
+    __shared__ __attribute__((aligned(16))) float s_w1[C1 * 36];
+    __shared__ __attribute__((aligned(16))) float s_ws1[CS1 * 20];
+    __shared__ __attribute__((aligned(16))) float s_w0[C0 * CIN];
+    for (int i = threadIdx.x; i < C1 * 32 / 4; i += 256)
+        *(float4 *)&s_w1[(i >> 3) * 36 + (i & 7) * 4] = ((const float4 *)w1)[i];
+    if (threadIdx.x < CS1 * CS0 / 4) *(float4 *)&s_ws1[(threadIdx.x >> 2) * 20 + (threadIdx.x & 3) * 4] = ((const float4 *)ws1)[threadIdx.x];
+    if (threadIdx.x < C0 * CIN / 4) ((float4 *)s_w0)[threadIdx.x] = ((const float4 *)w0)[threadIdx.x];
+    __syncthreads();
     if (wave >= M) return;
 #ifdef HVPR_EXP_TIMING
     const long long tt0 = __builtin_readcyclecounter();
@@ -154,7 +165,7 @@ __global__ void __launch_bounds__(256, 4) k_vfe(const float4 *__restrict__ voxel
     // ends layer 0 with channels chm(r) = 8 * (r / 4) + 4 * hh + r % 4, r < 8, and feeds exactly those to layer 1.
     float a0w[CIN / 2], b0h[8];
 #pragma unroll
-    for (int t = 0; t < CIN / 2; ++t) a0w[t] = slot < C0 ? w0[slot * CIN + 2 * t + h] : 0.f;
+    for (int t = 0; t < CIN / 2; ++t) a0w[t] = slot < C0 ? s_w0[slot * CIN + 2 * t + h] : 0.f;
     {
         const float4 lo = *(const float4 *)(b0 + 4 * h), hi = *(const float4 *)(b0 + 8 + 4 * h);
         b0h[0] = lo.x; b0h[1] = lo.y; b0h[2] = lo.z; b0h[3] = lo.w; b0h[4] = hi.x; b0h[5] = hi.y; b0h[6] = hi.z; b0h[7] = hi.w;
@@ -164,7 +175,7 @@ __global__ void __launch_bounds__(256, 4) k_vfe(const float4 *__restrict__ voxel
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float4 w4 = *(const float4 *)(w1 + (32 * mb + slot) * 32 + 8 * q + 4 * h);
+            const float4 w4 = *(const float4 *)&s_w1[(32 * mb + slot) * 36 + 8 * q + 4 * h];
             aw[mb][4 * q] = w4.x; aw[mb][4 * q + 1] = w4.y; aw[mb][4 * q + 2] = w4.z; aw[mb][4 * q + 3] = w4.w;
         }
     // after the transposing reduction lane l holds output channels 32 mb + 16 l4 + 8 l3 + 4 hh + 2 l1 + l0 (both mb, and
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(256, 4) k_vfe(const float4 *__restrict__ voxel
     float wb[C0];
 #pragma unroll
     for (int q = 0; q < C0 / 4; ++q) {
-        const float4 w4 = *(const float4 *)(w1 + oc * 32 + C0 + 4 * q);
+        const float4 w4 = *(const float4 *)&s_w1[oc * 36 + C0 + 4 * q];
         wb[4 * q] = w4.x; wb[4 * q + 1] = w4.y; wb[4 * q + 2] = w4.z; wb[4 * q + 3] = w4.w;
     }
     const float b1l = b1[oc];
@@ -374,11 +385,9 @@ __global__ void __launch_bounds__(256, 4) k_vfe(const float4 *__restrict__ voxel
         s1 = fmaxf(s1, 0.f);   // lanes 0..15 hold channel (lane & 15)
         float s2 = bsb;
         {
-            // second scale layer: the 16 weights of this lane's channel are re-read per pillar (L1-resident) instead of
-            // living in registers — with them the kernel does not fit 128 VGPRs = four workgroups per CU
-            int opaque = 0;
-            asm volatile("" : "+v"(opaque));
-            const float4 *wp = (const float4 *)(ws1 + (lane & 31) * CS0 + opaque);
+            // second scale layer: the 16 weights of this lane's channel are read from LDS per pillar instead of living in
+            // registers — with them the kernel does not fit 128 VGPRs = four workgroups per CU
+            const float4 *wp = (const float4 *)&s_ws1[(lane & 31) * 20];
 #pragma unroll
             for (int q = 0; q < CS0 / 4; ++q) {
                 const float4 w4 = wp[q];
