@@ -1,9 +1,8 @@
 // a1..a4 fused: raw points -> dense BEV canvases in five launches (hvpr_encode_fwd_f32, include/hvpr_amd.h).
 //   K1 keys | K2 rank scan | K3 arena fill      voxelizer index kernels (voxelize.hip)
-//   k_vfe<gather>                               voxel gather + pillar VFE + pillar/scale cells of the canvases (vfe.hip);
-//                                               extra workgroups of this latency-bound launch clear every canvas cell that
-//                                               belongs to no pillar (47 MB at hvpr_car, hidden under the VFE's dependent loads)
+//   k_vfe<gather>                               voxel gather + pillar VFE + pillar/scale cells of the canvases (vfe.hip)
 //   k_memory_readout                            memory read-out + memory cells of the main canvas (memory_scatter.hip)
+//   Extra workgroups of the VFE launch clear every canvas cell that belongs to no pillar (47 MB at hvpr_car).
 // Replaces the reference chain data_processor.py:43-75 -> pillar_vfe.py:184-221 -> memory_module.py:60-77 ->
 // pointpillar_scatter.py:169-222.  Results are bit-identical to the three separate C-ABI calls (tests/test_gpu_stage1.py).
 #include "common.h"

@@ -45,6 +45,52 @@ static inline size_t hvpr_vox_ws_bytes(int batch, int n, long long ncell) {
     return (size_t)((char *)(w.ticket) - (char *)nullptr) + 256;
 }
 
+// The dense BEV canvases of the fused encode path are cleared by EXTRA workgroups of the pillar-VFE launch (47 MB at
+// hvpr_car, next to the pillar waves' dependent loads; measured: hosting part of it on the ~22 CUs the memory read-out
+// leaves idle slows the read-out by more than it saves — a CU streams only ~45 GB/s of stores).  No race with the cells
+// the pillar waves and the read-out write: a cell whose voxel is emitted is skipped — the voxelizer's
+// cell maps still say which cells are occupied (K3 leaves cell_first alone on this path) and this pass returns them to
+// idle while it is there.
+struct ClearJob {
+    int *cell_first;              // [B * ny * nx], kIdle = empty; reset here
+    const int *cell_vid;          // rank of an occupied cell's voxel (uncapped order)
+    const int *frame_base;        // [B + 1]
+    const int *voxel_offsets;     // [B + 1]
+    int batch, nx, ny, max_voxels, capacity;
+    float *spatial;               // [B, ny, nx, 128]
+    float *spatial_scale;         // [B, ny, nx, 32]
+    long long cell_lo, cell_hi;   // the cells this launch clears
+};
+
+__device__ __forceinline__ void hvpr_canvas_clear(const ClearJob &c, int blk, int nblk) {
+    constexpr int V = 32, VS = 8;   // float4 per cell of the main / scale canvas; a wave clears 64 cells (40 KB) per step
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blk * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)nblk * blockDim.x) >> 6;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long long c0 = c.cell_lo + wave * 64; c0 < c.cell_hi; c0 += n_waves * 64) {
+        const long long cell = c0 + lane;
+        bool emitted = false;
+        if (cell < c.cell_hi && c.cell_first[cell] != kIdle) {
+            c.cell_first[cell] = kIdle;
+            const int b = (int)(cell / ((long long)c.nx * c.ny));
+            const int local = c.cell_vid[cell] - c.frame_base[b];
+            emitted = local < c.max_voxels && c.voxel_offsets[b] + local < c.capacity;
+        }
+        const unsigned long long skip = __ballot(emitted);   // bit i: cell c0 + i belongs to a pillar
+        // streaming stores: the zeros must not push the arrays the neighbouring waves are reading out of the L2
+        f32x4 *const main = reinterpret_cast<f32x4 *>(c.spatial) + c0 * V;
+        f32x4 *const side = reinterpret_cast<f32x4 *>(c.spatial_scale) + c0 * VS;
+        const int cells = (int)min(64ll, c.cell_hi - c0);
+#pragma unroll 8
+        for (int i = lane; i < cells * V; i += 64)
+            if (!((skip >> (i / V)) & 1ull)) __builtin_nontemporal_store(zero, main + i);
+#pragma unroll 8
+        for (int i = lane; i < cells * VS; i += 64)
+            if (!((skip >> (i / VS)) & 1ull)) __builtin_nontemporal_store(zero, side + i);
+    }
+}
+
 struct VoxelizeArgs {
     const float *points;
     int n_points, point_stride, xyz_col, n_feat;
@@ -66,12 +112,12 @@ HVPR_INTERNAL int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int3
                                      hipStream_t s);
 // K4 fused into the pillar VFE: selects each voxel's points straight from the arena, writes voxels (optional) / coords /
 // num_points, the pillar and scale features and the pillar + scale cells of the NHWC canvases; extra workgroups of the same
-// launch clear every canvas cell that belongs to no pillar and return cell_first to idle (pair with keep_cell_first above).
+// launch clear every canvas cell that belongs to no pillar and return cell_first to idle (pair with for_encode above).
 HVPR_INTERNAL int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxel_offsets, int capacity,
                                     const VfeWeights &v, float *voxels, int32_t *coords, int32_t *num_points,
                                     float *pillar_features, float *scale_features, float *pillar_mask, float *spatial,
                                     int spatial_channels, float *spatial_scale, hipStream_t s);
-// memory read-out; optional cell map (gather-form scatter) or direct write of the memory cells of a pre-cleared canvas
+// memory read-out; optional cell map (gather-form scatter) or direct write of the memory cells of a canvas
 HVPR_INTERNAL int hvpr_i_readout(const float *f, int M, const int32_t *m_device, const float *bank, int n_items, int k,
                                  float *out, int32_t *topk_idx, const int32_t *coords, int batch, int nx, int ny,
                                  int *cell_map, float *canvas, int canvas_channels, int canvas_offset, hipStream_t s);

@@ -41,44 +41,10 @@ struct GatherSrc {
     float *spatial;         // NHWC canvas, 128 channels per cell: pillar features in [0, 64), memory read-out in [64, 128)
     int spatial_channels;
     float *spatial_scale;   // NHWC canvas, 32 channels per cell
-    int work_blocks;        // the LAST work_blocks workgroups of the grid encode pillars, the ones before clear the canvases
+    int work_blocks;        // the LAST work_blocks workgroups of the grid encode pillars, the ones before clear canvas cells
+    ClearJob clear;         // ... (internal.h)
     int idx_bits;           // bits of the largest point index
 };
-
-// The dense canvases are cleared by extra workgroups of this latency-bound launch (47 MB at hvpr_car, hidden under the
-// VFE waves' dependent loads).  No race with the cells the VFE waves and the read-out write: a cell whose voxel is emitted
-// is skipped — the voxelizer's cell maps still say which cells are occupied (K3 leaves cell_first alone on this path) and
-// this pass returns them to idle while it is there.
-__device__ __forceinline__ void canvas_clear(const GatherSrc &g, int blk, int nblk) {
-    constexpr int V = 32, VS = 8;   // float4 per cell of the main / scale canvas; a wave clears 64 cells (40 KB) per step
-    const int lane = threadIdx.x & 63;
-    const long long n_cells = (long long)g.batch * g.nx * g.ny;
-    const long long wave = ((long long)blk * blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)nblk * blockDim.x) >> 6;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (long long c0 = wave * 64; c0 < n_cells; c0 += n_waves * 64) {
-        const long long c = c0 + lane;
-        bool emitted = false;
-        if (c < n_cells && g.w.cell_first[c] != kIdle) {
-            g.w.cell_first[c] = kIdle;
-            const int b = (int)(c / ((long long)g.nx * g.ny));
-            const int local = g.w.cell_vid[c] - g.w.frame_base[b];
-            emitted = local < g.max_voxels && g.voxel_offsets[b] + local < g.capacity;
-        }
-        const unsigned long long skip = __ballot(emitted);   // bit i: cell c0 + i belongs to a pillar
-        // streaming stores: 47 MB of zeros must not push the voxelizer's arrays, which the pillar waves of this launch are
-        // reading, out of the L2
-        f32x4 *const main = reinterpret_cast<f32x4 *>(g.spatial) + c0 * V;
-        f32x4 *const side = reinterpret_cast<f32x4 *>(g.spatial_scale) + c0 * VS;
-        const int cells = (int)min(64ll, n_cells - c0);
-#pragma unroll 8
-        for (int i = lane; i < cells * V; i += 64)
-            if (!((skip >> (i / V)) & 1ull)) __builtin_nontemporal_store(zero, main + i);
-#pragma unroll 8
-        for (int i = lane; i < cells * VS; i += 64)
-            if (!((skip >> (i / VS)) & 1ull)) __builtin_nontemporal_store(zero, side + i);
-    }
-}
 
 __device__ __forceinline__ int bitonic_asc(int v, int lane, int width) {
     for (int k = 2; k <= width; k <<= 1) {
@@ -122,7 +88,7 @@ __global__ void __launch_bounds__(256, 4) k_vfe(const float4 *__restrict__ voxel
 #ifdef HVPR_EXP_TIMING
         const long long f0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        canvas_clear(g, blockIdx.x, fill_blocks);
+        hvpr_canvas_clear(g.clear, blockIdx.x, fill_blocks);
 #ifdef HVPR_EXP_TIMING
         if ((blockIdx.x == 0 || blockIdx.x == fill_blocks - 1 || blockIdx.x == fill_blocks / 2) && threadIdx.x == 0)
             printf("vfe-abs fill blk %d: %lld .. %lld (x10 ns)\n", (int)blockIdx.x, f0, (long long)__builtin_amdgcn_s_memrealtime());
@@ -420,16 +386,21 @@ int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxe
                       float *pillar_mask, float *spatial, int spatial_channels, float *spatial_scale, hipStream_t s) {
     if (a.n_feat != 4 || a.max_points > 32 || a.nz != 1 || a.n_points >= (1 << 26)) return HVPR_ERR_UNSUPPORTED;
     if (!spatial || !spatial_scale || spatial_channels != 2 * C1) return HVPR_ERR_INVALID_ARG;
-    int blocks = hvpr_cdiv(capacity, 4);
-    if (blocks > 1024) blocks = 1024;   // four workgroups per CU: all resident at once, next to the clearing workgroups
+    // one frame (capacity <= 16 K pillars): 1024 workgroups = four per CU, all resident at once next to the clearing ones,
+    // one pillar per wave; batches: up to 8192 workgroups, each wave walks a few pillars
+    int blocks = hvpr_cdiv(capacity, 16);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1024) blocks = hvpr_cdiv(capacity, 4) < 1024 ? hvpr_cdiv(capacity, 4) : 1024;
     if (blocks < 1) blocks = 1;
     int idx_bits = 1;
     while (idx_bits < 30 && (1ll << idx_bits) < (long long)a.n_points) ++idx_bits;
-    GatherSrc g{a.points, a.point_stride, a.xyz_col, a.batch, a.nx, a.ny, a.nz, a.max_voxels, a.cap_mode, capacity, w,
-                voxel_offsets, voxels, coords, num_points, spatial, spatial_channels, spatial_scale, blocks, idx_bits};
     const long long n_cells = (long long)a.batch * a.nx * a.ny;
-    long long fill = (n_cells + 767) / 768;     // three 64-cell steps per wave: few, long-lived workgroups — they hold slots
-    if (fill > 1024) fill = 1024;               // the pillar workgroups want
+    const ClearJob cj{w.cell_first, w.cell_vid, w.frame_base, voxel_offsets, a.batch, a.nx, a.ny, a.max_voxels, capacity, spatial,
+                      spatial_scale, 0, n_cells};
+    GatherSrc g{a.points, a.point_stride, a.xyz_col, a.batch, a.nx, a.ny, a.nz, a.max_voxels, a.cap_mode, capacity, w,
+                voxel_offsets, voxels, coords, num_points, spatial, spatial_channels, spatial_scale, blocks, cj, idx_bits};
+    long long fill = (n_cells + 767) / 768;       // three 64-cell steps per wave: few, long-lived workgroups — they hold slots
+    if (fill > 1024) fill = 1024;                 // the pillar workgroups want
     hipLaunchKernelGGL(k_vfe<true>, dim3(blocks + (int)fill), dim3(256), 0, s, nullptr, nullptr, nullptr, capacity, a.max_points,
                        voxel_offsets + a.batch, v.vs_x, v.vs_y, v.vs_z, v.off_x, v.off_y, v.off_z, v.w0, v.b0, v.w1, v.b1, v.ws0,
                        v.bs0, v.ws1, v.bs1, pillar_features, scale_features, pillar_mask, g);
