@@ -1,8 +1,9 @@
-"""Turn the raw rocprofv3 CSVs under gpurun_out/r01b into the committed summaries under profiles/.
+"""Turn the raw rocprofv3 CSVs under gpurun_out/<run> (written by tools/run_profiles.sh on the GPU box) into the committed
+summaries under profiles/.
 
   profiles/r01_kernel_stats_single_graph.csv   rocprofv3 --kernel-trace --stats of `bench.py --no-pipeline` (serial frame graph)
   profiles/r01_kernel_stats_pipeline.csv       same of the default `bench.py` (frame pipeline; also holds the latency-mode and probe replays)
-  profiles/r01_kernel_stats_single_graph_bf16x6.csv / _bf16x3.csv   same with --conv-precision bf16x6 / bf16x3 (copied by hand)
+  profiles/r01_kernel_stats_single_graph_bf16x6.csv / _bf16x3.csv   same with --conv-precision bf16x6 / bf16x3
   profiles/r01_pmc_hbm_traffic.csv             per-kernel FETCH_SIZE / WRITE_SIZE (two separate --pmc passes), per frame
   profiles/roofline_traffic.json               the two totals bench.py quotes in `roofline.traffic`
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM /
@@ -15,12 +16,16 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RAW = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r01b")
+RAW = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r01c")
 OUT = os.path.join(ROOT, "profiles")
 FRAMES_PMC = 13 + 6            # bench.py --steps 10 --warmup 3, plus GraphedForward's 3 eager warm-ups and ... (calls are normalised per kernel below)
 
 shutil.copy(os.path.join(RAW, "stats_single", "bench_kernel_stats.csv"), os.path.join(OUT, "r01_kernel_stats_single_graph.csv"))
 shutil.copy(os.path.join(RAW, "stats", "bench_kernel_stats.csv"), os.path.join(OUT, "r01_kernel_stats_pipeline.csv"))
+for prec in ("bf16x6", "bf16x3"):
+    src = os.path.join(RAW, "stats_" + prec, "bench_kernel_stats.csv")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(OUT, "r01_kernel_stats_single_graph_%s.csv" % prec))
 
 
 def per_kernel(path):
@@ -35,7 +40,7 @@ f_tot, f_cnt = per_kernel(os.path.join(RAW, "pmc_fetch", "f_counter_collection.c
 w_tot, w_cnt = per_kernel(os.path.join(RAW, "pmc_write", "w_counter_collection.csv"))
 frames = f_cnt[[k for k in f_cnt if "k_vfe" in k][0]]          # k_vfe runs exactly once per frame
 rows, group, conv = [], 0.0, 0.0
-GROUP = ("k1_keys", "k2_scan", "k3_fill", "k4_gather", "k_vfe", "k_memory_readout", "k_cell_map", "k_scatter")
+GROUP = ("k1_keys", "k2_scan", "k3_fill", "k4_gather", "k_vfe", "k_memory_readout", "k_cell_map", "k_scatter")   # fused path: 5 of them
 for k in sorted(f_tot, key=lambda k: -(2 * f_tot[k] + w_tot.get(k, 0))):
     calls = f_cnt[k] / frames
     fk, wk = f_tot[k] / f_cnt[k], w_tot.get(k, 0.0) / max(w_cnt.get(k, 1), 1)
