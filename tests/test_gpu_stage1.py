@@ -275,7 +275,7 @@ def test_fused_memory_scatter_equals_the_two_calls():
 
 
 # ---------------------------------------------------------------------------------------------- a1..a4 fused
-def _encode_both(frames, max_voxels, cap_mode=0, seed=40):
+def _encode_both(frames, max_voxels, cap_mode=0, seed=40, RNG=RNG, VS=VS, GRID=GRID, P=32):
     """hvpr_encode_fwd_f32 against the three separate C-ABI calls on the same inputs (points as (N,5) [b,x,y,z,r])."""
     pts = np.concatenate([np.concatenate([np.full((len(f), 1), b, np.float32), f], 1) for b, f in enumerate(frames)], 0)
     offs = torch.from_numpy(np.cumsum([0] + [len(f) for f in frames]).astype(np.int32)).to(DEV)
@@ -285,14 +285,14 @@ def _encode_both(frames, max_voxels, cap_mode=0, seed=40):
     vfe_off = [VS[0] / 2 + RNG[0], VS[1] / 2 + RNG[1], VS[2] / 2 + RNG[2]]
     W = torch.from_numpy(np.random.default_rng(seed).uniform(-0.125, 0.125, (2000, 64)).astype(np.float32)).to(DEV)
     ws = kernels.VoxelizeWorkspace(B, max(len(pts), 1), GRID, DEV)
-    v, c, n, vo = kernels.voxelize(tp, offs, B, RNG, VS, GRID, 32, max_voxels, ws, xyz_col=1, cap_mode=cap_mode)
+    v, c, n, vo = kernels.voxelize(tp, offs, B, RNG, VS, GRID, P, max_voxels, ws, xyz_col=1, cap_mode=cap_mode)
     md = vo[B:B + 1]
     pf, sf, mask = kernels.pillar_vfe_fwd(v, n, c, folded, VS, vfe_off, m_device=md)
     mem, sp, sc = kernels.memory_scatter_fwd(pf, sf, c, W, 20, B, GRID[0], GRID[1], kernels.scatter_workspace(B, GRID[0], GRID[1], DEV),
                                              m_device=md)
     outs = []
     for _ in range(2):   # the second call proves the voxelizer workspace came back to idle and stale canvases are cleared
-        r = kernels.encode_fwd(tp, offs, B, RNG, VS, GRID, 32, max_voxels, ws, folded, vfe_off, W, 20, xyz_col=1, cap_mode=cap_mode,
+        r = kernels.encode_fwd(tp, offs, B, RNG, VS, GRID, P, max_voxels, ws, folded, vfe_off, W, 20, xyz_col=1, cap_mode=cap_mode,
                                out=None if not outs else (outs[0]["spatial"], outs[0]["spatial_scale"]))
         torch.cuda.synchronize()
         outs.append(r)
@@ -322,3 +322,11 @@ def test_encode_fused_with_the_voxel_cap(cap_mode):
     f = synthetic.uniform_frame(11, 16384, RNG)
     for cap in (100, 4000):
         assert _encode_both([f, f[::-1].copy()], cap, cap_mode=cap_mode) == 2 * cap
+
+
+def test_encode_fused_dense_scene_config5():
+    """SURVEY.md §8d config 5 shape: 512 x 512 grid, 20 points per voxel, 200 k uniform points per frame, the 60 k voxel
+    cap hit in both frames (several pillars per wave, batch > 1 row lookup, P < 32)."""
+    rng = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    f = [synthetic.uniform_frame(80 + i, 200000, rng) for i in range(2)]
+    assert _encode_both(f, 60000, RNG=rng, VS=[0.2, 0.2, 8.0], GRID=[512, 512, 1], P=20) == 120000
