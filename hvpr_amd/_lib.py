@@ -24,11 +24,13 @@ SIGNATURES = {
                                _P, _P, _P, _P, _I, _P, _Z, _I, _I, _P]),
     "hvpr_pillar_vfe_fwd_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P]),
-    "hvpr_memory_readout_fwd_f32": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P]),
+    "hvpr_memory_bank_packed_floats": (_Z, [_I]),
+    "hvpr_memory_bank_pack_f32": (_I, [_P, _I, _P, _P]),
+    "hvpr_memory_readout_fwd_f32": (_I, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
     "hvpr_scatter_workspace_bytes": (_Z, [_I, _I, _I]),
-    "hvpr_memory_scatter_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    "hvpr_memory_scatter_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "hvpr_encode_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _F, _F, _F,
-                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P,
+                                 _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P,
                                  _P, _Z, _I, _I, _P]),
     "hvpr_scatter_bev_fwd_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "hvpr_spatial_gate_f32": (_I, [_P, _I, _I, _I, _I, _P, _F, _F, _F, _P, _P]),

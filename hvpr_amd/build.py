@@ -35,7 +35,7 @@ def build(force=False, verbose=False, timing=False):
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "hvpr_amd.h"))
     objdir = os.path.join(HERE, "csrc", "_obj_timing" if timing else "_obj")
     out = os.path.join(HERE, "libhvpr_amd_timing.so") if timing else OUT
-    extra = ["-DHVPR_EXP_TIMING"] if timing else []
+    extra = (["-DHVPR_EXP_TIMING"] + os.environ.get("HVPR_EXP_DEFINES", "").split()) if timing else []
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     objs = []

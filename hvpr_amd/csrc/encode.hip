@@ -13,7 +13,7 @@ extern "C" int hvpr_encode_fwd_f32(const float *points, int n_points, int point_
                                    float vs_y, float vs_z, int nx, int ny, int nz, int max_points, int max_voxels,
                                    int cap_mode, float off_x, float off_y, float off_z, const float *w0, const float *b0,
                                    const float *w1, const float *b1, const float *ws0, const float *bs0, const float *ws1,
-                                   const float *bs1, const float *bank, int n_items, int k, float *voxels, int32_t *coords,
+                                   const float *bs1, const float *bank, const float *bank_packed, int n_items, int k, float *voxels, int32_t *coords,
                                    int32_t *num_points, int32_t *voxel_offsets, int capacity, float *pillar_features,
                                    float *pillar_scale_features, float *pillar_mask, float *memory_features, float *spatial,
                                    float *spatial_scale, void *workspace, size_t workspace_bytes, int ws_max_batch,
@@ -46,6 +46,6 @@ extern "C" int hvpr_encode_fwd_f32(const float *points, int n_points, int point_
     st = hvpr_i_vfe_gather(a, w, voxel_offsets, capacity, v, voxels, coords, num_points, pillar_features, pillar_scale_features,
                            pillar_mask, spatial, 128, spatial_scale, s);
     if (st != HVPR_OK) return st;
-    return hvpr_i_readout(pillar_features, capacity, voxel_offsets + batch, bank, n_items, k, memory_features, nullptr, coords,
+    return hvpr_i_readout(pillar_features, capacity, voxel_offsets + batch, bank, bank_packed, n_items, k, memory_features, nullptr, coords,
                           batch, nx, ny, nullptr, spatial, 128, 64, s);
 }

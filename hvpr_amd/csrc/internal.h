@@ -118,6 +118,6 @@ HVPR_INTERNAL int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const
                                     float *pillar_features, float *scale_features, float *pillar_mask, float *spatial,
                                     int spatial_channels, float *spatial_scale, hipStream_t s);
 // memory read-out; optional cell map (gather-form scatter) or direct write of the memory cells of a canvas
-HVPR_INTERNAL int hvpr_i_readout(const float *f, int M, const int32_t *m_device, const float *bank, int n_items, int k,
+HVPR_INTERNAL int hvpr_i_readout(const float *f, int M, const int32_t *m_device, const float *bank, const float *bank_packed, int n_items, int k,
                                  float *out, int32_t *topk_idx, const int32_t *coords, int batch, int nx, int ny,
                                  int *cell_map, float *canvas, int canvas_channels, int canvas_offset, hipStream_t s);

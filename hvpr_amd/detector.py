@@ -306,7 +306,7 @@ class MixAnchor_Memory(_VoxelizingDetector):
         r = kernels.encode_fwd(pts, self._frame_offsets(batch_dict), B, vg.point_cloud_range, vg.voxel_size, vg.grid_size,
                                vg.max_num_points, vg.max_voxels, vg._workspace(B, pts.shape[0]),
                                self.vfe._fold.get(pts.device, self.vfe._build_folded), self.vfe.offsets,
-                               m.memory.weight.detach().contiguous(), m.k, xyz_col=1, cap_mode=vg.cap_mode,
+                               m.memory.packed_bank(), m.k, xyz_col=1, cap_mode=vg.cap_mode,
                                out=batch_dict.get("_out_spatial"))
         vo = r["voxel_offsets"]
         batch_dict.update(voxels=r["voxels"], voxel_coords=r["coords"], voxel_num_points=r["num_points"], voxel_offsets=vo,

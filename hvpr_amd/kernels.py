@@ -94,13 +94,35 @@ def pillar_vfe_fwd(voxels, num_points, coords, folded, voxel_size, offsets, m_de
 
 
 # ------------------------------------------------------------------------------------------------ memory + scatter
+class PackedBank:
+    """Memory bank in the read-out kernel's streaming layout (hvpr_memory_bank_pack_f32): same values, [tile of 16 items]
+    [4 pieces][64 lanes] float4, so that every load instruction of the logits loop reads 1 KB contiguous."""
+
+    def __init__(self, weight):
+        w = weight.detach().float().contiguous()
+        if w.dim() != 2 or w.shape[1] != 64:
+            raise ValueError("PackedBank: (n_items, 64) memory bank expected")
+        self.n_items = int(w.shape[0])
+        self.shape = w.shape
+        self.rows = w                 # row-major copy: the k selected rows are gathered from it
+        self.data = torch.empty(lib().hvpr_memory_bank_packed_floats(self.n_items), dtype=torch.float32, device=w.device)
+        check(lib().hvpr_memory_bank_pack_f32(_ptr(w, torch.float32, "memory.weight"), self.n_items, self.data.data_ptr(), _stream()),
+              "hvpr_memory_bank_pack_f32")
+
+
+def _bank_args(bank):
+    """(row-major pointer, packed pointer or None, n_items) of a plain (n_items, 64) tensor or a PackedBank."""
+    if isinstance(bank, PackedBank):
+        return bank.rows.data_ptr(), bank.data.data_ptr(), bank.n_items
+    return _ptr(bank, torch.float32, "memory.weight"), None, bank.shape[0]
+
+
 def memory_readout_fwd(f, bank, k, m_device=None, want_idx=False):
     M, C = f.shape
     out = torch.empty((M, C), dtype=torch.float32, device=f.device)
     idx = torch.empty((M, k), dtype=torch.int32, device=f.device) if want_idx else None
     check(lib().hvpr_memory_readout_fwd_f32(_ptr(f, torch.float32, "pillar_features"), M,
-                                            _ptr(m_device, torch.int32, "m_device"),
-                                            _ptr(bank, torch.float32, "memory.weight"), bank.shape[0], int(k),
+                                            _ptr(m_device, torch.int32, "m_device"), *_bank_args(bank), int(k),
                                             out.data_ptr(), _ptr(idx), _stream()), "hvpr_memory_readout_fwd_f32")
     return (out, idx) if want_idx else out
 
@@ -248,7 +270,7 @@ def memory_scatter_fwd(pillar, scale, coords, bank, k, batch, nx, ny, workspace,
         raise ValueError("memory_scatter_fwd is specialised for 64 pillar / 64 memory / 32 scale channels")
     check(lib().hvpr_memory_scatter_fwd_f32(_ptr(pillar, torch.float32, "pillar_features"), _ptr(scale, torch.float32, "scale"),
                                             _ptr(coords, torch.int32, "voxel_coords"), M, _ptr(m_device, torch.int32),
-                                            _ptr(bank, torch.float32, "memory.weight"), bank.shape[0], int(k), batch, nx, ny,
+                                            *_bank_args(bank), int(k), batch, nx, ny,
                                             mem.data_ptr(), spatial.data_ptr(), spatial_scale.data_ptr(), workspace.data_ptr(),
                                             workspace.numel() * 4, _stream()), "hvpr_memory_scatter_fwd_f32")
     return mem, spatial.permute(0, 3, 1, 2), spatial_scale.permute(0, 3, 1, 2)
@@ -294,8 +316,7 @@ def encode_fwd(points, frame_offsets, batch, point_cloud_range, voxel_size, grid
         float(offsets[0]), float(offsets[1]), float(offsets[2]),
         _ptr(folded["w0"], torch.float32), _ptr(folded["b0"], torch.float32), _ptr(folded["w1"], torch.float32),
         _ptr(folded["b1"], torch.float32), _ptr(folded["ws0"], torch.float32), _ptr(folded["bs0"], torch.float32),
-        _ptr(folded["ws1"], torch.float32), _ptr(folded["bs1"], torch.float32), _ptr(bank, torch.float32, "memory.weight"),
-        bank.shape[0], int(k), _ptr(voxels), coords.data_ptr(), num.data_ptr(), offs.data_ptr(), capacity, pf.data_ptr(),
+        _ptr(folded["ws1"], torch.float32), _ptr(folded["bs1"], torch.float32), *_bank_args(bank), int(k), _ptr(voxels), coords.data_ptr(), num.data_ptr(), offs.data_ptr(), capacity, pf.data_ptr(),
         sf.data_ptr(), _ptr(mask), mem.data_ptr(), spatial.data_ptr(), spatial_scale.data_ptr(), workspace.buf.data_ptr(),
         workspace.buf.numel(), workspace.key[0], workspace.key[1], _stream()), "hvpr_encode_fwd_f32")
     return {"voxels": voxels, "coords": coords, "num_points": num, "voxel_offsets": offs, "pillar_features": pf,

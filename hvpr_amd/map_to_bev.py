@@ -21,13 +21,23 @@ class MemoryUnit_Agg(nn.Module):
         self.weight = nn.Parameter(torch.empty(mem_dim, fea_dim))
         stdv = 1.0 / math.sqrt(fea_dim)
         self.weight.data.uniform_(-stdv, stdv)
+        self._packed = None
+
+    def packed_bank(self):
+        """The bank in the read-out kernel's streaming layout (kernels.PackedBank), re-packed when the weight changed
+        (in-place updates bump the tensor version; .to() / load_state_dict change the storage)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, kernels.PackedBank(w) if (w.is_cuda and w.shape[1] == 64) else w.detach().contiguous())
+        return self._packed[1]
 
     def forward(self, input1, k, input2=None):
         """Eval branch (memory_module.py:60-77): returns {'output': (nv, C)}; 'att' is never consumed in eval.
         Training branch (:31-59): input2 = the k positive point features of every pillar, (nv, k, C)."""
         if self.training:
             return self._forward_train(input1, k, input2)
-        return {"output": kernels.memory_readout_fwd(input1.contiguous(), self.weight.detach().contiguous(), k)}
+        return {"output": kernels.memory_readout_fwd(input1.contiguous(), self.packed_bank(), k)}
 
     def _forward_train(self, pillars, k, positives):
         nv, _, d = positives.shape
@@ -189,7 +199,7 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         pf, sf = batch_dict["pillar_features"], batch_dict["pillar_scale_features"]
         md = batch_dict.get("voxel_count_device")
         B = _batch_size(batch_dict)
-        bank = self.memory.weight.detach().contiguous()
+        bank = self.memory.packed_bank()
         if pf.shape[1] == 64 and sf.shape[1] == 32 and bank.shape[1] == 64:   # hvpr.yaml widths: fused read-out + scatter
             _, sp, sc = kernels.memory_scatter_fwd(pf.contiguous(), sf.contiguous(), _coords_i32(batch_dict), bank, self.k, B,
                                                    self.nx, self.ny, self._workspace(B, pf.device), m_device=md,

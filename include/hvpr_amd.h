@@ -93,9 +93,14 @@ int hvpr_pillar_vfe_fwd_f32(const float *voxels, const int32_t *num_points, cons
  *     softmax over the k selected logits, weighted sum of the k items.
  *     f [M,64], bank [n_items,64] -> out [M,64]; topk_idx [M,k] i32 (may be NULL; the k selected ids, order unspecified).
  *     k <= 32, channels == 64.
+ *     bank_packed (may be NULL): the output of hvpr_memory_bank_pack_f32 for the same bank (same values, tiled so that the
+ *     logits loop streams it in full cache lines: 27 k instead of 36.5 k cycles at hvpr_car); pack once per weight update.
+ *     `bank` itself is always needed (the k selected rows are read from it).
  * ------------------------------------------------------------------------------------------- */
-int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t *m_device, const float *bank, int n_items,
-                                int k, float *out, int32_t *topk_idx, hvpr_stream_t stream);
+size_t hvpr_memory_bank_packed_floats(int n_items);   /* floats in the packed copy (rows padded to a multiple of 16) */
+int hvpr_memory_bank_pack_f32(const float *bank, int n_items, float *packed, hvpr_stream_t stream);
+int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t *m_device, const float *bank, const float *bank_packed,
+                                int n_items, int k, float *out, int32_t *topk_idx, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a4  Scatter to the dense BEV canvases.  Replaces the eval branch of
@@ -116,7 +121,8 @@ int hvpr_scatter_bev_fwd_f32(const float *pillar_features, int c_pillar, const f
  *     memory read-out also fills the scatter cell map (one launch less than the two calls above, same results).
  *     Fixed channel counts 64 (pillar) + 64 (memory) + 32 (scale).  memory_features [M,64] is an output. */
 int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale_features, const int32_t *coords, int M,
-                                const int32_t *m_device, const float *bank, int n_items, int k, int batch, int nx, int ny,
+                                const int32_t *m_device, const float *bank, const float *bank_packed, int n_items, int k, int batch,
+                                int nx, int ny,
                                 float *memory_features, float *spatial, float *spatial_scale, void *workspace,
                                 size_t workspace_bytes, hvpr_stream_t stream);
 
@@ -134,7 +140,7 @@ int hvpr_encode_fwd_f32(const float *points, int n_points, int point_stride, int
                         float vs_z, int nx, int ny, int nz, int max_points, int max_voxels, int cap_mode, float off_x,
                         float off_y, float off_z, const float *w0, const float *b0, const float *w1, const float *b1,
                         const float *ws0, const float *bs0, const float *ws1, const float *bs1, const float *bank,
-                        int n_items, int k, float *voxels, int32_t *coords, int32_t *num_points, int32_t *voxel_offsets,
+                        const float *bank_packed, int n_items, int k, float *voxels, int32_t *coords, int32_t *num_points, int32_t *voxel_offsets,
                         int capacity, float *pillar_features, float *pillar_scale_features, float *pillar_mask,
                         float *memory_features, float *spatial, float *spatial_scale, void *workspace,
                         size_t workspace_bytes, int ws_max_batch, int ws_max_points, hvpr_stream_t stream);
