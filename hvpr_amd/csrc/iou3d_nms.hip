@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(64) k_nms_mask(const Box *__restrict__ prepare
     __shared__ __attribute__((aligned(16))) BoxLite s_lrow[64], s_lcol[64];
     __shared__ __attribute__((aligned(16))) float4 s_circ[64];   // column boxes: centre and circum-radius
     __shared__ unsigned long long s_bits[64];
-    __shared__ unsigned short s_pairs[64 * 64];
+    __shared__ unsigned short s_pairs[64 * 32];   // one half of the columns at a time: 37 KB of LDS = four tiles per CU
     __shared__ PolyStore ps;
     const int col = cb * 64 + t;
     if (row < n) s_row[t] = prepared[row];
@@ -230,58 +230,62 @@ __global__ void __launch_bounds__(64) k_nms_mask(const Box *__restrict__ prepare
 #ifdef HVPR_EXP_TIMING
     const long long tq0 = __builtin_readcyclecounter();
 #endif
-    unsigned long long near = 0ull;
-    if (row < n) {   // reject no. 1 (the circum-circle test of far_apart()), one broadcast 16-byte LDS read per column box
-        const float mx = s_lrow[t].x, my = s_lrow[t].y, mr = s_lrow[t].rad + 0.05f;
-        const int i0 = (rb == cb) ? t + 1 : 0;
+    int total2_all = 0;   // (only the HVPR_EXP_TIMING build reports it)
+    (void)total2_all;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int c_lo = 32 * half;
+        unsigned near = 0u;
+        if (row < n) {   // reject no. 1 (the circum-circle test of far_apart()), one broadcast 16-byte LDS read per column box
+            const float mx = s_lrow[t].x, my = s_lrow[t].y, mr = s_lrow[t].rad + 0.05f;
+            const int i0 = (rb == cb) ? t + 1 : 0;
 #pragma unroll 8
-        for (int i = 0; i < 64; ++i) {
-            const float4 c = s_circ[i];
-            const float ddx = mx - c.x, ddy = my - c.y, lim = mr + c.z;
-            const bool close = !(ddx * ddx + ddy * ddy > lim * lim * 1.0001f);
-            if (close && i >= i0 && i < ncol) near |= 1ull << i;
+            for (int i = 0; i < 32; ++i) {
+                const float4 c = s_circ[c_lo + i];
+                const float ddx = mx - c.x, ddy = my - c.y, lim = mr + c.z;
+                const bool close = !(ddx * ddx + ddy * ddy > lim * lim * 1.0001f);
+                if (close && c_lo + i >= i0 && c_lo + i < ncol) near |= 1u << i;
+            }
         }
-    }
-    // exclusive prefix of the per-lane pair counts
-    const int cnt = __popcll(near);
-    int incl = cnt;
+        // exclusive prefix of the per-lane pair counts
+        const int cnt = __popc(near);
+        int incl = cnt;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_up(incl, o, 64);
-        if (t >= o) incl += u;
-    }
-    const int total = __shfl(incl, 63, 64);
-    int pos = incl - cnt;
-    while (near) {
-        const int i = __ffsll((long long)near) - 1;
-        near &= near - 1;
-        s_pairs[pos++] = (unsigned short)((t << 6) | i);
-    }
-    __syncthreads();
-    // reject no. 2 (separating axes) on the packed pair list, compacted in place (one wave: writes trail reads)
-    int total2 = 0;
-    for (int k0 = 0; k0 < total; k0 += 64) {
-        const int k = k0 + t;
-        const int pr = k < total ? s_pairs[k] : 0;
-        const bool keep = k < total && !axes_separate(s_lrow[pr >> 6], s_lcol[pr & 63]);
-        const unsigned long long m = __ballot(keep);
-        if (keep) s_pairs[total2 + __popcll(m & ((1ull << t) - 1ull))] = (unsigned short)pr;
-        total2 += __popcll(m);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (t >= o) incl += u;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int pos = incl - cnt;
+        while (near) {
+            const int i = __ffs((int)near) - 1;
+            near &= near - 1;
+            s_pairs[pos++] = (unsigned short)((t << 6) | (c_lo + i));
+        }
+        __syncthreads();
+        // reject no. 2 (separating axes) on the packed pair list, compacted in place (one wave: writes trail reads)
+        int total2 = 0;
+        for (int k0 = 0; k0 < total; k0 += 64) {
+            const int k = k0 + t;
+            const int pr = k < total ? s_pairs[k] : 0;
+            const bool keep = k < total && !axes_separate(s_lrow[pr >> 6], s_lcol[pr & 63]);
+            const unsigned long long m = __ballot(keep);
+            if (keep) s_pairs[total2 + __popcll(m & ((1ull << t) - 1ull))] = (unsigned short)pr;
+            total2 += __popcll(m);
+        }
+        __syncthreads();
+        for (int k = t; k < total2; k += 64) {
+            const int pr = s_pairs[k];
+            const int r = pr >> 6, c = pr & 63;
+            if (iou_bev(s_row[r], s_col[c], ps, t) > thresh) atomicOr(&s_bits[r], 1ull << c);
+        }
+        __syncthreads();
+        total2_all += total2;
     }
     __syncthreads();
 #ifdef HVPR_EXP_TIMING
-    const long long tq1 = __builtin_readcyclecounter();
-#endif
-    for (int k = t; k < total2; k += 64) {
-        const int pr = s_pairs[k];
-        const int r = pr >> 6, c = pr & 63;
-        if (iou_bev(s_row[r], s_col[c], ps, t) > thresh) atomicOr(&s_bits[r], 1ull << c);
-    }
-    __syncthreads();
-#ifdef HVPR_EXP_TIMING
-    if (t == 0 && ((rb % 8 == 0 && cb % 8 == 0) || total > 600))
-        printf("nms tile %d %d: %d near pairs, reject %lld cycles, clip %lld cycles\n", rb, cb, total2, tq1 - tq0,
-               (long long)__builtin_readcyclecounter() - tq1);
+    if (t == 0 && rb % 8 == 0 && cb % 8 == 0)
+        printf("nms tile %d %d: %d pairs clipped, %lld cycles\n", rb, cb, total2_all, (long long)__builtin_readcyclecounter() - tq0);
 #endif
     if (row < n) mask[(size_t)row * nb + cb] = s_bits[t];
 }
