@@ -48,12 +48,22 @@ def _conv_bn_relu(cin, cout, stride=1, zero_pad=False):
     return [nn.Conv2d(cin, cout, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01), nn.ReLU()]
 
 
-def _tile_cfg(h, w, cout_cols):
-    """Workgroup tile of hvpr_conv2d_nhwc_f32.  Measured on MI355X at batch 1 (tools/bench_conv.py): the 64 px x 64 ch
-    tile wins on every hvpr_car layer — the persistent launch balances best with many small tiles; HVPR_CONV_TILE
-    overrides it for experiments."""
+# Workgroup tile of hvpr_conv2d_nhwc_f32 per layer group and level: 0 = 128 px x 128 ch, 1 = 64 px x 64 ch, 2 = 128 px x 64 ch.
+# Measured on MI355X at batch 1 inside the whole frame (bench.py; the two streams of the backbone interact, so the per-layer
+# micro-benchmarks tools/bench_conv.py / bench_conv1x1.py do not decide alone).  HVPR_CONV_TILES="ttt sss ccc ddd" (trunk, sfm,
+# scale, deconv per level) or HVPR_CONV_TILE=<one digit for all> override it for experiments.
+_TILES = {"trunk": (1, 1, 1), "sfm": (1, 1, 1), "scale": (1, 1, 1), "deconv": (1, 1, 2)}
+
+
+def _tile_cfg(kind, level):
     forced = os.environ.get("HVPR_CONV_TILE")
-    return int(forced) if forced is not None else 1
+    if forced is not None:
+        return int(forced)
+    table = os.environ.get("HVPR_CONV_TILES")
+    if table is not None:
+        groups = table.split()
+        return int(groups[("trunk", "sfm", "scale", "deconv").index(kind)][min(level, 2)])
+    return _TILES[kind][min(level, 2)]
 
 
 class BaseBEVBackbone_Scale(nn.Module):
@@ -127,7 +137,7 @@ class BaseBEVBackbone_Scale(nn.Module):
             h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
             blk = self.blocks[i]
             cout = blk[1].weight.shape[0]
-            cfg = _tile_cfg(h, w, cout)
+            cfg = _tile_cfg("trunk", i)
             lv = {"convs": []}
             sc, sh = bn_scale_shift(blk[2])
             lv["convs"].append(kernels.pack_conv(blk[1].weight, sc, sh, stride=s, tile_cfg=cfg))
@@ -135,7 +145,7 @@ class BaseBEVBackbone_Scale(nn.Module):
                 sc, sh = bn_scale_shift(blk[5 + 3 * k])
                 lv["convs"].append(kernels.pack_conv(blk[4 + 3 * k].weight, sc, sh, tile_cfg=cfg))
             sc, sh = bn_scale_shift(self.sfmblocks_down[i][1])
-            lv["sfm"] = kernels.pack_conv(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=cfg)
+            lv["sfm"] = kernels.pack_conv(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=_tile_cfg("sfm", i))
             planes = self.PRECISIONS[self.conv_precision]
             if planes:
                 c3 = 4                                # 64 px x 64 ch tiles, weights staged per kernel row (2-3 workgroups per CU)
@@ -154,11 +164,14 @@ class BaseBEVBackbone_Scale(nn.Module):
                     if (planes == 2 and de[0].weight.shape[0] % 64 == 0) else None
             sl = self.scale_layers[i]
             sc, sh = bn_scale_shift(sl[2])
-            lv["scale"] = kernels.pack_conv(sl[1].weight, sc, sh, stride=s, tile_cfg=_tile_cfg(h, w, sl[1].weight.shape[0]))
+            lv["scale"] = kernels.pack_conv(sl[1].weight, sc, sh, stride=s, tile_cfg=_tile_cfg("scale", i))
             de = self.deblocks[i]
             sc, sh = bn_scale_shift(de[1])
             us = int(self.upsample_strides[i])
-            lv["deconv"] = kernels.pack_deconv(de[0].weight, sc, sh, tile_cfg=_tile_cfg(h, w, us * us * de[0].weight.shape[1]))
+            # the k = s = 4 deconvolution (K = 512, 2048 columns, 4.6 k pixels) is bound by what its tiles pull out of L2: the
+            # 128 px x 64 ch tile halves the weight traffic per FLOP (121 -> 111 us alone, backbone 3.83 -> 3.75 ms in the frame)
+            dcfg = _tile_cfg("deconv", i)
+            lv["deconv"] = kernels.pack_deconv(de[0].weight, sc, sh, tile_cfg=dcfg)
             packed["levels"].append(lv)
         return packed
 
