@@ -23,9 +23,19 @@ class MemoryUnit_Agg(nn.Module):
         self.weight.data.uniform_(-stdv, stdv)
         self._packed = None
 
+    def train(self, mode=True):
+        self._packed = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(*a, **k)
+
     def packed_bank(self):
-        """The bank in the read-out kernel's streaming layout (kernels.PackedBank), re-packed when the weight changed
-        (in-place updates bump the tensor version; .to() / load_state_dict change the storage)."""
+        """The bank in the read-out kernel's streaming layout (kernels.PackedBank), re-packed when the weight changed:
+        tracked in-place updates bump the tensor version, .to() changes the storage, train() / load_state_dict drop the
+        copy.  (Writing through `weight.data` while in eval mode is invisible to all of these, as for the folded BatchNorms:
+        call train(False) again afterwards.)"""
         w = self.weight
         key = (w.data_ptr(), w._version, w.device)
         if self._packed is None or self._packed[0] != key:

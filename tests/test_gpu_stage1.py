@@ -330,3 +330,23 @@ def test_encode_fused_dense_scene_config5():
     rng = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
     f = [synthetic.uniform_frame(80 + i, 200000, rng) for i in range(2)]
     assert _encode_both(f, 60000, RNG=rng, VS=[0.2, 0.2, 8.0], GRID=[512, 512, 1], P=20) == 120000
+
+
+def test_packed_bank_equals_row_major_and_follows_the_weight():
+    """The read-out streams a packed copy of the bank (kernels.PackedBank): same results as the row-major bank, also for a
+    bank whose length is not a multiple of 16, and the module's cached copy follows weight updates."""
+    from hvpr_amd.map_to_bev import MemoryUnit_Agg
+    rng = np.random.default_rng(5)
+    f = torch.from_numpy(rng.normal(0, 1, (300, 64)).astype(np.float32)).to(DEV)
+    for n_items in (2000, 1999, 37):
+        W = torch.from_numpy(rng.uniform(-0.125, 0.125, (n_items, 64)).astype(np.float32)).to(DEV)
+        a, ia = kernels.memory_readout_fwd(f, W, 20, want_idx=True)
+        b, ib = kernels.memory_readout_fwd(f, kernels.PackedBank(W), 20, want_idx=True)
+        assert torch.equal(a, b) and torch.equal(ia.sort(dim=1)[0], ib.sort(dim=1)[0])
+    mem = MemoryUnit_Agg(2000, 64).to(DEV).eval()
+    out0 = mem(f, 20)["output"]
+    assert torch.equal(out0, kernels.memory_readout_fwd(f, mem.weight.detach(), 20))
+    with torch.no_grad():
+        mem.weight.mul_(-1.5)
+    out1 = mem(f, 20)["output"]
+    assert torch.equal(out1, kernels.memory_readout_fwd(f, mem.weight.detach(), 20)) and not torch.equal(out0, out1)
