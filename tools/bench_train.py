@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cfg", choices=["car", "3class"], default="car", help="car = config 3, 3class = config 4 of SURVEY.md §8d")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: MIOpen searches its convolution solvers once per shape")
+    ap.add_argument("--channels-last", action="store_true", help="backbone + head weights in channels_last memory format")
     args = ap.parse_args()
     rank, local_rank, world = distributed.env_rank()
     if not torch.cuda.is_available():
@@ -54,7 +56,12 @@ def main():
     cfg = hvpr_car_cfg() if args.cfg == "car" else hvpr_3class_cfg()
     model = detector.build_network(cfg.MODEL, len(cfg.CLASS_NAMES), detector.SyntheticDataset(cfg, training=True))
     synthetic_weights.load_synthetic(model, seed=0, cls_bias=-4.59511985013459)
-    model = distributed.wrap_ddp(model.to(device), device)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    model = model.to(device)
+    if args.channels_last:
+        model.backbone_2d.to(memory_format=torch.channels_last)
+        model.dense_head.to(memory_format=torch.channels_last)
+    model = distributed.wrap_ddp(model, device)
     opt = optim.build_optimizer(model, cfg.OPTIMIZATION)
     sched, _ = optim.build_scheduler(opt, total_iters_each_epoch=args.steps + args.warmup, total_epochs=1, last_epoch=-1,
                                      optim_cfg=cfg.OPTIMIZATION)
