@@ -89,6 +89,7 @@ class StagedGraphs:
 
     def __init__(self, model, example_batch):
         self.static_in = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        self.static_in.update(model.persistent_canvases(example_batch))   # as GraphedForward / PipelinedForward do
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():

@@ -31,7 +31,7 @@ SIGNATURES = {
     "hvpr_memory_scatter_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "hvpr_encode_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _F, _F, _F,
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P,
-                                 _P, _Z, _I, _I, _P]),
+                                 _P, _P, _Z, _I, _I, _P]),
     "hvpr_scatter_bev_fwd_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "hvpr_spatial_gate_f32": (_I, [_P, _I, _I, _I, _I, _P, _F, _F, _F, _P, _P]),
     "hvpr_head_decode_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P]),

@@ -16,8 +16,8 @@ extern "C" int hvpr_encode_fwd_f32(const float *points, int n_points, int point_
                                    const float *bs1, const float *bank, const float *bank_packed, int n_items, int k, float *voxels, int32_t *coords,
                                    int32_t *num_points, int32_t *voxel_offsets, int capacity, float *pillar_features,
                                    float *pillar_scale_features, float *pillar_mask, float *memory_features, float *spatial,
-                                   float *spatial_scale, void *workspace, size_t workspace_bytes, int ws_max_batch,
-                                   int ws_max_points, hvpr_stream_t stream) {
+                                   float *spatial_scale, uint8_t *canvas_state, void *workspace, size_t workspace_bytes,
+                                   int ws_max_batch, int ws_max_points, hvpr_stream_t stream) {
     if (!points || !frame_offsets || !coords || !num_points || !voxel_offsets || !workspace || !w0 || !b0 || !w1 || !b1 ||
         !ws0 || !bs0 || !ws1 || !bs1 || !bank || !pillar_features || !pillar_scale_features || !memory_features || !spatial ||
         !spatial_scale)
@@ -35,6 +35,7 @@ extern "C" int hvpr_encode_fwd_f32(const float *points, int n_points, int point_
         if (hipMemsetAsync(voxel_offsets, 0, sizeof(int) * (batch + 1), s) != hipSuccess) return HVPR_ERR_LAUNCH;
         if (hipMemsetAsync(spatial, 0, (size_t)cells * 128 * 4, s) != hipSuccess) return HVPR_ERR_LAUNCH;
         if (hipMemsetAsync(spatial_scale, 0, (size_t)cells * 32 * 4, s) != hipSuccess) return HVPR_ERR_LAUNCH;
+        if (canvas_state && hipMemsetAsync(canvas_state, 0, (size_t)cells, s) != hipSuccess) return HVPR_ERR_LAUNCH;
         return HVPR_OK;
     }
     const VoxWs w = hvpr_vox_carve(workspace, ws_max_batch, ws_max_points, ncell);
@@ -44,7 +45,7 @@ extern "C" int hvpr_encode_fwd_f32(const float *points, int n_points, int point_
     if (st != HVPR_OK) return st;
     const VfeWeights v{vs_x, vs_y, vs_z, off_x, off_y, off_z, w0, b0, w1, b1, ws0, bs0, ws1, bs1};
     st = hvpr_i_vfe_gather(a, w, voxel_offsets, capacity, v, voxels, coords, num_points, pillar_features, pillar_scale_features,
-                           pillar_mask, spatial, 128, spatial_scale, s);
+                           pillar_mask, spatial, 128, spatial_scale, canvas_state, s);
     if (st != HVPR_OK) return st;
     return hvpr_i_readout(pillar_features, capacity, voxel_offsets + batch, bank, bank_packed, n_items, k, memory_features, nullptr, coords,
                           batch, nx, ny, nullptr, spatial, 128, 64, s);

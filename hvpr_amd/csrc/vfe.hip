@@ -383,7 +383,8 @@ __global__ void __launch_bounds__(256, 4) k_vfe(const float4 *__restrict__ voxel
 
 int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxel_offsets, int capacity, const VfeWeights &v,
                       float *voxels, int32_t *coords, int32_t *num_points, float *pillar_features, float *scale_features,
-                      float *pillar_mask, float *spatial, int spatial_channels, float *spatial_scale, hipStream_t s) {
+                      float *pillar_mask, float *spatial, int spatial_channels, float *spatial_scale, unsigned char *canvas_state,
+                      hipStream_t s) {
     if (a.n_feat != 4 || a.max_points > 32 || a.nz != 1 || a.n_points >= (1 << 26)) return HVPR_ERR_UNSUPPORTED;
     if (!spatial || !spatial_scale || spatial_channels != 2 * C1) return HVPR_ERR_INVALID_ARG;
     // one frame (capacity <= 16 K pillars): 1024 workgroups = four per CU, all resident at once next to the clearing ones,
@@ -396,7 +397,7 @@ int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxe
     while (idx_bits < 30 && (1ll << idx_bits) < (long long)a.n_points) ++idx_bits;
     const long long n_cells = (long long)a.batch * a.nx * a.ny;
     const ClearJob cj{w.cell_first, w.cell_vid, w.frame_base, voxel_offsets, a.batch, a.nx, a.ny, a.max_voxels, capacity, spatial,
-                      spatial_scale, 0, n_cells};
+                      spatial_scale, 0, n_cells, canvas_state};
     GatherSrc g{a.points, a.point_stride, a.xyz_col, a.batch, a.nx, a.ny, a.nz, a.max_voxels, a.cap_mode, capacity, w,
                 voxel_offsets, voxels, coords, num_points, spatial, spatial_channels, spatial_scale, blocks, cj, idx_bits};
     long long fill = (n_cells + 767) / 768;       // three 64-cell steps per wave: few, long-lived workgroups — they hold slots

@@ -307,13 +307,23 @@ class MixAnchor_Memory(_VoxelizingDetector):
                                vg.max_num_points, vg.max_voxels, vg._workspace(B, pts.shape[0]),
                                self.vfe._fold.get(pts.device, self.vfe._build_folded), self.vfe.offsets,
                                m.memory.packed_bank(), m.k, xyz_col=1, cap_mode=vg.cap_mode,
-                               out=batch_dict.get("_out_spatial"))
+                               out=batch_dict.get("_out_spatial"), state=batch_dict.get("_canvas_state"))
         vo = r["voxel_offsets"]
         batch_dict.update(voxels=r["voxels"], voxel_coords=r["coords"], voxel_num_points=r["num_points"], voxel_offsets=vo,
                           voxel_count_device=vo[B:B + 1], pillar_features=r["pillar_features"],
                           pillar_scale_features=r["pillar_scale_features"], pillar_mask=r["pillar_mask"],
                           spatial_features=r["spatial"], spatial_scale_features=r["spatial_scale"])
         return batch_dict
+
+    def persistent_canvases(self, example_batch):
+        """{"_out_spatial", "_canvas_state"} for callers that replay the eval forward on fixed buffers (hipGraphs, the frame
+        pipeline): a zeroed canvas pair that stays theirs plus its occupancy state, so that encode_fused clears only the cells
+        the previous frame left behind (~2.4 MB instead of 47 MB per hvpr_car frame).  {} when the fused path does not apply."""
+        if not self._can_fuse_encode(example_batch):
+            return {}
+        m = self.map_to_bev_module
+        canv, state = kernels.canvas_buffers(example_batch["batch_size"], m.nx, m.ny, example_batch["points"].device)
+        return {"_out_spatial": canv, "_canvas_state": state}
 
     # the eval forward in the three stages a frame pipeline overlaps (PipelinedForward)
     def stage_encode(self, batch_dict):
@@ -361,6 +371,8 @@ class GraphedForward:
         assert not model.training
         self.model = model
         self.static_in = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        if hasattr(model, "persistent_canvases"):
+            self.static_in.update(model.persistent_canvases(example_batch))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -401,12 +413,14 @@ class PipelinedForward:
         self.B = example_batch["batch_size"]
         self.inp = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()} for _ in range(2)]
         self.canvas, self.head, self.aux = [None, None], [None, None], [None, None]
+        # each lane owns its canvases for good, so the encode stage only clears what the lane's previous frame left in them
+        self.own = [model.persistent_canvases(example_batch) if hasattr(model, "persistent_canvases") else {} for _ in range(2)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for p in range(2):                       # eager runs: lazy init + the persistent boundary buffers of each lane
                 for _ in range(warmup):
-                    bd = model.stage_encode(dict(self.inp[p]))
+                    bd = model.stage_encode({**self.inp[p], **self.own[p]})
                     self.canvas[p] = (bd["spatial_features"], bd["spatial_scale_features"])
                     bd = model.stage_dense(bd)
                     self.head[p] = tuple(bd[k] for k in self._HEAD_KEYS)
@@ -425,7 +439,7 @@ class PipelinedForward:
                 with torch.cuda.stream(self.s_post):      # frame k-2 (lane p): top-k + NMS
                     self.out[p] = model.post_processing(self._post_dict(p), sync=False)[0]
                 with torch.cuda.stream(self.s_enc):       # frame k (lane p): points -> canvases of lane p
-                    bd = model.stage_encode({**self.inp[p], "_out_spatial": self.canvas[p]})
+                    bd = model.stage_encode({**self.inp[p], "_out_spatial": self.canvas[p], **self.own[p]})
                     self.aux[p] = bd["voxel_offsets"]
                 # frame k-1 (lane q): convolutions on the capture stream (+ the backbone's own side stream)
                 model.stage_dense({"batch_size": self.B, "spatial_features": self.canvas[q][0],

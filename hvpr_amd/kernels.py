@@ -277,11 +277,13 @@ def memory_scatter_fwd(pillar, scale, coords, bank, k, batch, nx, ny, workspace,
 
 
 def encode_fwd(points, frame_offsets, batch, point_cloud_range, voxel_size, grid, max_points, max_voxels, workspace, folded,
-               offsets, bank, k, xyz_col=0, cap_mode=0, capacity=None, want_voxels=True, want_mask=True, out=None):
+               offsets, bank, k, xyz_col=0, cap_mode=0, capacity=None, want_voxels=True, want_mask=True, out=None, state=None):
     """a1..a4 fused (hvpr_encode_fwd_f32): raw points -> canvases in five launches, bit-identical to voxelize ->
     pillar_vfe_fwd -> memory_scatter_fwd.  Returns a dict with voxels|None, coords, num_points, voxel_offsets,
     pillar_features, pillar_scale_features, pillar_mask|None, memory_features, spatial (B,128,ny,nx), spatial_scale
-    (B,32,ny,nx) (channels_last).  `out` = (spatial, spatial_scale) of an earlier call: write into those canvases."""
+    (B,32,ny,nx) (channels_last).  `out` = (spatial, spatial_scale) of an earlier call: write into those canvases.
+    `state` (with `out`): the uint8 (B*ny*nx,) occupancy that travels with those canvases (see canvas_buffers): only the
+    cells the previous call left non-zero are cleared instead of the whole 47 MB."""
     n, stride = points.shape
     n_feat = stride - xyz_col
     if capacity is None:
@@ -306,6 +308,8 @@ def encode_fwd(points, frame_offsets, batch, point_cloud_range, voxel_size, grid
         spatial_scale = torch.empty((batch, ny, nx, 32), dtype=torch.float32, device=dev)
     if bank.shape[1] != 64:
         raise ValueError("encode_fwd is specialised for 64 pillar / 64 memory / 32 scale channels")
+    if state is not None and (out is None or state.dtype != torch.uint8 or state.numel() != batch * ny * nx or not state.is_contiguous()):
+        raise ValueError("encode_fwd: `state` is the (B*ny*nx,) uint8 occupancy of the `out` canvases")
     lo = [float(torch.tensor(v, dtype=torch.float32)) for v in point_cloud_range[:3]]
     vs = [float(torch.tensor(v, dtype=torch.float32)) for v in voxel_size]
     if workspace.key[0] < batch or workspace.key[1] < n:
@@ -317,11 +321,19 @@ def encode_fwd(points, frame_offsets, batch, point_cloud_range, voxel_size, grid
         _ptr(folded["w0"], torch.float32), _ptr(folded["b0"], torch.float32), _ptr(folded["w1"], torch.float32),
         _ptr(folded["b1"], torch.float32), _ptr(folded["ws0"], torch.float32), _ptr(folded["bs0"], torch.float32),
         _ptr(folded["ws1"], torch.float32), _ptr(folded["bs1"], torch.float32), *_bank_args(bank), int(k), _ptr(voxels), coords.data_ptr(), num.data_ptr(), offs.data_ptr(), capacity, pf.data_ptr(),
-        sf.data_ptr(), _ptr(mask), mem.data_ptr(), spatial.data_ptr(), spatial_scale.data_ptr(), workspace.buf.data_ptr(),
+        sf.data_ptr(), _ptr(mask), mem.data_ptr(), spatial.data_ptr(), spatial_scale.data_ptr(), _ptr(state), workspace.buf.data_ptr(),
         workspace.buf.numel(), workspace.key[0], workspace.key[1], _stream()), "hvpr_encode_fwd_f32")
     return {"voxels": voxels, "coords": coords, "num_points": num, "voxel_offsets": offs, "pillar_features": pf,
             "pillar_scale_features": sf, "pillar_mask": mask, "memory_features": mem,
             "spatial": spatial.permute(0, 3, 1, 2), "spatial_scale": spatial_scale.permute(0, 3, 1, 2)}
+
+
+def canvas_buffers(batch, nx, ny, device):
+    """A persistent pair of zeroed canvases + their occupancy state for encode_fwd(out=..., state=...): (spatial (B,128,ny,nx),
+    spatial_scale (B,32,ny,nx)) in channels_last memory format and the uint8 state.  Nobody else may write them."""
+    sp = torch.zeros((batch, ny, nx, 128), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+    sc = torch.zeros((batch, ny, nx, 32), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+    return (sp, sc), torch.zeros((batch * ny * nx,), dtype=torch.uint8, device=device)
 
 
 # ------------------------------------------------------------------------------------------------ convolutions

@@ -134,7 +134,13 @@ int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale
  *         cell cleared by extra workgroups of the (latency-bound) VFE launch: no scatter pass, no cell map.
  *     Arguments as in the three separate calls; n_feat must be 4, nz 1, max_points <= 32, channels 64 + 64 + 32.
  *     voxel_offsets[batch] is the live pillar count M (device word); rows >= M of the per-pillar outputs are unspecified.
- *     pillar_mask may be NULL.  workspace: hvpr_voxelize_workspace_bytes / _reset, as for hvpr_voxelize_f32. */
+ *     pillar_mask may be NULL.  workspace: hvpr_voxelize_workspace_bytes / _reset, as for hvpr_voxelize_f32.
+ *     Weight / bias pointers 16-byte aligned.
+ *     canvas_state (may be NULL): [batch * ny * nx] bytes that travel with ONE pair of canvases the caller keeps between calls.
+ *     NULL: every element of both canvases is written (zeros included), the canvases may hold anything on entry.
+ *     Non-NULL: 1 = the cell holds a pillar of the previous call, and the caller guarantees the canvases are zero wherever it
+ *     says 0 (start: canvases and state all zero).  Only the stale cells are then cleared (~2.4 MB instead of 47 MB per
+ *     hvpr_car frame) and the state is updated; results are the same dense canvases. */
 int hvpr_encode_fwd_f32(const float *points, int n_points, int point_stride, int xyz_col, int n_feat,
                         const int32_t *frame_offsets, int batch, float lo_x, float lo_y, float lo_z, float vs_x, float vs_y,
                         float vs_z, int nx, int ny, int nz, int max_points, int max_voxels, int cap_mode, float off_x,
@@ -142,7 +148,7 @@ int hvpr_encode_fwd_f32(const float *points, int n_points, int point_stride, int
                         const float *ws0, const float *bs0, const float *ws1, const float *bs1, const float *bank,
                         const float *bank_packed, int n_items, int k, float *voxels, int32_t *coords, int32_t *num_points, int32_t *voxel_offsets,
                         int capacity, float *pillar_features, float *pillar_scale_features, float *pillar_mask,
-                        float *memory_features, float *spatial, float *spatial_scale, void *workspace,
+                        float *memory_features, float *spatial, float *spatial_scale, uint8_t *canvas_state, void *workspace,
                         size_t workspace_bytes, int ws_max_batch, int ws_max_points, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

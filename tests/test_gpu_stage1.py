@@ -350,3 +350,30 @@ def test_packed_bank_equals_row_major_and_follows_the_weight():
         mem.weight.mul_(-1.5)
     out1 = mem(f, 20)["output"]
     assert torch.equal(out1, kernels.memory_readout_fwd(f, mem.weight.detach(), 20)) and not torch.equal(out0, out1)
+
+
+def test_encode_fused_persistent_canvases_sparse_clear():
+    """canvas_state: the same pair of canvases across different frames (and a frame with fewer pillars, an empty frame, a cap)
+    always equals the dense result of a fresh call, and the state equals the occupancy."""
+    frames_seq = [[synthetic.hvpr_frame(0), synthetic.hvpr_frame(1)[:4000]], [synthetic.hvpr_frame(2)[:300], synthetic.hvpr_frame(3)],
+                  [np.zeros((0, 4), np.float32), synthetic.hvpr_frame(4)[:50]], [synthetic.hvpr_frame(0), synthetic.hvpr_frame(1)[:4000]]]
+    folded = _folded_from(_vfe_params(41))
+    vfe_off = [VS[0] / 2 + RNG[0], VS[1] / 2 + RNG[1], VS[2] / 2 + RNG[2]]
+    W = torch.from_numpy(np.random.default_rng(41).uniform(-0.125, 0.125, (2000, 64)).astype(np.float32)).to(DEV)
+    canv, state = kernels.canvas_buffers(2, GRID[0], GRID[1], DEV)
+    ws = kernels.VoxelizeWorkspace(2, 40000, GRID, DEV)
+    for step, frames in enumerate(frames_seq):
+        cap = 40000 if step != 1 else 2000
+        pts = np.concatenate([np.concatenate([np.full((len(f), 1), b, np.float32), f], 1) for b, f in enumerate(frames)], 0)
+        offs = torch.from_numpy(np.cumsum([0] + [len(f) for f in frames]).astype(np.int32)).to(DEV)
+        tp = torch.from_numpy(pts).to(DEV)
+        ref = kernels.encode_fwd(tp, offs, 2, RNG, VS, GRID, 32, cap, ws, folded, vfe_off, W, 20, xyz_col=1)
+        got = kernels.encode_fwd(tp, offs, 2, RNG, VS, GRID, 32, cap, ws, folded, vfe_off, W, 20, xyz_col=1, out=canv, state=state)
+        torch.cuda.synchronize()
+        assert got["spatial"].data_ptr() == canv[0].data_ptr()
+        assert torch.equal(got["spatial"], ref["spatial"]) and torch.equal(got["spatial_scale"], ref["spatial_scale"]), step
+        m = int(ref["voxel_offsets"][-1])
+        c = ref["coords"][:m].long()
+        occ = torch.zeros(2 * GRID[0] * GRID[1], dtype=torch.uint8, device=DEV)
+        occ[(c[:, 0] * GRID[1] + c[:, 2]) * GRID[0] + c[:, 3]] = 1
+        assert torch.equal(state, occ), step

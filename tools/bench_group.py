@@ -26,6 +26,8 @@ def run(name, cfg, frames, iters=50):
     synthetic_weights.load_synthetic(model, seed=0)
     model = model.to(DEV).eval()
     b = batch_of(frames)
+    if "--dense-clear" not in sys.argv:
+        b.update(model.persistent_canvases(b))     # the canvases stay ours: only the previous frame's cells are cleared
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side), torch.no_grad():
