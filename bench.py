@@ -317,7 +317,7 @@ def main():
         traffic = json.load(open(tpath))
     # per-kernel averages of the committed rocprofv3 --kernel-trace --stats run of this command (serial frame graph): the group
     # above is timed live; its members, and the one bandwidth-bound kernel among them, are quoted from the profile
-    members, scatter = {}, None
+    members = {}
     spath = os.path.join(ROOT, "profiles", "r01_kernel_stats_single_graph.csv")
     if os.path.exists(spath):
         import csv
@@ -325,12 +325,8 @@ def main():
             for k in ("k1_keys", "k2_scan", "k3_fill", "k_vfe", "k_memory_readout"):
                 if k in r["Name"]:
                     members[k] = round(float(r["AverageNs"]) / 1e3, 2)
-        if "k_vfe" in members:
-            canvas = 4 * (128 + 32) * nx * ny
-            scatter = {"kernel": "k_vfe<gather>: hosts the canvas clear (dense canvases written once, zeros included) next to the pillar waves",
-                       "algorithmic_bytes": canvas, "avg_duration_us": members["k_vfe"],
-                       "achieved": round(canvas / members["k_vfe"] / 1e3, 1), "unit": "GB/s",
-                       "frac": round(canvas / members["k_vfe"] / 1e3 / HBM_PEAK_GBPS, 4), "source": "profiles/r01_kernel_stats_single_graph.csv"}
+        # no bandwidth-bound member any more: the canvases are persistent buffers of the graph / pipeline lane and only the
+        # cells the previous frame left behind are cleared (~2.4 MB instead of 47 MB), see `canvas`
     res = {
         "metric": "KITTI frames/sec/GPU (fwd, ~20k pts); VFE+scatter achieved HBM GB/s vs peak",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -355,7 +351,10 @@ def main():
                      "timing": "HIP events around 10 consecutive replays of the captured group, / 10, mean of 5 frames; "
                                "single_replay_between_events_us additionally holds the start-up of one graph launch",
                      "traffic": None if traffic is None else traffic.get("vfe_scatter_group_bytes"),
-                     "member_kernels_avg_us_from_profile": members, "bandwidth_bound_member": scatter},
+                     "member_kernels_avg_us_from_profile": members,
+                     "canvas": "persistent canvases + occupancy state (hvpr_encode_fwd_f32 canvas_state): the dense result is the same, "
+                               "but only stale cells are cleared — `traffic` (PMC) is therefore BELOW the algorithmic bytes, which still "
+                               "count the dense canvases written once; dense-clear variant: tools/bench_group.py --dense-clear"},
         "roofline_mfma": {"kernel": "BEV backbone + head convolutions (hvpr_conv2d_nhwc_f32, v_mfma_f32_32x32x2_f32)",
                           "bound": "mfma", "achieved": round(flops / (stage[1] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": round(flops / (stage[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
