@@ -348,7 +348,8 @@ def main():
                      "frac": round(group_bytes / group_s / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": group_bytes,
                      "avg_duration_us": round(group_s * 1e6, 2),
                      "single_replay_between_events_us": round(float(stage[0]) * 1e3, 2),
-                     "timing": "HIP events around 10 consecutive replays of the captured group, / 10, mean of 5 frames; "
+                     "timing": "HIP events around 10 consecutive replays of the captured group, / 10, mean of 5 frames (the replays of one "
+                               "repetition see the same frame: no stale canvas cells to clear; a new frame adds ~2.4 MB of zeros); "
                                "single_replay_between_events_us additionally holds the start-up of one graph launch",
                      "traffic": None if traffic is None else traffic.get("vfe_scatter_group_bytes"),
                      "member_kernels_avg_us_from_profile": members,
