@@ -36,6 +36,16 @@ __device__ __forceinline__ unsigned wave_kth_largest_u32(unsigned key, int k) {
     }
     return prefix;
 }
+// the same on the 16 most significant bits only: a LOWER bound of the k-th largest key, for half the steps
+__device__ __forceinline__ unsigned wave_kth_largest_hi16(unsigned key, int k) {
+    unsigned prefix = 0u;
+#pragma unroll
+    for (int bit = 31; bit >= 16; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        if (__popcll(__ballot(key >= cand)) >= k) prefix = cand;
+    }
+    return prefix;
+}
 __device__ __forceinline__ unsigned long long wave_kth_largest_u64(unsigned long long key, int k) {
     unsigned long long prefix = 0ull;
 #pragma unroll
@@ -180,8 +190,9 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         float lmax = -INFINITY;
 #pragma unroll
         for (int t = 0; t < kItemsPad / 64; ++t) { v[t] = row[lane + 64 * t]; lmax = fmaxf(lmax, v[t]); }
-        // tau = k-th largest of the 64 lane maxima: a lower bound of the k-th largest logit
-        const unsigned tau_bits = wave_kth_largest_u32(ord_bits(lmax), k);
+        // tau <= k-th largest of the 64 lane maxima (its 16 leading bits: half the ballot steps, a handful of extra
+        // candidates): a lower bound of the k-th largest logit
+        const unsigned tau_bits = wave_kth_largest_hi16(ord_bits(lmax), k);
         const unsigned tb = (tau_bits & 0x80000000u) ? (tau_bits & 0x7fffffffu) : ~tau_bits;
         const float tau = __uint_as_float(tb);                    // > -inf whenever at least k lanes hold a finite logit
         // candidates (>= tau) per lane as a bit mask (float compares only), then compacted rank by rank: rank r of every
@@ -251,15 +262,10 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         const unsigned ub = (unsigned)(key >> 32);
         const float logit = sel ? __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub) : -INFINITY;
         const int idx = sel ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0;
-        // softmax over the selected logits, every lane redundantly from readlane broadcasts (no LDS round trips)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 32; ++r) mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(logit), r)));
+        // softmax over the selected logits: two DPP wave reductions (lanes past the selection carry -inf / 0)
+        const float mx = hvpr_reduce_max<64>(logit);
         const float e = sel ? __expf(logit - mx) : 0.f;
-        float esum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 32; ++r) esum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), r));
-        const float a = e / esum;
+        const float a = e / hvpr_reduce_sum<64>(e);
         if (topk_idx && lane < k) topk_idx[(size_t)(p0 + p) * k + lane] = idx;
         long long cell = -1;           // fused a3+a4: this pillar's BEV cell (pointpillar_scatter.py:192, nz == 1)
         if (cell_map || canvas) {
@@ -268,14 +274,15 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                 cell = ((long long)c.x * ny + c.z) * nx + c.w;
             if (cell_map && lane == 0 && cell >= 0) cell_map[cell] = p0 + p;   // gather-form scatter: k_cell_map's job
         }
-        // lane = channel.  All 32 candidate rows are requested before the first is used (lanes >= k carry weight 0 and
-        // row 0), so the gather costs one L2 round trip instead of k dependent ones.
+        // lane = channel.  All k selected rows are requested before the first is used, so the gather costs one L2 round
+        // trip instead of k dependent ones (row-major copy of the bank: 256 B per row).
         float rows[32];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(idx, r) * kC + lane];   // row-major copy: 256 B per row
+        for (int r = 0; r < 32; ++r) rows[r] = r < k ? bank[(size_t)__builtin_amdgcn_readlane(idx, r) * kC + lane] : 0.f;
         float acc = 0.f;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), r)), rows[r], acc);
+        for (int r = 0; r < 32; ++r)
+            if (r < k) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), r)), rows[r], acc);
         out[(size_t)(p0 + p) * kC + lane] = acc;
         // fused encode path: the memory channels of this pillar's cell, straight into the pre-cleared NHWC canvas
         if (canvas && cell >= 0) canvas[(size_t)cell * canvas_channels + canvas_offset + lane] = acc;
