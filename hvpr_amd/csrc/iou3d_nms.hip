@@ -407,7 +407,9 @@ __global__ void __launch_bounds__(kRingThreads) k_nms_sweep_ring(const unsigned 
             const int r = i / (kRingWords / 2), c = i % (kRingWords / 2);
             const int row = ph * kPhaseRows + r;
             v[u] = make_ulonglong2(0ull, 0ull);
-            if (i < kPieces && row < n && 2 * c < nb_stride) {
+            // words left of the diagonal block are zero (lower triangle) and never looked at again: not fetched — half the
+            // bytes this one workgroup has to pull through its CU
+            if (i < kPieces && row < n && 2 * c < nb_stride && 2 * c + 1 >= (row >> 6)) {
                 const unsigned long long *src = mask + (size_t)row * nb_stride + 2 * c;
                 if (!(nb_stride & 1)) v[u] = *(const ulonglong2 *)src;            // even stride: 16-byte aligned, both words exist
                 else { v[u].x = src[0]; if (2 * c + 1 < nb_stride) v[u].y = src[1]; }
