@@ -377,3 +377,24 @@ def test_encode_fused_persistent_canvases_sparse_clear():
         occ = torch.zeros(2 * GRID[0] * GRID[1], dtype=torch.uint8, device=DEV)
         occ[(c[:, 0] * GRID[1] + c[:, 2]) * GRID[0] + c[:, 3]] = 1
         assert torch.equal(state, occ), step
+
+
+@pytest.mark.parametrize("P", [5, 20, 32])
+def test_encode_fused_stress_shapes(P):
+    """Odd sizes around the scan-tile and wave boundaries, very dense cells (> 512 points: the chunked-selection fallback of the
+    fused gather), few points per voxel allowed (P < 32), several frames, both cap modes — fused == the three calls, and the
+    voxelizer == the oracle."""
+    rng = np.random.default_rng(100 + P)
+    base = synthetic.hvpr_frame(7)
+    for n_pts in (1, 63, 64, 65, 511, 512, 513, 1025, 6000):
+        f0 = base[:n_pts].copy()
+        _encode_both([f0], 40000, P=P)
+        _check_voxelize([f0], P, 40000)
+    heavy = base[:9000].copy()                                   # 700 points in one cell, 3000 in another, the rest spread
+    heavy[:700, 0] = 20.0 + 0.1 * rng.random(700).astype(np.float32); heavy[:700, 1] = 1.0
+    heavy[700:3700, 0] = 30.0 + 0.1 * rng.random(3000).astype(np.float32); heavy[700:3700, 1] = -3.0
+    rng.shuffle(heavy)
+    for cap_mode in (0, 1):
+        _encode_both([heavy, base[:100], heavy[::-1].copy()], 500, cap_mode=cap_mode, P=P)
+        _encode_both([heavy], 40000, cap_mode=cap_mode, P=P)
+    _check_voxelize([heavy, base[:100]], P, 40000)
