@@ -62,6 +62,12 @@ struct ConvArgs {
     int tiles_x, tiles_y, n_ct;
 };
 
+#ifdef HVPR_EXP_TIMING
+// kernel experiments: cycle stamps of the phases of every chunk of the SECOND tile of a few workgroups (all four waves), read
+// back by hvpr_exp_conv_dbg: [block slot 0..7][wave][chunk 0..63][4] = wait start, barrier exit, DMA issued, multiply done
+__device__ long long g_conv_dbg[8 * 4 * 64 * 4];
+#endif
+
 template <int TH, int TW, int BN, int S, int TAPS>
 __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     constexpr int BM = TH * TW;
@@ -140,6 +146,10 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     // the SAME xcd: they run at the same time on the same L2 and the input patch is fetched from HBM once, not n_ct times.
     const int n_pt = a.tiles_x * a.tiles_y * a.N;
     const int total_walk = ((n_pt + 7) / 8) * 8 * a.n_ct;
+#ifdef HVPR_EXP_TIMING
+    int dbg_tile = 0;
+    const int dbg_slot = (blockIdx.x % 97 == 5 && blockIdx.x / 97 < 8) ? (int)(blockIdx.x / 97) : -1;
+#endif
     for (int it = blockIdx.x; it < total_walk; it += gridDim.x) {
     const int xcd = it & 7, j = it >> 3;
     const int ct = j % a.n_ct;
@@ -198,9 +208,18 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
         constexpr int BUF = decltype(buf_tag)::value;
         // chunk c has landed: this wave's DMA is waited for by hand, the barrier covers the other waves' and also
         // says that every wave is done reading the other stage
+#ifdef HVPR_EXP_TIMING
+        const long long q0 = __builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef HVPR_EXP_TIMING
+        const long long q1 = __builtin_readcyclecounter();
+#endif
         if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
+#ifdef HVPR_EXP_TIMING
+        const long long q2 = __builtin_readcyclecounter();
+#endif
         const float4 *sp = s_patch[BUF];
         const float4 *sw = s_w[BUF];
         // operand ring: LDS reads run PF taps ahead of the MFMAs that consume them (a dependent-accumulator
@@ -232,6 +251,13 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef HVPR_EXP_TIMING
+        if (dbg_slot >= 0 && dbg_tile == 1 && lane == 0 && c < 64) {
+            asm volatile("" ::"v"(acc[0][0][0]));
+            long long *d = g_conv_dbg + (((size_t)dbg_slot * 4 + wid) * 64 + c) * 4;
+            d[0] = q0; d[1] = q1; d[2] = q2; d[3] = __builtin_readcyclecounter();
+        }
+#endif
     };
     stage(0, 0);
     for (int c = 0; c + 1 < n_chunks; c += 2) {        // straight-line body: no accumulator shuffling at a join
@@ -273,6 +299,9 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
         }
     }
     __syncthreads();   // the next tile re-zeroes and refills the LDS stages
+#ifdef HVPR_EXP_TIMING
+    ++dbg_tile;
+#endif
     }
 }
 
@@ -298,6 +327,12 @@ int launch(ConvArgs a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef HVPR_EXP_TIMING
+extern "C" int hvpr_exp_conv_dbg(long long *host_out, int n_words) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_dbg), sizeof(long long) * n_words) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int hvpr_conv2d_nhwc_f32(const float *in, int N, int H, int W, int Cin, const float *w_packed,
                                     const float *bias, int taps, int stride, int cout, int cout_pad, int up,
