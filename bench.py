@@ -360,7 +360,9 @@ def main():
                           "bound": "mfma", "achieved": round(flops / (stage[1] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": round(flops / (stage[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                           "algorithmic_flops": flops, "avg_duration_us": round(float(stage[1]) * 1e3, 1),
-                          "traffic": None if traffic is None else traffic.get("conv_stack_bytes")},
+                          "traffic": None if traffic is None else traffic.get("conv_stack_bytes"),
+                          "note": "peak = 157.3 TFLOP/s at 2.4 GHz; under this load the shader clock measured 2.02 GHz (s_memtime vs "
+                                  "s_memrealtime inside the kernel, DESIGN.md §4.2), i.e. ~132 TFLOP/s attainable"},
     }
     res["alt_precision"] = alt
     if world == 1 and not args.no_cpu_baseline:
