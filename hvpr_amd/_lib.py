@@ -51,6 +51,7 @@ SIGNATURES = {
     "hvpr_point_flags_f32": (_I, [_P, _I, _I, _I, _P, _F, _P, _P, _I, _I, _P, _P]),
     "hvpr_compact_workspace_bytes": (_Z, [_I]),
     "hvpr_compact_rows_f32": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
+    "hvpr_frame_offsets_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "hvpr_gather_rows_f32": (_I, [_P, _I, _I, _P, _I, _P, _P]),
     "hvpr_conv2d_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
 }

@@ -113,6 +113,17 @@ __global__ void __launch_bounds__(256) k_gather_rows(const float *__restrict__ s
     dst[t] = (s >= 0 && s < n_src) ? src[(size_t)s * row + j] : 0.f;
 }
 
+// frame_offsets of a collated point array (dataset.py:161-166: frames contiguous, ascending batch index in column 0):
+// offsets[b] = first row of frame b, offsets[batch] = n.  One launch instead of searchsorted + arange + casts.
+__global__ void __launch_bounds__(256) k_frame_offsets(const float *__restrict__ pts, int n, int stride, int batch,
+                                                       int *__restrict__ offsets) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const int b_here = i < n ? min(max((int)pts[(size_t)i * stride], 0), batch) : batch;   // row n acts as "frame batch"
+    const int b_prev = i > 0 ? min(max((int)pts[(size_t)(i - 1) * stride], 0), batch) : -1;
+    for (int b = b_prev + 1; b <= b_here; ++b) offsets[b] = i;    // empty frames in between start here as well
+}
+
 }  // namespace
 
 extern "C" int hvpr_point_flags_f32(const float *points, int n, int stride, int mode, const float *range_xy, float near_thresh,
@@ -168,6 +179,15 @@ extern "C" int hvpr_gather_rows_f32(const float *src, int n_src, int row_floats,
     if (!src || !idx || !dst) return HVPR_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_gather_rows, dim3(hvpr_cdiv((long long)m * row_floats, 256)), dim3(256), 0, (hipStream_t)stream, src, n_src,
                        row_floats, idx, m, dst);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_frame_offsets_f32(const float *points, int n_points, int point_stride, int batch, int32_t *frame_offsets,
+                                      hvpr_stream_t stream) {
+    if ((!points && n_points > 0) || !frame_offsets || n_points < 0 || point_stride < 1 || batch < 1) return HVPR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_frame_offsets, dim3(hvpr_cdiv(n_points + 1, 256)), dim3(256), 0, (hipStream_t)stream, points, n_points,
+                       point_stride, batch, frame_offsets);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }

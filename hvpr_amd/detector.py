@@ -255,7 +255,10 @@ class _VoxelizingDetector(Detector3DTemplate):
         offs = batch_dict.get("point_frame_offsets")
         if offs is None:   # frames are contiguous and ordered (dataset.py:161-166); count per frame on device
             pts, B = batch_dict["points"], batch_dict["batch_size"]
-            offs = torch.searchsorted(pts[:, 0].contiguous(), torch.arange(B + 1, device=pts.device, dtype=pts.dtype)).to(torch.int32)
+            if pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous():
+                offs = kernels.frame_offsets(pts, B)
+            else:
+                offs = torch.searchsorted(pts[:, 0].contiguous(), torch.arange(B + 1, device=pts.device, dtype=pts.dtype)).to(torch.int32)
         return offs
 
     def voxelize_on_device(self, batch_dict):

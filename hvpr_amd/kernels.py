@@ -276,6 +276,14 @@ def memory_scatter_fwd(pillar, scale, coords, bank, k, batch, nx, ny, workspace,
     return mem, spatial.permute(0, 3, 1, 2), spatial_scale.permute(0, 3, 1, 2)
 
 
+def frame_offsets(points, batch):
+    """(batch+1,) i32 frame offsets of a collated (N, C) point tensor whose column 0 is the batch index (one launch)."""
+    offs = torch.empty((batch + 1,), dtype=torch.int32, device=points.device)
+    check(lib().hvpr_frame_offsets_f32(_ptr(points, torch.float32, "points"), points.shape[0], points.shape[1], int(batch),
+                                       offs.data_ptr(), _stream()), "hvpr_frame_offsets_f32")
+    return offs
+
+
 def encode_fwd(points, frame_offsets, batch, point_cloud_range, voxel_size, grid, max_points, max_voxels, workspace, folded,
                offsets, bank, k, xyz_col=0, cap_mode=0, capacity=None, want_voxels=True, want_mask=True, out=None, state=None):
     """a1..a4 fused (hvpr_encode_fwd_f32): raw points -> canvases in five launches, bit-identical to voxelize ->

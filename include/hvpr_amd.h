@@ -293,6 +293,10 @@ int hvpr_compact_rows_f32(const float *src, int n, int row_floats, const uint8_t
                           int32_t *count, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
 int hvpr_gather_rows_f32(const float *src, int n_src, int row_floats, const int32_t *idx, int m, float *dst,
                          hvpr_stream_t stream);
+/* frame_offsets [batch+1] i32 of a collated point array (dataset.py:161-166: column 0 = batch index, frames contiguous and
+ * ascending): offsets[b] = first row of frame b (empty frames included), offsets[batch] = n_points. */
+int hvpr_frame_offsets_f32(const float *points, int n_points, int point_stride, int batch, int32_t *frame_offsets,
+                           hvpr_stream_t stream);
 
 #ifdef __cplusplus
 }

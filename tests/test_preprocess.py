@@ -108,3 +108,16 @@ def test_input_pipeline_double_buffered_upload():
         np.testing.assert_array_equal(got.cpu().numpy(), want)
         assert bd["batch_size"] == len(frames)
         np.testing.assert_array_equal(bd["point_frame_offsets"].cpu().numpy(), np.cumsum([0] + [len(f) for f in frames]))
+
+
+@pytest.mark.gpu
+def test_frame_offsets_kernel_matches_searchsorted():
+    import torch
+    from hvpr_amd import kernels
+    rng = np.random.default_rng(3)
+    for counts in ([5, 0, 7, 3], [0, 0, 4], [9], [0], [3, 0, 0], [1000, 1, 0, 2500, 0]):
+        B = len(counts)
+        rows = [np.concatenate([np.full((c, 1), b, np.float32), rng.normal(size=(c, 4)).astype(np.float32)], 1) for b, c in enumerate(counts)]
+        pts = torch.from_numpy(np.concatenate(rows, 0) if sum(counts) else np.zeros((0, 5), np.float32)).cuda()
+        got = kernels.frame_offsets(pts, B).cpu().numpy()
+        np.testing.assert_array_equal(got, np.cumsum([0] + counts))
