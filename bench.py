@@ -167,7 +167,18 @@ def main():
     ap.add_argument("--cls-bias", type=float, default=-4.59511985013459, help="conv_cls.bias of the synthetic weights")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: this process becomes the launcher — N fresh child processes, one rank per GPU (reference:
+        # tools/train.py:61-70 / common_utils.py:141-154).  Nothing here has touched the GPU (device_count() does not).
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
+        sys.exit(distributed.launch_local(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank, local_rank, world = distributed.env_rank()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if torch.cuda.device_count() < max(world, 1):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -190,6 +201,8 @@ def main():
     n_pts = len(frames[0])
     nx, ny = int(ds.grid_size[0]), int(ds.grid_size[1])
 
+    dt_local = [0.0]          # this rank's own time of the last timed() call
+
     def barrier():
         distributed.barrier(device)
 
@@ -202,7 +215,8 @@ def main():
         for i in range(args.steps):
             step(batches[(args.warmup + i) % N_POOL])
         barrier()
-        return distributed.max_over_ranks(time.perf_counter() - t0, device)
+        dt_local[0] = time.perf_counter() - t0
+        return distributed.max_over_ranks(dt_local[0], device)
 
     alt = None
     with torch.no_grad():
@@ -225,6 +239,7 @@ def main():
                 mode = "3-stage frame pipeline: one hipGraph replay per step = encode(k) | convolutions(k-1) | top-k+NMS(k-2) " \
                        "on three HIP streams (frame latency = 3 steps)"
 
+        dt_rank = dt_local[0]      # this rank's own time of the headline run (`dt` is the max over ranks)
         if not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32" and not args.skip_single:
             # reported next to the headline, never as `value`: the same pipeline with the trunk/SFM 3x3 convolutions on the bf16
             # matrix cores with split operands
@@ -300,6 +315,8 @@ def main():
             group_us = tot / reps
         kept = int(out[0][0]["pred_count"].item()) if args.probe_steps > 0 else -1
 
+    rccl_ranks = distributed.ranks_seen(device)                       # all-reduce of ones over RCCL
+    per_rank_fps = [round(args.steps / t, 2) for t in distributed.gather_floats(dt_rank, device)]
     if rank != 0:
         distributed.finalize()
         return
@@ -332,6 +349,7 @@ def main():
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rccl_ranks_seen": rccl_ranks, "per_rank_frames_per_s": per_rank_fps,
         "config": {"workload": "hvpr_car.yaml batch=1 forward-only, a1..a8 (on-GPU voxelize, pillar VFE, memory read-out + "
                                "scatter, BEV backbone, head + decode, score top-k + rotated-BEV NMS); frames sharded "
                                "over ranks, replicas only",

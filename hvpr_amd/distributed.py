@@ -3,6 +3,9 @@
 for the start/stop barriers, the max-over-ranks time and the host-side merge of results (reference: pickle files + two
 barriers, pcdet/utils/common_utils.py:174-195).  Backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU."""
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -20,6 +23,69 @@ def init(backend=None, device=None):
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def launch_local(n_ranks, argv, env=None, timeout=None):
+    """Start `n_ranks` fresh child processes `python argv...`, one per GPU of this node, each with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set (reference launcher: tools/train.py:61-70,
+    pcdet/utils/common_utils.py:141-154 — one process per GPU, tcp://127.0.0.1 rendezvous).  The caller must not have
+    touched the GPU: children are started with subprocess (fork + exec of a new interpreter), never by re-exec'ing a
+    process that initialised HIP.  Returns the largest exit code (0 = every rank succeeded); when one rank fails the others
+    are terminated."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    procs = []
+    for r in range(n_ranks):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    rc = 0
+    try:
+        pending = list(procs)
+        import time
+        t_end = None if timeout is None else time.time() + timeout
+        while pending:
+            for p in list(pending):
+                c = p.poll()
+                if c is not None:
+                    pending.remove(p)
+                    rc = max(rc, abs(c))
+                    if c != 0:                    # one rank died: the others would wait in a collective forever
+                        for q in pending:
+                            q.terminate()
+            if t_end is not None and time.time() > t_end:
+                for q in pending:
+                    q.terminate()
+                rc = max(rc, 124)
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def ranks_seen(device):
+    """Number of ranks that take part in the process group's collectives: an all-reduce (sum) of ones — RCCL on the GPU."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def gather_floats(value, device):
+    """The python float of every rank, in rank order, on every rank."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def shard_frames(n_frames, rank, world):

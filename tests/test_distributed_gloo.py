@@ -134,3 +134,35 @@ def test_ddp_gradients_are_the_rank_mean():
     got = sorted(q.get(timeout=10) for _ in procs)
     for rank, n, worst in got:
         assert n > 20 and worst < 1e-4, (rank, n, worst)
+
+
+# ------------------------------------------------------------------------------------------------ the --gpus N launcher
+def test_launch_local_two_ranks(tmp_path):
+    """distributed.launch_local — what `bench.py --gpus N` / `tools/bench_train.py --gpus N` call when WORLD_SIZE is unset:
+    N fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, a collective sees all of them, exit code 0."""
+    import json
+    from hvpr_amd import distributed
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_launch_worker.py")
+    rc = distributed.launch_local(2, [worker, str(tmp_path), "ok"], timeout=240)
+    assert rc == 0
+    got = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r, g in enumerate(got):
+        assert (g["rank"], g["local_rank"], g["world"], g["seen"], g["master"]) == (r, r, 2, 2, "127.0.0.1")
+        assert g["times"] == [10.0, 11.0] and g["slowest"] == 11.0
+
+
+def test_launch_local_propagates_a_failing_rank(tmp_path):
+    from hvpr_amd import distributed
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_launch_worker.py")
+    assert distributed.launch_local(2, [worker, str(tmp_path), "fail"], timeout=240) != 0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` must fail loudly when fewer than N GPUs are visible (this box has none), not run one rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for script in ("bench.py", os.path.join("tools", "bench_train.py")):
+        p = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout), (script, p.stderr[-500:])

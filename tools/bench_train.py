@@ -40,6 +40,7 @@ def make_batch(seed0, B, device, rng, n_class=1):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks of this node; without WORLD_SIZE in the env this process launches them")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -47,7 +48,13 @@ def main():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: MIOpen searches its convolution solvers once per shape")
     ap.add_argument("--channels-last", action="store_true", help="backbone + head weights in channels_last memory format")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # launcher: one fresh child per GPU (tools/train.py:61-70)
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench_train.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        sys.exit(distributed.launch_local(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank, local_rank, world = distributed.env_rank()
+    if torch.cuda.device_count() < max(world, args.gpus):
+        raise SystemExit(f"bench_train.py: {max(world, args.gpus)} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench_train.py needs an MI355X")
     torch.cuda.set_device(local_rank)
@@ -79,9 +86,10 @@ def main():
     distributed.barrier(device)
     torch.cuda.synchronize()
     dt = distributed.max_over_ranks(time.perf_counter() - t0, device)
+    seen = distributed.ranks_seen(device)
     if rank == 0:
         print(json.dumps({"metric": "hvpr_car training steps/s (fwd+bwd+Adam-onecycle)", "value": round(args.steps / dt, 3),
-                          "unit": "steps/s", "frames_per_s": round(world * args.batch * args.steps / dt, 2), "n_gpus": world,
+                          "unit": "steps/s", "frames_per_s": round(world * args.batch * args.steps / dt, 2), "n_gpus": world, "rccl_ranks_seen": seen,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 1),
                           "dtype": "f32", "data": "synthetic", "scaling": "weak",
                           "config": {"workload": f"hvpr_{args.cfg}.yaml full train step a1..a15, batch={args.batch}/GPU, 8 GT boxes/frame",
