@@ -13,9 +13,15 @@
  *               tools/vis.py:9-60 (fp32 floor((p-lo)/vs) :37, bounds test
  *               :38-40, reversed zyx coordinate :41, first-touch map :44-50,
  *               `break` at max_voxels :47-48).
- * PARITY UNPINNED: the reference holds no test, fixture or golden vector for
- * this function, and spconv is not installed here; this file restates the
- * published sequential algorithm.
+ * PINNED (voxel index part) by fixture G13, tests/golden/g13_voxel_index.npz =
+ * the reference's own tools/vis.py:9-60 executed as plain Python by
+ * tests/golden/make_golden.py (numba.jit -> identity): cell -> voxel-id order,
+ * the range-border tests, the V1 stop at max_voxels and the per-voxel point
+ * counts are checked in tests/test_oracle_golden.py (this file, mode 1) and on
+ * the GPU in tests/test_gpu_stage1.py.  NOT pinned by any reference-held
+ * vector (spconv is absent): the V2 `continue` at the
+ * cap and the order of the <= max_points points stored inside a voxel — both
+ * restated from the published spconv algorithm.
  */
 #include <math.h>
 #include <stdint.h>

@@ -564,6 +564,60 @@ def g12_kitti_eval(R):
     print("g12 ok:", {k: round(float(ret[k]), 3) for k in keys if "moderate" in k and "3d" in k})
 
 
+def g13_voxel_index(R):
+    """Voxel-id order + cap semantics through the reference's in-tree copy of the voxel index loop, tools/vis.py:9-60
+    (`_points_to_bevmap_reverse_kernel` + its caller `points_to_bev` :63-107), executed as plain Python: numba.jit -> identity;
+    only the top of the file is executed (imports of cv2 / matplotlib / the broken pcdet packages dropped, everything from
+    `point_to_vis_bev` on — drawing helpers, the demo main — is not needed).  The loop is structurally identical to spconv's
+    `points_to_voxel` (absent): fp32 floor((p - lo) / vs) :37, per-axis bounds test :38-40, zyx coordinate :41, first-touch
+    `coor_to_voxelidx` map :44-50, `break` at max_voxels :47-48.  Saved per case: the points, and for every cell the loop
+    opened its (z, y, x), its voxel id and the number of points the loop counted into it (bev_map[-1], :51)."""
+    def jit(*a, **k):
+        return a[0] if (len(a) == 1 and callable(a[0]) and not k) else (lambda f: f)
+    nb = _stub("numba"); nb.jit = jit; nb.prange = range
+
+    def head_only(src):
+        lines = src.split("\n")
+        stop = next(i for i, l in enumerate(lines) if l.startswith("def point_to_vis_bev"))
+        keep = [l for l in lines[:stop] if not (l.startswith("import cv2") or l.startswith("import matplotlib") or l.startswith("from pcdet"))]
+        return "\n".join(keep)
+    vis = _load("hvpr_ref_tools_vis", "tools/vis.py", head_only)
+    captured = {}
+    kernel = vis._points_to_bevmap_reverse_kernel
+
+    def spy(points, voxel_size, coors_range, coor_to_voxelidx, bev_map, height_lowers, with_reflectivity, max_voxels):
+        kernel(points, voxel_size, coors_range, coor_to_voxelidx, bev_map, height_lowers, with_reflectivity, max_voxels)
+        captured["map"], captured["bev"] = coor_to_voxelidx, bev_map
+    vis._points_to_bevmap_reverse_kernel = spy
+    rng = [0.0, -19.84, -2.5, 47.36, 19.84, 0.5]
+    vs = [0.16, 0.16, 3.0]
+    gen = np.random.default_rng(1313)
+    out = {"range": np.array(rng, np.float32), "voxel_size": np.array(vs, np.float32)}
+    for tag, n, max_voxels, spread in (("nocap", 4000, 40000, 1.0), ("cap", 4000, 700, 1.0), ("dense", 4000, 40000, 0.04), ("densecap", 4000, 40, 0.04), ("cap1", 300, 1, 1.0)):
+        pts = np.empty((n, 4), np.float32)
+        pts[:, 0] = gen.uniform(-1.0, 48.5, n) * spread + (10.0 if spread < 1 else 0.0)
+        pts[:, 1] = gen.uniform(-21.0, 21.0, n) * spread
+        pts[:, 2] = gen.uniform(-3.2, 1.0, n)
+        pts[:, 3] = gen.uniform(0, 1, n)
+        # exact borders: x == hi (dropped), x == lo (kept), y == +-hi, z == lo / hi, cell edges k * 0.16
+        pts[:8, 0] = [47.36, 0.0, 47.359997, 0.16, 0.32, 0.48, 12.8, 25.6]
+        pts[8:12, 1] = [-19.84, 19.84, 19.839998, 0.0]
+        pts[12:14, 2] = [-2.5, 0.5]
+        gen.shuffle(pts, axis=0)
+        vis.points_to_bev(pts, vs, rng, max_voxels=max_voxels)
+        cmap, bev = captured["map"], captured["bev"]
+        z, y, x = np.nonzero(cmap >= 0)
+        ids = cmap[z, y, x]
+        order = np.argsort(ids)
+        assert (ids[order] == np.arange(len(ids))).all()
+        out[tag + "_points"] = pts
+        out[tag + "_max_voxels"] = np.int32(max_voxels)
+        out[tag + "_cells_zyx"] = np.stack([z, y, x], 1)[order].astype(np.int32)          # row v = cell of voxel id v
+        out[tag + "_counts"] = bev[-1][y, x][order].astype(np.int32)                        # points the loop put into voxel v
+        print("g13", tag, "voxels", len(ids), "max count", int(out[tag + "_counts"].max()))
+    np.savez_compressed(os.path.join(OUT, "g13_voxel_index.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     R = load_reference()
@@ -577,6 +631,7 @@ if __name__ == "__main__":
     g10_train_memory(R)
     g11_preprocess(R)
     g12_kitti_eval(R)
+    g13_voxel_index(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")

@@ -117,6 +117,25 @@ def test_voxelize_dense_nuscenes_scale():
         np.testing.assert_array_equal(v[sl], rv)
 
 
+def test_voxelize_matches_reference_loop_fixture_g13(golden_dir):
+    """hvpr_voxelize_f32(cap_mode=1) against fixture G13 — the reference's own in-tree voxel index loop (tools/vis.py:9-60,
+    executed as plain Python by tests/golden/make_golden.py): cell -> voxel-id order, border handling, the stop point at the
+    cap and the per-voxel counts, bit for bit; also through the fused encode entry point."""
+    z = np.load(os.path.join(golden_dir, "g13_voxel_index.npz"))
+    for tag in ("nocap", "cap", "dense", "densecap", "cap1"):
+        pts, cap = z[tag + "_points"], int(z[tag + "_max_voxels"])
+        cells, counts = z[tag + "_cells_zyx"], z[tag + "_counts"]
+        v, c, n, vo = _gpu_voxelize([pts], 32, cap, cap_mode=1)
+        m = int(vo[-1])
+        assert m == len(cells), (tag, m, len(cells))
+        np.testing.assert_array_equal(c[:m, 1:], cells)
+        np.testing.assert_array_equal(n[:m], np.minimum(counts, 32))
+        if m < cap:      # cap not reached: the V2 (`continue`) build must give the same voxels
+            v2, c2, n2, vo2 = _gpu_voxelize([pts], 32, cap, cap_mode=0)
+            np.testing.assert_array_equal(c2[:m, 1:], cells)
+            np.testing.assert_array_equal(n2[:m], np.minimum(counts, 32))
+
+
 # ---------------------------------------------------------------------------------------------- VFE
 def _fold(lin_w, bn_w, bn_b, mean, var, eps=1e-3):
     s = bn_w / np.sqrt(var + eps)

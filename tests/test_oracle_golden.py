@@ -112,3 +112,25 @@ def test_g6_g7_coder_and_limit_period(golden_dir):
     np.testing.assert_array_equal(O.limit_period(z["lp_val"], 0.0, np.pi).numpy(), z["lp_0_pi"])
     np.testing.assert_array_equal(O.limit_period(z["lp_val"], 0.5, 2 * np.pi).numpy(), z["lp_05_2pi"])
     np.testing.assert_array_equal(O.limit_period(z["lp_val"], 0.0, 2 * np.pi).numpy(), z["lp_0_2pi"])
+
+
+G13_CASES = ("nocap", "cap", "dense", "densecap", "cap1")
+
+
+def test_g13_voxel_index_pins_the_voxelizer_oracle(golden_dir):
+    """Fixture G13 = the reference's in-tree voxel index loop tools/vis.py:9-60 run as plain Python (make_golden.g13_voxel_index):
+    voxel id of every cell (first-touch order), the bounds test at the range borders, the V1 stop (`break`) at max_voxels and the
+    per-voxel point counts.  The C oracle (mode v1) and its python twin must reproduce all of them."""
+    z = _load(golden_dir, "g13_voxel_index.npz")
+    for tag in G13_CASES:
+        pts, cap = z[tag + "_points"], int(z[tag + "_max_voxels"])
+        cells, counts = z[tag + "_cells_zyx"], z[tag + "_counts"]
+        for fn in (O.voxelize, O.voxelize_py) if len(pts) <= 4000 else (O.voxelize,):
+            v, c, n = fn(pts, z["voxel_size"], z["range"], 32, cap, mode="v1")
+            assert len(c) == len(cells), (tag, len(c), len(cells))
+            np.testing.assert_array_equal(c, cells)                        # row v = (z, y, x) of voxel id v
+            np.testing.assert_array_equal(n, np.minimum(counts, 32))
+        if len(cells) < cap:                                               # cap not hit: V2 (`continue`) is the same loop
+            v2, c2, n2 = O.voxelize(pts, z["voxel_size"], z["range"], 32, cap, mode="v2")
+            np.testing.assert_array_equal(c2, cells)
+            np.testing.assert_array_equal(n2, np.minimum(counts, 32))
