@@ -114,3 +114,47 @@ def test_get_score_topk_through_the_readout_kernel_equals_torch_topk():
         # same top-k VALUES in the same (descending) order; indices equal wherever the values are distinct
         np.testing.assert_allclose(logits.gather(1, got).cpu().numpy(), want[0].cpu().numpy(), rtol=1e-5, atol=1e-5)
         assert (got == want[1]).float().mean() > 0.999
+
+
+def test_config3_full_train_step_batch16():
+    """BASELINE.json configs[2]: hvpr_car full train step (a1..a15: on-GPU voxelize, point stream, VFE, get_score + memory
+    train branch, three canvases, two-stream backbone, head, target assigner, losses, backward, clip, Adam-onecycle) at the FULL
+    size — 16 frames of 16384 points per step.  Finite loss, EVERY trainable parameter receives a finite gradient, the step
+    changes the weights, peak memory is recorded (and bounded well below the 288 GB of the part)."""
+    import json
+    import os
+    cfg = hvpr_car_cfg()
+    model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg, training=True))
+    synthetic_weights.load_synthetic(model, seed=3, cls_bias=-4.595)
+    model = model.to(DEV).train()
+    opt = optim.build_optimizer(model, cfg.OPTIMIZATION)
+    sched, _ = optim.build_scheduler(opt, total_iters_each_epoch=10, total_epochs=1, last_epoch=-1, optim_cfg=cfg.OPTIMIZATION)
+    rng = np.random.default_rng(16)
+    batch = _train_batch(list(range(100, 116)), rng)
+    assert batch["batch_size"] == 16 and batch["points"].shape == (16 * 16384, 5)
+    torch.cuda.reset_peak_memory_stats()
+    sched.step(0)
+    opt.zero_grad()
+    ret, tb, _ = model(dict(batch))
+    loss = ret["loss"].mean()
+    assert torch.isfinite(loss)
+    loss.backward()
+    missing = [k for k, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing
+    bad = [k for k, p in model.named_parameters() if p.requires_grad and not torch.isfinite(p.grad).all()]
+    assert not bad, bad
+    nonzero = [k for k, p in model.named_parameters() if p.requires_grad and float(p.grad.abs().max()) > 0]
+    assert len(nonzero) >= 0.95 * sum(1 for p in model.parameters() if p.requires_grad)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+    opt.step()
+    model.update_global_step()
+    assert all(not torch.equal(v, before[k]) for k, v in model.named_parameters() if k in nonzero[:50])
+    loss2, _ = optim.train_step(model, opt, sched, dict(batch), 1, cfg.OPTIMIZATION.GRAD_NORM_CLIP)     # a second whole step
+    assert np.isfinite(float(loss2))
+    peak = torch.cuda.max_memory_allocated() / 2**30
+    print(f"config 3 (batch 16): loss {float(loss):.4f} -> {float(loss2):.4f}, peak memory {peak:.1f} GiB")
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"config": "hvpr_car full train step, batch 16", "loss": [float(loss), float(loss2)], "peak_mem_GiB": round(peak, 1)},
+              open(os.path.join("gpurun_out", "config3_train_step_test.json"), "w"))
+    assert peak < 200.0

@@ -1,101 +1,20 @@
 """CPU: the torch-level training logic of the product (target assigner, losses, Adam-onecycle, train branches of the
-memory / point-pillar attention) against fixtures produced by the reference's own code (tests/golden/make_golden.py G8-G10)."""
-import os
-
-import numpy as np
-import torch
-
-from detparams import det_tensor
-from hvpr_amd import anchor_head, map_to_bev, optim
-from hvpr_amd.config import AttrDict
-
-
-def _load(golden_dir, name):
-    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
-
-
-def _head_cfg():
-    return AttrDict(
-        CLASS_AGNOSTIC=False, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
-        ANCHOR_GENERATOR_CONFIG=[dict(class_name="Car", anchor_sizes=[[3.9, 1.6, 1.56]], anchor_rotations=[0, 1.57],
-                                      anchor_bottom_heights=[-1.78], align_center=False, feature_map_stride=1,
-                                      matched_threshold=0.6, unmatched_threshold=0.45)],
-        TARGET_ASSIGNER_CONFIG=dict(NAME="AxisAlignedTargetAssigner", POS_FRACTION=-1.0, SAMPLE_SIZE=512,
-                                    NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False, BOX_CODER="ResidualCoder"),
-        LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, mem_weight=1.0, code_weights=[1.0] * 7)))
+memory / point-pillar attention) against fixtures produced by the reference's own code (tests/golden/make_golden.py G8-G10).
+The same cases run on cuda:0 in tests/test_gpu_train_fixtures.py."""
+import train_fixture_cases as C
 
 
 def test_g8_target_assignment_and_losses(golden_dir):
-    z = _load(golden_dir, "g8_assigner_losses.npz")
-    head = anchor_head.AnchorHeadSingle(model_cfg=_head_cfg(), input_channels=24, num_class=1, class_names=["Car"],
-                                        grid_size=np.array([int(z["nx"]), int(z["ny"]), 1]), point_cloud_range=z["point_cloud_range"])
-    head.anchors = [a.cpu() for a in head.anchors]
-    head.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")})
-    head.train()
-    head({"spatial_features_2d": torch.from_numpy(z["spatial_features_2d"]),
-          "spatial_features_point_2d": torch.from_numpy(z["spatial_features_point_2d"]),
-          "point_positive_features": torch.from_numpy(z["pos_point"]), "memory_positive_features": torch.from_numpy(z["pos_memory"]),
-          "memory_items": torch.zeros(1), "gt_boxes": torch.from_numpy(z["gt_boxes"]), "batch_size": 2})
-    fr = head.forward_ret_dict
-    ref_labels = z["target.box_cls_labels"]
-    np.testing.assert_array_equal(fr["box_cls_labels"].numpy(), ref_labels)                  # integer labels: exact
-    assert (ref_labels > 0).sum() >= 4 and (ref_labels == -1).sum() > 0                    # the case has positives and don't-cares
-    np.testing.assert_array_equal(fr["reg_weights"].numpy(), z["target.reg_weights"])
-    np.testing.assert_allclose(fr["box_reg_targets"].numpy(), z["target.box_reg_targets"], rtol=1e-5, atol=1e-6)
-    rpn, rpn_pt, mem, tb, _ = head.get_loss()
-    np.testing.assert_allclose(rpn.item(), float(z["rpn_loss"]), rtol=1e-5)
-    np.testing.assert_allclose(rpn_pt.item(), float(z["rpn_loss_point"]), rtol=1e-5)
-    np.testing.assert_allclose(mem.item(), float(z["mem_loss"]), rtol=1e-5)
-    for k in ("rpn_loss_cls", "rpn_loss_loc", "rpn_loss_dir", "rpn_loss_cls_pt", "rpn_loss_loc_pt", "rpn_loss_dir_pt", "mem_loss"):
-        np.testing.assert_allclose(tb[k].item(), float(z["tb." + k]), rtol=1e-5, err_msg=k)
+    C.run_g8(golden_dir)
 
 
 def test_g8_no_ground_truth_is_all_background(golden_dir):
-    z = _load(golden_dir, "g8_assigner_losses.npz")
-    head = anchor_head.AnchorHeadSingle(model_cfg=_head_cfg(), input_channels=24, num_class=1, class_names=["Car"],
-                                        grid_size=np.array([int(z["nx"]), int(z["ny"]), 1]), point_cloud_range=z["point_cloud_range"])
-    head.anchors = [a.cpu() for a in head.anchors]
-    t = head.assign_targets(torch.zeros(1, 3, 8))
-    assert (t["box_cls_labels"] == 0).all() and (t["reg_weights"] == 0).all() and (t["box_reg_targets"] == 0).all()
+    C.run_g8_no_gt(golden_dir)
 
 
 def test_g9_onecycle_schedule_and_true_weight_decay(golden_dir):
-    z = _load(golden_dir, "g9_onecycle.npz")
-    net = torch.nn.Sequential(torch.nn.Linear(6, 5, bias=False), torch.nn.BatchNorm1d(5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
-    net.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("init.")}, strict=False)
-    opt = optim.AdamOneCycle(net, wd=0.01)
-    sched = optim.OneCycle(opt, 100, 0.003, [0.95, 0.85], 10, 0.4)
-    xs = torch.from_numpy(z["x"])
-    lrs, moms = [], []
-    for it in range(100):
-        sched.step(it)
-        lrs.append(opt.lr); moms.append(opt.mom)
-        if it < 3:
-            net.train(); opt.zero_grad()
-            net(xs[it]).pow(2).mean().backward()
-            torch.nn.utils.clip_grad_norm_(net.parameters(), 10)
-            opt.step()
-            for k, v in net.state_dict().items():
-                if "num_batches" not in k:
-                    np.testing.assert_allclose(v.numpy(), z[f"after{it}.{k}"], rtol=2e-5, atol=1e-7, err_msg=f"step {it} {k}")
-    np.testing.assert_allclose(lrs, z["lr"], rtol=1e-12)
-    np.testing.assert_allclose(moms, z["mom"], rtol=1e-12)
+    C.run_g9(golden_dir)
 
 
 def test_g10_point_pillar_attention_and_memory_train_branch(golden_dir):
-    z = _load(golden_dir, "g10_train_memory.npz")
-    cfg = AttrDict(NUM_BEV_FEATURES=128, NUM_COORD_POINTS=3, NUM_PT_FEATURES=64, NUM_SCALE_FEATURES=32, NUM_K=20, NUM_M=2000, SHRINK_TH=0.0025)
-    m = map_to_bev.PointPillarScatter_Agg_Memory_1_scale(cfg, np.array([12, 10, 1]))
-    m.memory.weight.data = torch.from_numpy(det_tensor(str(z["W_name"]), (2000, 64), int(z["W_seed"])))
-    m.train()
-    pillars, points = torch.from_numpy(z["pillars"]), torch.from_numpy(z["points"])
-    agg, positives = m.get_score(points, pillars)
-    np.testing.assert_allclose(agg.detach().numpy(), z["get_score_output"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_array_equal(positives.detach().numpy(), z["positives"])
-    out = m.memory(pillars, 20, positives)
-    np.testing.assert_allclose(out["output"].detach().numpy(), z["memory_output"], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(out["att"].sum(1).detach().numpy(), z["memory_att_rowsum"], rtol=1e-5)
-    np.testing.assert_array_equal((out["att"] > 0).sum(1).numpy(), z["memory_att_nnz"])
-    # gradients flow to the bank through the read-out and to the pillars through the point stream weights only via detach rules
-    out["output"].sum().backward()
-    assert m.memory.weight.grad is not None and torch.isfinite(m.memory.weight.grad).all()
+    C.run_g10(golden_dir)
