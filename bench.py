@@ -108,8 +108,10 @@ class StagedGraphs:
                 bd = model.dense_head.forward(bd)
             with torch.cuda.graph(self.graphs[2], pool=pool):
                 self.out = model.post_processing(bd, sync=False)
+        self.captured = detector._CapturedState(model)      # keeps the captured workspaces / packed weights alive
 
     def run(self, batch, ev):
+        self.captured.check()
         for k, v in batch.items():
             if torch.is_tensor(v):
                 self.static_in[k].copy_(v, non_blocking=True)

@@ -27,6 +27,17 @@ struct hvpr_carver {
     }
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: remember it per device (bit d of a
+// per-call-site mask), not once per process.  The call is idempotent, so a lost update only repeats it.
+static inline int hvpr_ensure_dyn_lds(const void *fn, int bytes, unsigned long long *done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64 && ((__atomic_load_n(done_mask, __ATOMIC_RELAXED) >> dev) & 1ull)) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64) __atomic_fetch_or(done_mask, 1ull << dev, __ATOMIC_RELAXED);
+    return 0;
+}
+
 __device__ __forceinline__ int hvpr_lane() { return threadIdx.x & 63; }
 
 // All-lanes reductions over the 64-lane wave or within its 32-lane halves, without the LDS crossbar: two quad permutes, the two

@@ -509,12 +509,8 @@ extern "C" int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_
     hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, s, prepared, n_device, n_max, thresh, mask, nb);
     if (nb <= kRingWords) {
         const size_t lds = (size_t)2 * kRingBlocks * 64 * kRingWords * sizeof(unsigned long long);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)k_nms_sweep_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return HVPR_ERR_LAUNCH;
-            attr_set = true;
-        }
+        static unsigned long long lds_set = 0ull;   // per device
+    if (hvpr_ensure_dyn_lds((const void *)k_nms_sweep_ring, (int)lds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
         hipLaunchKernelGGL(k_nms_sweep_ring, dim3(1), dim3(kRingThreads), lds, s, mask, nb, n_device, n_max, order, map_through_order,
                            max_keep, keep, keep_count);
     } else {

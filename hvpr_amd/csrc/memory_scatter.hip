@@ -379,13 +379,8 @@ int hvpr_i_readout(const float *f, int M, const int32_t *m_device, const float *
     if ((cell_map || canvas) && !coords) return HVPR_ERR_INVALID_ARG;
     if (canvas && canvas_offset + kC > canvas_channels) return HVPR_ERR_INVALID_ARG;
     const size_t lds = (size_t)kPillars * kItemsPad * 4 + kPillars * kC * 4 + (kThreads / 64) * 64 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_memory_readout, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return HVPR_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0ull;   // per device
+    if (hvpr_ensure_dyn_lds((const void *)k_memory_readout, (int)lds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
     hipLaunchKernelGGL(k_memory_readout, dim3(hvpr_cdiv(M, kPillars)), dim3(kThreads), lds, stream, f, M, m_device, bank,
                        bank_packed, n_items, k, out, topk_idx, (const int4 *)coords, batch, nx, ny, cell_map, canvas, canvas_channels,
                        canvas_offset);

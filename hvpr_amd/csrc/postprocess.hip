@@ -431,12 +431,8 @@ extern "C" int hvpr_score_topk_f32(const float *scores, int batch, int n_scores,
         hipLaunchKernelGGL(k_score_compact, dim3(bx, batch), dim3(256), 0, s, scores, n_scores, score_thresh, use_thresh, keys, cnt);
     }
     const size_t lds = (size_t)SORTCAP * 8 + 2048 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_topk_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return HVPR_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned long long lds_set = 0ull;   // per device
+    if (hvpr_ensure_dyn_lds((const void *)k_topk_select, (int)lds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
     hipLaunchKernelGGL(k_rank_count, dim3(SORTCAP / 256, SORTCAP / RK_CHUNK, batch), dim3(256), 0, s, keys, n_scores, cnt, rank);
     hipLaunchKernelGGL(k_rank_place, dim3(SORTCAP / 256, batch), dim3(256), 0, s, keys, n_scores, cnt, rank, pre_max, order,
                        sorted_scores);

@@ -229,13 +229,35 @@ class Detector3DTemplate(nn.Module):
         return len(update), len(state)
 
 
+    def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None):
+        """detector3d_template.py:348-375: resume — strict model load, optimizer state from the same file (or the side file
+        `<name>_optim.<ext>` older checkpoints used).  Returns (it, epoch) like the reference."""
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None)
+        self.load_state_dict(ckpt["model_state"])
+        if optimizer is not None:
+            ost = ckpt.get("optimizer_state")
+            if ost is None:
+                stem, ext = os.path.splitext(filename)
+                side = "%s_optim%s" % (stem, ext)
+                if os.path.exists(side):
+                    ost = torch.load(side, map_location=torch.device("cpu") if to_cpu else None)["optimizer_state"]
+            if ost is not None:
+                optimizer.load_state_dict(ost)
+        if logger is not None:
+            logger.info("==> Resumed from %s (epoch %s, it %s, version %s)" % (filename, ckpt.get("epoch", -1), ckpt.get("it", 0.0),
+                                                                              ckpt.get("version", "none")))
+        return ckpt.get("it", 0.0), ckpt.get("epoch", -1)
+
+
 class _VoxelizingDetector(Detector3DTemplate):
     """Adds the step the north_star moves on-device: when batch_dict carries raw `points` (N,5) [b,x,y,z,r] and no
     `voxels`, voxelize on the GPU (replaces the CPU dataloader step data_processor.py:43-75)."""
 
     def __init__(self, model_cfg, num_class, dataset):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
-        self._voxgen = None
+        self._voxgen = {}            # one generator per mode: MAX_NUMBER_OF_VOXELS differs between train and test
 
     def _voxel_cfg(self):
         for p in self.dataset.dataset_cfg.DATA_PROCESSOR:
@@ -244,11 +266,13 @@ class _VoxelizingDetector(Detector3DTemplate):
         raise KeyError("transform_points_to_voxels")
 
     def _voxel_generator(self, device):
-        if self._voxgen is None:
+        mode = "train" if self.training else "test"
+        key = (mode, torch.device(device))
+        if key not in self._voxgen:
             vc = self._voxel_cfg()
-            self._voxgen = VoxelGenerator(vc.VOXEL_SIZE, self.dataset.point_cloud_range, vc.MAX_POINTS_PER_VOXEL,
-                                          vc.MAX_NUMBER_OF_VOXELS["train" if self.training else "test"], device=device)
-        return self._voxgen
+            self._voxgen[key] = VoxelGenerator(vc.VOXEL_SIZE, self.dataset.point_cloud_range, vc.MAX_POINTS_PER_VOXEL,
+                                               vc.MAX_NUMBER_OF_VOXELS[mode], device=device)
+        return self._voxgen[key]
 
     @staticmethod
     def _frame_offsets(batch_dict):
@@ -361,6 +385,32 @@ class MixAnchor_Memory(_VoxelizingDetector):
         return self.post_processing(batch_dict, sync=sync)
 
 
+class _CapturedState:
+    """What a captured hipGraph bakes in as raw pointers without owning it: folded / packed weights (FoldCache values, the
+    packed memory bank), the post-processing and voxelizer workspaces.  The wrapper (a) keeps a reference to every such object
+    as it was at capture time, so the memory a replay touches can never be freed under it, and (b) refuses to replay once the
+    model has replaced any of them (train()/eval() toggles, load_state_dict, set_conv_precision, a bigger batch elsewhere):
+    the replay would silently use stale weights or a workspace the model no longer looks at."""
+
+    def __init__(self, model):
+        self.slots = []
+        for m in model.modules():
+            if hasattr(m, "_fold") and hasattr(m._fold, "value"):
+                self.slots.append((m._fold, "value"))
+            if hasattr(m, "_packed"):
+                self.slots.append((m, "_packed"))
+        self.slots.append((model, "_post_ws"))
+        for vg in getattr(model, "_voxgen", {}).values():
+            self.slots.append((vg, "_ws"))
+        self.keep = [getattr(o, a) for o, a in self.slots]        # strong references: ids below cannot be recycled
+
+    def check(self):
+        for (o, a), was in zip(self.slots, self.keep):
+            if getattr(o, a) is not was:
+                raise RuntimeError(f"hvpr_amd: {type(o).__name__}.{a} was rebuilt after this hipGraph was captured (train()/eval(), "
+                                   "load_state_dict, set_conv_precision or a workspace re-allocation): capture a new graph")
+
+
 class GraphedForward:
     """Whole-frame hipGraph of the eval forward (voxelize -> ... -> NMS) for a fixed input shape.
 
@@ -386,8 +436,10 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.static_out = model(dict(self.static_in), sync=False)
+        self.captured = _CapturedState(model)
 
     def __call__(self, batch):
+        self.captured.check()
         for k, v in batch.items():
             if torch.is_tensor(v):
                 self.static_in[k].copy_(v, non_blocking=True)
@@ -450,6 +502,7 @@ class PipelinedForward:
                 main.wait_stream(self.s_enc)
                 main.wait_stream(self.s_post)
             pool = self.graphs[p].pool()
+        self.captured = _CapturedState(model)
 
     def _post_dict(self, p):
         d = dict(zip(self._HEAD_KEYS, self.head[p]))
@@ -457,6 +510,7 @@ class PipelinedForward:
         return d
 
     def __call__(self, batch):
+        self.captured.check()
         p = self.step & 1
         for k, v in batch.items():
             if torch.is_tensor(v):

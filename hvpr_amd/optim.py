@@ -88,10 +88,19 @@ class AdamOneCycle:
         self.opt.step()
 
     def state_dict(self):
-        return self.opt.state_dict()
+        """Inner Adam state (step counters + both moments per parameter) plus the wrapper's own scalars, so that a resumed
+        run continues with the same lr / momentum until the scheduler's next step."""
+        sd = self.opt.state_dict()
+        sd["hvpr_onecycle"] = {"lr": self._lr, "mom": self._mom, "wd": self.wd, "beta2": self.beta2}
+        return sd
 
     def load_state_dict(self, sd):
+        sd = dict(sd)
+        extra = sd.pop("hvpr_onecycle", None)
         self.opt.load_state_dict(sd)
+        if extra is not None:
+            self.wd, self.beta2 = float(extra["wd"]), float(extra["beta2"])
+            self.lr, self.mom = extra["lr"], extra["mom"]
 
 
 def build_optimizer(model, optim_cfg):
@@ -102,6 +111,34 @@ def build_optimizer(model, optim_cfg):
 def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch, optim_cfg):
     total = total_iters_each_epoch * total_epochs
     return OneCycle(optimizer, total, optim_cfg.LR, list(optim_cfg.MOMS), optim_cfg.DIV_FACTOR, optim_cfg.PCT_START), None
+
+
+def checkpoint_state(model=None, optimizer=None, epoch=None, it=None):
+    """The dict tools/train_utils/train_utils.py:124-140 writes: {'epoch', 'it', 'model_state', 'optimizer_state', 'version'}.
+    A DDP wrapper is unwrapped (its `.module` holds the reference's key names) and every tensor goes to the CPU, so a file
+    written by one rank loads anywhere."""
+    model_state = None
+    if model is not None:
+        inner = model.module if hasattr(model, "module") else model
+        model_state = type(inner.state_dict())((k, v.detach().cpu()) for k, v in inner.state_dict().items())
+
+    def to_cpu(o):
+        if torch.is_tensor(o):
+            return o.detach().cpu()
+        if isinstance(o, dict):
+            return {k: to_cpu(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(to_cpu(v) for v in o)
+        return o
+    return {"epoch": epoch, "it": it, "model_state": model_state,
+            "optimizer_state": None if optimizer is None else to_cpu(optimizer.state_dict()), "version": "hvpr_amd"}
+
+
+def save_checkpoint(state, filename="checkpoint"):
+    """train_utils.py:143-150: one file `<filename>.pth`."""
+    path = "{}.pth".format(filename)
+    torch.save(state, path)
+    return path
 
 
 def model_fn_decorator():
