@@ -7,26 +7,53 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// a3  memory read-out.  One workgroup = kPillars pillars; the kPillars x n_items logit rows (fp32 MFMA) live in LDS
-// (never in HBM: the reference materialises M x 2000 floats twice).  Selection per pillar (one wave):
-//   lane-local max of the lane's 32 logits -> 64-lane bitonic sort -> tau = k-th largest lane max, a
-//   lower bound of the k-th largest logit -> the expected ~23 logits >= tau are compacted and sorted
-//   (value desc, index asc) -> top k.  More than 64 candidates (mass ties) takes an exact slow path.
-// softmax(f . W[idx]) reuses the selected logits (memory_module.py:70-72 recomputes the same dot products).
+// a3  memory read-out.  One workgroup = kPillars pillars x all n_items (<= 2048) memory items.
+//
+// The top-k of the EXACT fp32 logits is found with a half-precision pre-filter and an exact re-check, so that the matrix
+// cores run at the fp16 rate (16x the fp32 MFMA rate) and the bank streams as 256 KB instead of 512 KB per workgroup:
+//   1. A[p][j] ~ f[p] . bank[j] on v_mfma_f32_16x16x32_f16 (operands rounded to fp16, fp32 accumulate), rows in LDS
+//      (never in HBM: the reference materialises M x 2000 floats twice).
+//   2. Error bound per pillar: |A - L| <= eps_p for every item, L = the exact logit.  fp16 round-to-nearest errs by at most
+//      2^-11 |x| for a normal result and by at most 2^-14 = 6.1e-5 when the result is subnormal (assumed flushed to zero by
+//      the matrix cores: the weaker assumption), so with wmax_c = max_j |W_jc|
+//         eps_p = 1.0e-3 * sum_c |f_c| wmax_c  +  6.2e-5 * (sum_c |f_c| + sum_c wmax_c)  (+ 1e-30)
+//      ((1 + 2^-11)^2 - 1 = 0.00097680; the rest of 1.0e-3 covers the fp32 accumulation of both sides); a value beyond the
+//      fp16 range makes eps_p infinite (everything becomes a candidate: exact slow path).
+//      tau = a lower bound of the k-th largest A (k-th largest of the 64 lane maxima, 16 leading bits).  Every item of the
+//      exact top-k has A >= tau - 2 eps_p:  k items have A >= tau, hence L >= tau - eps, so the k-th largest L is
+//      >= tau - eps, and an item with L >= tau - eps has A >= tau - 2 eps.
+//   3. The ~25 candidates with A >= tau - 2 eps_p get their exact logit: L_j = butterfly-tree sum over the 64 channels of
+//      the fp32 products f_c * W_jc (rows gathered coalesced, lane = channel, and KEPT in registers; 32 candidates reduced
+//      at once by a vector-halving butterfly — the same summation tree as hvpr_reduce_sum<64>).
+//   4. top-k of (L desc, index asc) among the candidates = the exact top-k; softmax over the selected L (memory_module.py:
+//      70-72 recomputes the same dot products); weighted sum of the selected rows straight from the registers of step 3.
+// More than 64 candidates (mass ties, e.g. an all-zero feature row) takes an exact slow path over all items.
 // ------------------------------------------------------------------------------------------------
-constexpr int kC = 64;          // feature channels
-constexpr int kPillars = 16;    // pillars per workgroup
-constexpr int kItemsPad = 2048; // logits row length in LDS
-constexpr int kThreads = 1024;  // 16 waves: one pillar per wave in the selection phase, 4 waves per SIMD hide the bank stream latency
+constexpr int kC = 64;            // feature channels
+constexpr int kPillars = 16;      // pillars per workgroup
+constexpr int kItemsPad = 2048;   // logits row length in LDS
+constexpr int kPitch = kItemsPad + 4;   // row pitch in floats: the 16 pillar rows of one ds_write_b128 land in distinct banks
+constexpr int kThreads = 1024;    // 16 waves: one pillar per wave in the selection phase
+constexpr float kRelErr = 1.0e-3f, kAbsErr = 6.2e-5f, kHalfMax = 65000.f;    // see 2. above
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned ord_bits(float v) {
     const unsigned b = __float_as_uint(v);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+__device__ __forceinline__ float ord_to_float(unsigned ub) {
+    return __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub);
+}
+// fp32 -> fp16 bits, round to nearest even (v_cvt_f16_f32 under the default rounding mode)
+__device__ __forceinline__ unsigned f16_rne(float x) {
+    const _Float16 h = (_Float16)x;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
 
 // k-th largest (k >= 1) of one key per lane: the largest v with count(key >= v) >= k, found bit by bit with ballots —
-// compares and scalar popcounts only, no cross-lane data movement (a 64-lane bitonic sort costs 42 dependent
-// ds_bpermute round trips).  Lanes that do not take part pass key 0.
+// compares and scalar popcounts only, no cross-lane data movement.  Lanes that do not take part pass key 0.
 __device__ __forceinline__ unsigned wave_kth_largest_u32(unsigned key, int k) {
     unsigned prefix = 0u;
 #pragma unroll
@@ -56,34 +83,67 @@ __device__ __forceinline__ unsigned long long wave_kth_largest_u64(unsigned long
     return prefix;
 }
 
-// sort 64 keys descending across the wave
-__device__ __forceinline__ unsigned long long bitonic64_desc_u64(unsigned long long v, int lane) {
+// lane l <-> lane l ^ 4 inside every row of 16: two DPP moves (row_shl:4 into banks 0 and 2, row_shr:4 into banks 1 and 3)
+__device__ __forceinline__ float xchg_xor4(float v) {
+    const int iv = __float_as_int(v);
+    int r = __builtin_amdgcn_update_dpp(0, iv, 0x104, 0xf, 0x5, false);
+    r = __builtin_amdgcn_update_dpp(r, iv, 0x114, 0xf, 0xa, false);
+    return __int_as_float(r);
+}
+
+// Sums over the 64 lanes of 32 vectors at once: on return lane l holds sum_lanes x[l & 31].  A vector-halving butterfly —
+// at lane bit b every lane keeps the half of the vectors whose index has bit b equal to its own lane bit and adds its
+// partner's copy of them — 31 + 1 exchange-adds instead of 32 x 6.  Each level adds the same two numbers the plain
+// butterfly of hvpr_reduce_sum<64> adds (addition is commutative), so the result is bit-identical to 32 separate reductions.
+__device__ __forceinline__ float wave_sum32(float (&x)[32], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8, b4 = lane & 16;
 #pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), j, 64);
-            const unsigned hi = __shfl_xor((unsigned)(v >> 32), j, 64);
-            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-            const bool up = (lane & k) == 0;
-            const bool lower = (lane & j) == 0;
-            v = (lower == up) ? (v > o ? v : o) : (v < o ? v : o);
-        }
+    for (int i = 0; i < 16; ++i) {
+        const float keep = b0 ? x[2 * i + 1] : x[2 * i], send = b0 ? x[2 * i] : x[2 * i + 1];
+        x[i] = keep + hvpr_dpp<0xB1>(send);                       // quad_perm [1,0,3,2]: lane ^ 1
     }
-    return v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b1 ? x[2 * i + 1] : x[2 * i], send = b1 ? x[2 * i] : x[2 * i + 1];
+        x[i] = keep + hvpr_dpp<0x4E>(send);                       // quad_perm [2,3,0,1]: lane ^ 2
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b2 ? x[2 * i + 1] : x[2 * i], send = b2 ? x[2 * i] : x[2 * i + 1];
+        x[i] = keep + xchg_xor4(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b3 ? x[2 * i + 1] : x[2 * i], send = b3 ? x[2 * i] : x[2 * i + 1];
+        x[i] = keep + hvpr_dpp<0x128>(send);                      // row_ror:8: lane ^ 8
+    }
+    {
+        const float keep = b4 ? x[1] : x[0], send = b4 ? x[0] : x[1];
+        // v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second: with the same value
+        // in both, result 0 holds the even row's value and result 1 the odd row's in BOTH rows of a pair — the partner's
+        // (lane ^ 16) value is result 1 for an even-row lane and result 0 for an odd-row lane
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(send), __float_as_uint(send), false, false);
+        x[0] = keep + __uint_as_float(b4 ? r[0] : r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[0]), __float_as_uint(x[0]), false, false);
+        x[0] = __uint_as_float(r[0]) + __uint_as_float(r[1]);     // lane ^ 32
+    }
+    return x[0];
 }
 
 __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__restrict__ f, int M,
                                                              const int *__restrict__ m_device,
                                                              const float *__restrict__ bank,
-                                                             const float *__restrict__ bank_packed, int n_items, int k,
+                                                             const uint4 *__restrict__ bank_bf,
+                                                             const float *__restrict__ wmax, int n_items, int k,
                                                              float *__restrict__ out, int *__restrict__ topk_idx,
                                                              const int4 *__restrict__ coords, int batch, int nx, int ny,
                                                              int *__restrict__ cell_map, float *__restrict__ canvas,
                                                              int canvas_channels, int canvas_offset) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_logit = (float *)smem;                              // [kPillars][kItemsPad]
-    float *s_f = s_logit + kPillars * kItemsPad;                 // [kPillars][kC]
+    float *s_logit = (float *)smem;                              // [kPillars][kPitch]
+    float *s_f = s_logit + kPillars * kPitch;                    // [kPillars][kC]
     unsigned long long *s_cand = (unsigned long long *)(s_f + kPillars * kC);   // [waves][64]
     if (m_device) M = min(M, *m_device);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -98,108 +158,94 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         const int p = i / kC;
         s_f[i] = p < np ? f[(size_t)(p0 + p) * kC + (i % kC)] : 0.f;
     }
+    // items past n_items never win: their logits are -inf (written once; the partial last tile stores only its live rows)
+    for (int i = tid; i < kPillars * (kItemsPad - n_items); i += kThreads)
+        s_logit[(i / (kItemsPad - n_items)) * kPitch + n_items + i % (kItemsPad - n_items)] = -INFINITY;
     __syncthreads();
 
-    // ---- phase 1: logits[p][j] = f[p] . bank[j] on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) ----
-    // D (16 items x 16 pillars) = A (items x K) . B (K x pillars), K = 64 channels.  Lane quarter q feeds channels
-    // 16g+4q .. 16g+4q+3 of group g to four consecutive MFMAs from ONE 16-byte load per operand (the MFMA k index is a
-    // free permutation as long as A and B agree).  B (the 16 pillars) stays in registers for the whole kernel; A (the
-    // bank, 512 KB, L2 resident) is streamed 16 items at a time, next tile prefetched while the current one multiplies.
-    {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int l15 = lane & 15, q = lane >> 4;
-        float4 bf[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bf[g] = *(const float4 *)(s_f + l15 * kC + 16 * g + 4 * q);
-        // items past n_items never win: their logits are -inf (written once, not tested per tile)
-        for (int i = tid; i < kPillars * (kItemsPad - n_items); i += kThreads)
-            s_logit[(i / (kItemsPad - n_items)) * kItemsPad + n_items + i % (kItemsPad - n_items)] = -INFINITY;
-        // The fp32 MFMA runs on the vector ALU lanes: every VALU instruction of a wave costs its SIMD one MFMA slot, and four
-        // waves share a SIMD.  The tile loop therefore carries no vector arithmetic: the tile index is a scalar (SGPR base
-        // + fixed per-lane offset addressing), registers ping-pong instead of being copied, bounds are handled outside.
-        const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wid);
-        constexpr int kWaves = kThreads / 64;
-        const int n_full = n_items / 16;                           // whole 16-item tiles
-        // This lane's float offset inside a 16-item tile (1024 floats in both layouts) and the step between its four 16-byte
-        // pieces.  Row-major bank: 16 rows x 64 contiguous bytes per load instruction (half cache lines).  Packed bank
-        // (hvpr_memory_bank_pack_f32: [tile][piece][lane] float4): every load instruction reads 1 KB contiguous — the same
-        // bytes, but the logits phase drops from 36.5 k to 24 k cycles (the bank streams out of L2 in full-line requests).
-        const int lane_elem = bank_packed ? 4 * l15 + 64 * q : l15 * kC + 4 * q;
-        const int piece = bank_packed ? 256 : 16;
-        float *const lrow = s_logit + l15 * kItemsPad + 4 * q;     // this lane's logits slot inside tile 0
-        const int rot = (int)((blockIdx.x * 7u) % (unsigned)(n_full > 0 ? n_full : 1));   // de-phase the workgroups' bank streams
-        auto tile_of = [&](int j) { int t = j + rot; return t >= n_full ? t - n_full : t; };
-        auto load_a = [&](int t, float4 (&a)[4]) {
-            const float *tb = (bank_packed ? bank_packed : bank) + (size_t)t * (16 * kC);   // wave-uniform
-#pragma unroll
-            for (int g = 0; g < 4; ++g) a[g] = *(const float4 *)(tb + lane_elem + piece * g);
-        };
-        auto mul_store = [&](int t, const float4 (&a)[4]) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, bf[g].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, bf[g].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].z, bf[g].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].w, bf[g].w, acc, 0, 0, 0);
-            }
-            // C/D map of 16x16x4: column (pillar) = lane & 15, row (item) = 4 * (lane >> 4) + reg
-            *(float4 *)(lrow + t * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        };
-        // wave w owns tiles w, w + 16, w + 32, ... (rotated); two register sets alternate, the next tile's loads are in flight
-        // while the current one multiplies
-        float4 a0[4], a1[4];
-        int j = (int)wave_u;
-        if (j < n_full) load_a(tile_of(j), a0);
-        for (; j < n_full; j += 2 * kWaves) {
-            const int j1 = j + kWaves, j2 = j + 2 * kWaves;
-            if (j1 < n_full) load_a(tile_of(j1), a1);
-            mul_store(tile_of(j), a0);
-            if (j1 < n_full) {
-                if (j2 < n_full) load_a(tile_of(j2), a0);
-                mul_store(tile_of(j1), a1);
-            }
-        }
-        if ((n_items & 15) && wave_u == 0) {                       // the partial last tile: rows clamped, tail stays -inf
-            const int item = min(n_full * 16 + l15, n_items - 1);
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 a = bank_packed ? *(const float4 *)(bank_packed + (size_t)n_full * (16 * kC) + lane_elem + piece * g)   // zero padded
-                                             : *(const float4 *)(bank + (size_t)item * kC + 4 * q + 16 * g);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bf[g].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bf[g].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bf[g].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bf[g].w, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n_full * 16 + 4 * q + r < n_items) lrow[n_full * 16 + r] = acc[r];
-        }
-    }
-    __syncthreads();
 #ifdef HVPR_EXP_TIMING
     const long long tt1 = __builtin_readcyclecounter();
 #endif
+    // ---- phase 1: A[p][j] on the fp16 matrix cores.  D (16 items x 16 pillars) = A (items x K) . B (K x pillars), K = 2 x 32
+    // channels.  Lane (l15, q) holds channels 32h + 8q .. 32h + 8q + 7 of item / pillar l15 for both operands (the k index of
+    // an MFMA is a free permutation as long as A and B agree).  B (the 16 pillars) stays in registers.
+    {
+        const int l15 = lane & 15, q = lane >> 4;
+        f16x8_t bfrag[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 lo = *(const float4 *)(s_f + l15 * kC + 32 * h + 8 * q), hi = *(const float4 *)(s_f + l15 * kC + 32 * h + 8 * q + 4);
+            const unsigned w0 = f16_rne(lo.x) | (f16_rne(lo.y) << 16), w1 = f16_rne(lo.z) | (f16_rne(lo.w) << 16);
+            const unsigned w2 = f16_rne(hi.x) | (f16_rne(hi.y) << 16), w3 = f16_rne(hi.z) | (f16_rne(hi.w) << 16);
+            const uint4 u = make_uint4(w0, w1, w2, w3);
+            bfrag[h] = __builtin_bit_cast(f16x8_t, u);
+        }
+        // the wave's tiles of the packed bank ([tile][half][lane] 16 bytes: every load instruction reads 1 KB contiguous), all
+        // requested up front.  (Requesting them before the feature fetch was measured slower: the features then queue behind
+        // 16 KB per wave in vmcnt order.)
+        constexpr int kWaves = kThreads / 64, kMaxTiles = kItemsPad / 16 / kWaves;    // 8 tiles per wave at most
+        const int n_tiles = (n_items + 15) >> 4;
+        const int first = (int)((__builtin_amdgcn_readfirstlane((unsigned)wid) + blockIdx.x) % (unsigned)kWaves);   // de-phase the workgroups' bank streams
+        uint4 a[kMaxTiles][2];
+#pragma unroll
+        for (int i = 0; i < kMaxTiles; ++i) {
+            const int t = first + i * kWaves;                      // wave-uniform
+            if (t < n_tiles) {
+                a[i][0] = bank_bf[(size_t)t * 128 + lane];
+                a[i][1] = bank_bf[(size_t)t * 128 + 64 + lane];
+            }
+        }
+        float *const lrow = s_logit + l15 * kPitch + 4 * q;       // this lane's logits slot inside tile 0
+#pragma unroll
+        for (int i = 0; i < kMaxTiles; ++i) {
+            const int t = first + i * kWaves;
+            if (t < n_tiles) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[i][0]), bfrag[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[i][1]), bfrag[1], acc, 0, 0, 0);
+                // C/D map of 16x16: column (pillar) = lane & 15, row (item) = 4 * (lane >> 4) + reg
+                if (16 * t + 16 <= n_items) {
+                    *(float4 *)(lrow + t * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * t + 4 * q + r < n_items) lrow[t * 16 + r] = acc[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
 
-    // ---- phase 2/3: one wave per pillar ----
+#ifdef HVPR_EXP_TIMING
+    const long long tt2 = __builtin_readcyclecounter();
+    long long tt3 = tt2, tt4 = tt2, tt5 = tt2;
+    int t_cnt = 0;
+#endif
+    // ---- phase 2-4: one wave per pillar ----
     unsigned long long *cand = s_cand + wid * 64;
+    // sum_c wmax_c and max_c wmax_c (the same for every pillar)
+    const float wm = wmax[lane];
+    const float wsum = hvpr_reduce_sum<64>(wm), wtop = hvpr_reduce_max<64>(wm);
     for (int p = wid; p < np; p += kThreads / 64) {
-        const float *row = s_logit + p * kItemsPad;
+        const float *row = s_logit + p * kPitch;
+        const float fc = s_f[p * kC + lane];                      // lane = channel
+        // 2 eps_p: the bound on |A - L| of this pillar, doubled (see the header); infinite outside the fp16 range
+        const float fa = fabsf(fc);
+        float eps2 = 2.f * (hvpr_reduce_sum<64>(fmaf(kRelErr * wm, fa, kAbsErr * fa)) + kAbsErr * wsum + 1e-30f);   // one reduction
+        if (!(hvpr_reduce_max<64>(fa) <= kHalfMax) || !(wtop <= kHalfMax)) eps2 = INFINITY;
         float v[kItemsPad / 64];
         float lmax = -INFINITY;
 #pragma unroll
         for (int t = 0; t < kItemsPad / 64; ++t) { v[t] = row[lane + 64 * t]; lmax = fmaxf(lmax, v[t]); }
-        // tau <= k-th largest of the 64 lane maxima (its 16 leading bits: half the ballot steps, a handful of extra
-        // candidates): a lower bound of the k-th largest logit
-        const unsigned tau_bits = wave_kth_largest_hi16(ord_bits(lmax), k);
-        const unsigned tb = (tau_bits & 0x80000000u) ? (tau_bits & 0x7fffffffu) : ~tau_bits;
-        const float tau = __uint_as_float(tb);                    // > -inf whenever at least k lanes hold a finite logit
-        // candidates (>= tau) per lane as a bit mask (float compares only), then compacted rank by rank: rank r of every
-        // lane with more than r candidates goes to LDS at a ballot-prefix position.  ~23 candidates, at most a few per lane.
+        // tau <= k-th largest of the 64 lane maxima (its 16 leading bits): a lower bound of the k-th largest A
+        const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(lmax), k));
+        // tau = -inf or eps2 = inf / NaN let every live item through; the -inf padding past n_items never passes
+        const float tau_lo = fmaxf(tau - eps2, -3.4028235e38f);
+        // candidates (not below tau_lo) per lane as a bit mask, then compacted rank by rank: rank r of every lane with more
+        // than r candidates goes to LDS at a ballot-prefix position.  ~25 candidates, at most a few per lane.
         unsigned hits = 0u;
 #pragma unroll
-        for (int t = 0; t < kItemsPad / 64; ++t) hits |= (v[t] >= tau && v[t] > -INFINITY) ? (1u << t) : 0u;
+        for (int t = 0; t < kItemsPad / 64; ++t) hits |= v[t] >= tau_lo ? (1u << t) : 0u;
         int cnt = 0;
         for (unsigned left = hits; __ballot(left != 0u) != 0ull;) {
             const bool has = left != 0u;
@@ -207,15 +253,40 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
             const int t = has ? __ffs((int)left) - 1 : 0;
             left &= left - 1u;
             const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-            if (has && pos < 64)
-                cand[pos] = ((unsigned long long)ord_bits(row[lane + 64 * t]) << 32) | (unsigned)(0xffffffffu - (unsigned)(lane + 64 * t));
+            if (has && pos < 64) cand[pos] = (unsigned long long)(unsigned)(lane + 64 * t);
             cnt += __popcll(m);
         }
-        // the k largest keys (value desc, index asc; keys are unique) end up in lanes [0,k), in no particular order
-        unsigned long long key = 0ull;
-        bool sel;
+        if (!(eps2 < INFINITY)) cnt = 65;     // out of the fp16 range (A may be inf / NaN): no pre-filter, exact slow path
+#ifdef HVPR_EXP_TIMING
+        tt3 = __builtin_readcyclecounter(); t_cnt = cnt;
+#endif
+        // From here lane c < 64 owns candidate c: its item id, its exact logit, whether it is selected, its softmax weight.
+        int my_idx = 0;
+        float L = -INFINITY;
+        bool sel = false;
+        float rows0[32];                   // the rows of candidates 0..31 (lane = channel), kept for the weighted sum
         if (cnt <= 64) {
-            key = lane < cnt ? cand[lane] : 0ull;
+            my_idx = lane < cnt ? (int)cand[lane] : 0;
+#pragma unroll
+            for (int r = 0; r < 32; ++r)   // lanes past cnt hold item 0: harmless
+                rows0[r] = bank[(size_t)__builtin_amdgcn_readlane(my_idx, r) * kC + lane];
+            {
+                float x[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) x[r] = __fmul_rn(rows0[r], fc);
+                const float s0 = wave_sum32(x, lane);              // lane l: exact logit of candidate l & 31
+                if (lane < 32) L = s0;
+            }
+            if (cnt > 32) {                                        // wave-uniform, uncommon: candidates 32..63
+                float x[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) x[r] = bank[(size_t)__builtin_amdgcn_readlane(my_idx, 32 + r) * kC + lane];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) x[r] = __fmul_rn(x[r], fc);
+                const float s1 = wave_sum32(x, lane);
+                if (lane >= 32) L = s1;
+            }
+            const unsigned long long key = lane < cnt ? (((unsigned long long)ord_bits(L) << 32) | (unsigned)(0xffffffffu - (unsigned)my_idx)) : 0ull;
             const int kk = min(k, cnt);
             // select on the 32 value bits; the 32 index bits only matter when equal values straddle the k-th place
             const unsigned hi = (unsigned)(key >> 32);
@@ -228,15 +299,27 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                 sel = key != 0ull && key >= kth;
             }
         } else {
-            // exact slow path (mass ties): k rounds of wave arg-max with (value desc, index asc) order
-            unsigned long long prev = ~0ull;
+            // exact slow path (mass ties): the exact logit of EVERY item (one reduction each), then k rounds of wave arg-max
+            // with (value desc, index asc) order; winner r goes to lane r
+#pragma unroll
+            for (int t = 0; t < kItemsPad / 64; ++t) {
+                float mine = -INFINITY;
+                for (int i = 0; i < 64; ++i) {
+                    const int j = 64 * t + i;                       // wave-uniform
+                    if (j >= n_items) break;
+                    const float s = hvpr_reduce_sum<64>(__fmul_rn(bank[(size_t)j * kC + lane], fc));
+                    if (lane == i) mine = s;
+                }
+                v[t] = mine;
+            }
+            unsigned long long prev = ~0ull, key = 0ull;
             for (int r = 0; r < k; ++r) {
                 unsigned long long best = 0ull;
 #pragma unroll
                 for (int t = 0; t < kItemsPad / 64; ++t) {
                     const unsigned long long c = ((unsigned long long)ord_bits(v[t]) << 32) |
                                                  (unsigned)(0xffffffffu - (unsigned)(lane + 64 * t));
-                    if (c < prev && c > best && v[t] > -INFINITY) best = c;
+                    if (c < prev && c > best && lane + 64 * t < n_items) best = c;
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
@@ -249,24 +332,22 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                 prev = best;
             }
             sel = lane < k && key != 0ull;
+            L = sel ? ord_to_float((unsigned)(key >> 32)) : -INFINITY;
+            my_idx = sel ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0;
+#pragma unroll
+            for (int r = 0; r < 32; ++r)   // k <= 32 winners sit in lanes 0..k-1
+                rows0[r] = bank[(size_t)__builtin_amdgcn_readlane(my_idx, r) * kC + lane];
         }
-        // move the selected keys to lanes [0, #selected)
-        {
-            const unsigned long long m = __ballot(sel);
-            const int dst = __popcll(m & ((1ull << lane) - 1ull));
-            if (sel) cand[dst] = key;
-            const int nsel = __popcll(m);
-            key = lane < nsel ? cand[lane] : 0ull;
-            sel = lane < nsel;
-        }
-        const unsigned ub = (unsigned)(key >> 32);
-        const float logit = sel ? __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub) : -INFINITY;
-        const int idx = sel ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0;
-        // softmax over the selected logits: two DPP wave reductions (lanes past the selection carry -inf / 0)
+#ifdef HVPR_EXP_TIMING
+        tt4 = __builtin_readcyclecounter();
+#endif
+        // softmax over the selected exact logits, in place: two DPP wave reductions (unselected lanes carry -inf / 0)
+        const float logit = sel ? L : -INFINITY;
         const float mx = hvpr_reduce_max<64>(logit);
         const float e = sel ? __expf(logit - mx) : 0.f;
         const float a = e / hvpr_reduce_sum<64>(e);
-        if (topk_idx && lane < k) topk_idx[(size_t)(p0 + p) * k + lane] = idx;
+        const unsigned long long selmask = __ballot(sel);
+        if (topk_idx && sel) topk_idx[(size_t)(p0 + p) * k + __popcll(selmask & ((1ull << lane) - 1ull))] = my_idx;
         long long cell = -1;           // fused a3+a4: this pillar's BEV cell (pointpillar_scatter.py:192, nz == 1)
         if (cell_map || canvas) {
             const int4 c = coords[p0 + p];
@@ -274,21 +355,25 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                 cell = ((long long)c.x * ny + c.z) * nx + c.w;
             if (cell_map && lane == 0 && cell >= 0) cell_map[cell] = p0 + p;   // gather-form scatter: k_cell_map's job
         }
-        // lane = channel.  All k selected rows are requested before the first is used, so the gather costs one L2 round
-        // trip instead of k dependent ones (row-major copy of the bank: 256 B per row).
-        float rows[32];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) rows[r] = r < k ? bank[(size_t)__builtin_amdgcn_readlane(idx, r) * kC + lane] : 0.f;
+        // lane = channel: weighted sum over candidates 0..31 from the rows already in registers (weight 0 if not selected);
+        // selected candidates 32..63 (uncommon) are read again, one row each
         float acc = 0.f;
 #pragma unroll
-        for (int r = 0; r < 32; ++r)
-            if (r < k) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), r)), rows[r], acc);
+        for (int r = 0; r < 32; ++r) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), r)), rows0[r], acc);
+        for (unsigned long long m = selmask >> 32; m != 0ull; m &= m - 1ull) {
+            const int c = 32 + (__ffsll((long long)m) - 1);         // wave-uniform
+            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), c));
+            acc = fmaf(w, bank[(size_t)__builtin_amdgcn_readlane(my_idx, c) * kC + lane], acc);
+        }
         out[(size_t)(p0 + p) * kC + lane] = acc;
         // fused encode path: the memory channels of this pillar's cell, straight into the pre-cleared NHWC canvas
         if (canvas && cell >= 0) canvas[(size_t)cell * canvas_channels + canvas_offset + lane] = acc;
     }
 #ifdef HVPR_EXP_TIMING
-    if (blockIdx.x == 3 && lane == 0) printf("readout wave %d: mfma phase %lld cycles, select+gather %lld cycles\n", wid, tt1 - tt0, (long long)__builtin_readcyclecounter() - tt1);
+    tt5 = __builtin_readcyclecounter();
+    if ((blockIdx.x == 3 || blockIdx.x == 100) && lane == 0 && (wid & 3) == 0)
+        printf("readout wg %d wave %d: features %lld | logits %lld | select %lld (cands %d) | exact+topk %lld | softmax+gather %lld cycles\n",
+               (int)blockIdx.x, wid, tt1 - tt0, tt2 - tt1, tt3 - tt2, t_cnt, tt4 - tt3, tt5 - tt4);
 #endif
 }
 
@@ -375,14 +460,17 @@ int hvpr_i_readout(const float *f, int M, const int32_t *m_device, const float *
     if (M < 0 || n_items < 1 || k < 1) return HVPR_ERR_INVALID_ARG;
     if (k > 32 || k > n_items || n_items > kItemsPad) return HVPR_ERR_UNSUPPORTED;
     if (M == 0) return HVPR_OK;
-    if (!f || !bank || !out) return HVPR_ERR_INVALID_ARG;
+    if (!f || !bank || !bank_packed || !out) return HVPR_ERR_INVALID_ARG;   // the packed copy is required (fp16 tiles + channel maxima)
     if ((cell_map || canvas) && !coords) return HVPR_ERR_INVALID_ARG;
     if (canvas && canvas_offset + kC > canvas_channels) return HVPR_ERR_INVALID_ARG;
-    const size_t lds = (size_t)kPillars * kItemsPad * 4 + kPillars * kC * 4 + (kThreads / 64) * 64 * 8;
+    const size_t lds = (size_t)kPillars * kPitch * 4 + kPillars * kC * 4 + (kThreads / 64) * 64 * 8;
     static unsigned long long lds_set = 0ull;   // per device
     if (hvpr_ensure_dyn_lds((const void *)k_memory_readout, (int)lds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
+    const int n_tiles = hvpr_cdiv(n_items, 16);
+    const uint4 *bank_bf = (const uint4 *)bank_packed;
+    const float *wmax = bank_packed + (size_t)n_tiles * 512;      // 2 KB of fp16 per tile = 512 floats
     hipLaunchKernelGGL(k_memory_readout, dim3(hvpr_cdiv(M, kPillars)), dim3(kThreads), lds, stream, f, M, m_device, bank,
-                       bank_packed, n_items, k, out, topk_idx, (const int4 *)coords, batch, nx, ny, cell_map, canvas, canvas_channels,
+                       bank_bf, wmax, n_items, k, out, topk_idx, (const int4 *)coords, batch, nx, ny, cell_map, canvas, canvas_channels,
                        canvas_offset);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
@@ -396,20 +484,43 @@ int launch_readout(const float *f, int M, const int32_t *m_device, const float *
 }
 }  // namespace
 
-// bank (n_items, 64) row-major -> packed [ceil(n_items / 16)][4 pieces][64 lanes] float4, rows past n_items zero
-__global__ void __launch_bounds__(256) k_bank_pack(const float *__restrict__ bank, int n_items, float4 *__restrict__ packed, int n_out) {
+// bank (n_items, 64) row-major fp32 -> the read-out kernel's streaming copy:
+//   [ceil(n_items / 16) tiles][2 channel halves][64 lanes] x 8 fp16 (round to nearest even; rows past n_items zero): lane
+//   (l15, q) of half h holds channels 32h + 8q .. + 7 of item 16 * tile + l15 — the A operand of v_mfma_f32_16x16x32_f16,
+//   1 KB contiguous per load instruction; followed by wmax[64] fp32 = max_j |bank[j][c]| (the pre-filter's error bound).
+__global__ void __launch_bounds__(256) k_bank_pack(const float *__restrict__ bank, int n_items, uint4 *__restrict__ packed, int n_out) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n_out) return;
-    const int t = o >> 8, g = (o >> 6) & 3, ln = o & 63, row = 16 * t + (ln & 15);
-    packed[o] = row < n_items ? *(const float4 *)(bank + (size_t)row * kC + 16 * g + 4 * (ln >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int t = o >> 7, h = (o >> 6) & 1, ln = o & 63, row = 16 * t + (ln & 15), c0 = 32 * h + 8 * (ln >> 4);
+    uint4 u = make_uint4(0u, 0u, 0u, 0u);
+    if (row < n_items) {
+        const float4 lo = *(const float4 *)(bank + (size_t)row * kC + c0), hi = *(const float4 *)(bank + (size_t)row * kC + c0 + 4);
+        u = make_uint4(f16_rne(lo.x) | (f16_rne(lo.y) << 16), f16_rne(lo.z) | (f16_rne(lo.w) << 16),
+                       f16_rne(hi.x) | (f16_rne(hi.y) << 16), f16_rne(hi.z) | (f16_rne(hi.w) << 16));
+    }
+    packed[o] = u;
 }
 
-extern "C" size_t hvpr_memory_bank_packed_floats(int n_items) { return n_items < 1 ? 0 : (size_t)hvpr_cdiv(n_items, 16) * 16 * kC; }
+__global__ void __launch_bounds__(1024) k_bank_wmax(const float *__restrict__ bank, int n_items, float *__restrict__ wmax) {
+    __shared__ float s[16][kC];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    float m = 0.f;
+    for (int j = part; j < n_items; j += 16) m = fmaxf(m, fabsf(bank[(size_t)j * kC + c]));
+    s[part][c] = m;
+    __syncthreads();
+    if (part == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, s[i][c]);
+        wmax[c] = m;          // NaN rows propagate nothing here (fmaxf drops NaN): a NaN bank gives NaN logits either way
+    }
+}
+
+extern "C" size_t hvpr_memory_bank_packed_floats(int n_items) { return n_items < 1 ? 0 : (size_t)hvpr_cdiv(n_items, 16) * 512 + kC; }
 
 extern "C" int hvpr_memory_bank_pack_f32(const float *bank, int n_items, float *packed, hvpr_stream_t stream) {
     if (!bank || !packed || n_items < 1) return HVPR_ERR_INVALID_ARG;
-    const int n_out = hvpr_cdiv(n_items, 16) * 256;
-    hipLaunchKernelGGL(k_bank_pack, dim3(hvpr_cdiv(n_out, 256)), dim3(256), 0, (hipStream_t)stream, bank, n_items, (float4 *)packed, n_out);
+    const int n_tiles = hvpr_cdiv(n_items, 16), n_out = n_tiles * 128;
+    hipLaunchKernelGGL(k_bank_pack, dim3(hvpr_cdiv(n_out, 256)), dim3(256), 0, (hipStream_t)stream, bank, n_items, (uint4 *)packed, n_out);
+    hipLaunchKernelGGL(k_bank_wmax, dim3(1), dim3(1024), 0, (hipStream_t)stream, bank, n_items, packed + (size_t)n_tiles * 512);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }

@@ -95,8 +95,10 @@ def pillar_vfe_fwd(voxels, num_points, coords, folded, voxel_size, offsets, m_de
 
 # ------------------------------------------------------------------------------------------------ memory + scatter
 class PackedBank:
-    """Memory bank in the read-out kernel's streaming layout (hvpr_memory_bank_pack_f32): same values, [tile of 16 items]
-    [4 pieces][64 lanes] float4, so that every load instruction of the logits loop reads 1 KB contiguous."""
+    """Memory bank with its streaming copy for the read-out kernel (hvpr_memory_bank_pack_f32): bf16 tiles in the matrix-core
+    operand layout ([tile of 16 items][channel half][64 lanes] x 8 bf16, 1 KB contiguous per load instruction) + the 64
+    channel maxima max_j |W_jc| that bound the pre-filter's rounding error.  The fp32 rows stay next to it: candidates are
+    re-checked and the k selected rows are read in exact fp32."""
 
     def __init__(self, weight):
         w = weight.detach().float().contiguous()
@@ -111,10 +113,12 @@ class PackedBank:
 
 
 def _bank_args(bank):
-    """(row-major pointer, packed pointer or None, n_items) of a plain (n_items, 64) tensor or a PackedBank."""
-    if isinstance(bank, PackedBank):
-        return bank.rows.data_ptr(), bank.data.data_ptr(), bank.n_items
-    return _ptr(bank, torch.float32, "memory.weight"), None, bank.shape[0]
+    """(row-major pointer, packed pointer, n_items) of a PackedBank; a plain (n_items, 64) tensor is packed here (callers that
+    reuse a bank pack it once themselves)."""
+    if not isinstance(bank, PackedBank):
+        _ptr(bank, torch.float32, "memory.weight")
+        bank = PackedBank(bank)
+    return bank.rows.data_ptr(), bank.data.data_ptr(), bank.n_items
 
 
 def memory_readout_fwd(f, bank, k, m_device=None, want_idx=False):

@@ -93,11 +93,13 @@ int hvpr_pillar_vfe_fwd_f32(const float *voxels, const int32_t *num_points, cons
  *     softmax over the k selected logits, weighted sum of the k items.
  *     f [M,64], bank [n_items,64] -> out [M,64]; topk_idx [M,k] i32 (may be NULL; the k selected ids, order unspecified).
  *     k <= 32, channels == 64.
- *     bank_packed (may be NULL): the output of hvpr_memory_bank_pack_f32 for the same bank (same values, tiled so that the
- *     logits loop streams it in full cache lines: 27 k instead of 36.5 k cycles at hvpr_car); pack once per weight update.
- *     `bank` itself is always needed (the k selected rows are read from it).
+ *     bank_packed (REQUIRED): the output of hvpr_memory_bank_pack_f32 for the same bank — bf16 tiles in the matrix-core
+ *     operand layout + the 64 channel maxima max_j |bank[j][c]|; pack once per weight update.  The kernel pre-filters on the
+ *     bf16 matrix cores with a rigorous rounding-error bound and re-checks the ~30 surviving candidates per row in exact
+ *     fp32 from `bank` (logit = butterfly-tree sum of the 64 fp32 products), so the selected ids are the exact fp32 top-k
+ *     (value descending, id ascending on ties); the k selected rows are read from `bank` too.
  * ------------------------------------------------------------------------------------------- */
-size_t hvpr_memory_bank_packed_floats(int n_items);   /* floats in the packed copy (rows padded to a multiple of 16) */
+size_t hvpr_memory_bank_packed_floats(int n_items);   /* size of the packed copy in floats: ceil(n_items/16) * 512 + 64 */
 int hvpr_memory_bank_pack_f32(const float *bank, int n_items, float *packed, hvpr_stream_t stream);
 int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t *m_device, const float *bank, const float *bank_packed,
                                 int n_items, int k, float *out, int32_t *topk_idx, hvpr_stream_t stream);

@@ -235,6 +235,29 @@ def test_memory_readout_ties_take_lowest_indices():
     np.testing.assert_allclose(out.cpu().numpy(), np.tile(W[:20].mean(0), (3, 1)), rtol=1e-5, atol=1e-6)
 
 
+def test_memory_readout_prefilter_edge_cases():
+    """The fp16 pre-filter must never change the exact fp32 top-k: (a) 50 nearly identical bank rows put far more than k items
+    inside the filter's error band (candidates 33..64: second exact pass), (b) 300 of them overflow the 64-candidate list
+    (exact slow path over all items), (c) features beyond the fp16 range switch the filter off, (d) tiny features and tiny
+    bank entries (fp16 subnormal range)."""
+    rng = np.random.default_rng(77)
+    f = np.maximum(rng.normal(0, 1, (40, 64)), 0).astype(np.float32)
+    W = det_tensor("memory.weight", (2000, 64), 8).copy()
+    best = int(np.argmax(f[:1] @ W.T))
+    for n_close in (50, 300):
+        Wc = W.copy()
+        ids = rng.choice(2000, n_close, replace=False)
+        Wc[ids] = W[best] * (1 + 3e-4 * rng.normal(0, 1, (n_close, 1))) + 1e-4 * rng.normal(0, 1, (n_close, 64))
+        _check_memory(f, Wc.astype(np.float32))
+    # (the logits themselves keep their usual scale in every case: the oracle takes its top-k on softmax scores, which
+    # saturate for huge logits and collapse for tiny ones — memory_module.py:65-66)
+    _check_memory((f * 1e-6).astype(np.float32), (W * 1e6).astype(np.float32))        # bank beyond the fp16 range
+    _check_memory((f * 1e6).astype(np.float32), (W * 1e-6).astype(np.float32))        # features beyond it, bank in the subnormal range
+    ft = f.copy(); ft[:, ::2] *= 1e-6                                                   # half of the channels tiny
+    W0 = W.copy(); W0[::3, 1::2] *= 1e-5
+    _check_memory(ft.astype(np.float32), W0.astype(np.float32))
+
+
 def test_scatter_golden_and_idle_workspace(golden_dir):
     z = np.load(os.path.join(golden_dir, "g3_scatter_eval.npz"))
     W = det_tensor(str(z["W_name"]), (2000, 64), int(z["W_seed"]))
