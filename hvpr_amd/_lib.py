@@ -44,6 +44,11 @@ SIGNATURES = {
     "hvpr_furthest_point_sample_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "hvpr_ball_query_f32": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P]),
     "hvpr_three_nn_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "hvpr_group_points_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "hvpr_group_points_grad_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "hvpr_three_interpolate_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "hvpr_three_interpolate_grad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "hvpr_fused_adam_truewd_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _F, _F, _F, _F, _F, _I, _P, _P]),
     "hvpr_split_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),
     "hvpr_unsplit_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),
     "hvpr_conv2d_nhwc_bf16x3": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

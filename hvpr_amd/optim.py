@@ -35,20 +35,27 @@ class OneCycle:
                 self.optimizer.mom = annealing_cos(a, b, (step - start) / (end - start))
 
 
+def split_bn_params(model):
+    """(non-BatchNorm, BatchNorm) trainable parameters in the order the reference's flattened leaf-module list gives them
+    (tools/train_utils/optimization/__init__.py:26-27, fastai_optim.py:13-24)."""
+    bn_types = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
+    bn, rest = [], []
+    for m in model.modules():
+        if next(m.children(), None) is not None:
+            continue            # leaves only (the reference flattens the model into leaf modules, __init__.py:26-27)
+        for p in m.parameters(recurse=False):
+            if p.requires_grad:
+                (bn if isinstance(m, bn_types) else rest).append(p)
+    owned = {id(p) for p in bn + rest}
+    rest += [p for p in model.parameters() if p.requires_grad and id(p) not in owned]   # parameters held by non-leaf modules
+    return rest, bn
+
+
 class AdamOneCycle:
     """Adam(betas=(mom, 0.99)) over two parameter groups (non-BatchNorm / BatchNorm), decoupled weight decay on both."""
 
     def __init__(self, model, wd, lr=3e-3, beta2=0.99):
-        bn_types = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
-        bn, rest = [], []
-        for m in model.modules():
-            if next(m.children(), None) is not None:
-                continue            # leaves only (the reference flattens the model into leaf modules, __init__.py:26-27)
-            for p in m.parameters(recurse=False):
-                if p.requires_grad:
-                    (bn if isinstance(m, bn_types) else rest).append(p)
-        owned = {id(p) for p in bn + rest}
-        rest += [p for p in model.parameters() if p.requires_grad and id(p) not in owned]   # parameters held by non-leaf modules
+        rest, bn = split_bn_params(model)
         self.opt = torch.optim.Adam([{"params": rest}, {"params": bn}], lr=lr, betas=(0.9, beta2), weight_decay=0.0)
         self.wd, self._lr, self._mom, self.beta2 = wd, lr, 0.9, beta2
 
@@ -103,8 +110,123 @@ class AdamOneCycle:
             self.lr, self.mom = extra["lr"], extra["mom"]
 
 
+class FusedAdamOneCycle:
+    """The same optimiser as AdamOneCycle on ONE flat fp32 buffer: every trainable parameter becomes a view into `flat_p`, its
+    gradient a view into `flat_g`, and a step is one launch of hvpr_fused_adam_truewd_f32 (decay + Adam + the gradient-norm
+    clip as a device-side scale) instead of hundreds of small kernels per tensor (the reference: per-tensor python loops,
+    fastai_optim.py:132-149).  state_dict() / load_state_dict() speak torch.optim.Adam's format in AdamOneCycle's parameter
+    order, so checkpoints move between the two."""
+
+    def __init__(self, model, wd, lr=3e-3, beta2=0.99, eps=1e-8):
+        from . import kernels
+        rest, bn = split_bn_params(model)
+        self.params = rest + bn
+        self.n_rest = len(rest)
+        assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), "FusedAdamOneCycle: fp32 parameters on the GPU"
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4                     # every view starts 16-byte aligned
+        self.numel = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_p[o:o + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+        self._grad_views = [self.flat_g[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
+        self._point_grads()
+        self.wd, self._lr, self._mom, self.beta2, self.eps = wd, lr, 0.9, beta2, eps
+        self.steps = 0
+        self._scale = None
+        self._kernels = kernels
+
+    def _point_grads(self):
+        for p, g in zip(self.params, self._grad_views):
+            p.grad = g
+
+    lr = property(lambda self: self._lr, lambda self, v: setattr(self, "_lr", float(v)))
+    mom = property(lambda self: self._mom, lambda self, v: setattr(self, "_mom", float(v)))
+
+    @property
+    def param_groups(self):
+        return [{"params": self.params[:self.n_rest], "lr": self._lr, "betas": (self._mom, self.beta2)},
+                {"params": self.params[self.n_rest:], "lr": self._lr, "betas": (self._mom, self.beta2)}]
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        self._point_grads()
+        self._scale = None
+
+    @torch.no_grad()
+    def _collect_grads(self):
+        """Gradients normally accumulate straight into the flat buffer; anything that re-pointed p.grad (DDP bucket views, a
+        zero_grad(set_to_none) elsewhere) is copied back in."""
+        for p, g in zip(self.params, self._grad_views):
+            if p.grad is None:
+                g.zero_()
+            elif p.grad.data_ptr() != g.data_ptr():
+                g.copy_(p.grad)
+
+    @torch.no_grad()
+    def clip_grad_norm(self, max_norm):
+        """clip_grad_norm_ (train_utils.py:41) without touching the gradients: the coefficient stays on the device and the step
+        kernel applies it.  Returns the total norm (device scalar)."""
+        self._collect_grads()
+        total = torch.linalg.vector_norm(self.flat_g)
+        self._scale = torch.clamp(max_norm / (total + 1e-6), max=1.0).to(torch.float32).reshape(1)
+        return total
+
+    @torch.no_grad()
+    def step(self):
+        from ._lib import check, lib
+        if self._scale is None:
+            self._collect_grads()
+        self.steps += 1
+        check(lib().hvpr_fused_adam_truewd_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                               self.exp_avg_sq.data_ptr(), self.numel, self._lr, self._mom, self.beta2, self.eps,
+                                               self.wd, self.steps, None if self._scale is None else self._scale.data_ptr(),
+                                               self._kernels._stream()), "hvpr_fused_adam_truewd_f32")
+        self._scale = None
+
+    def state_dict(self):
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if self.steps > 0:
+                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.exp_avg[o:o + p.numel()].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view_as(p).clone()}
+        base = {"lr": self._lr, "betas": (self._mom, self.beta2), "eps": self.eps, "weight_decay": 0.0, "amsgrad": False,
+                "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                "decoupled_weight_decay": False}
+        groups = [dict(base, params=list(range(self.n_rest))), dict(base, params=list(range(self.n_rest, len(self.params))))]
+        return {"state": state, "param_groups": groups,
+                "hvpr_onecycle": {"lr": self._lr, "mom": self._mom, "wd": self.wd, "beta2": self.beta2}}
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            steps = 0
+            for i, st in sd["state"].items():
+                i = int(i)
+                p, o = self.params[i], self.offsets[i]
+                self.exp_avg[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
+                self.exp_avg_sq[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+                steps = max(steps, int(float(st["step"])))
+            self.steps = steps
+        extra = sd.get("hvpr_onecycle")
+        if extra is not None:
+            self.wd, self.beta2, self._lr, self._mom = float(extra["wd"]), float(extra["beta2"]), float(extra["lr"]), float(extra["mom"])
+
+
 def build_optimizer(model, optim_cfg):
+    """adam_onecycle (tools/train_utils/optimization/__init__.py:19-32).  On the GPU the flat fused optimiser; FUSED: False in the
+    OPTIMIZATION config (or a CPU model) keeps the per-tensor torch.optim.Adam form."""
     assert optim_cfg.OPTIMIZER == "adam_onecycle", "hvpr path: adam_onecycle (hvpr.yaml:158)"
+    ps = [p for p in model.parameters() if p.requires_grad]
+    if optim_cfg.get("FUSED", True) and ps and all(p.is_cuda and p.dtype == torch.float32 for p in ps):
+        return FusedAdamOneCycle(model, wd=optim_cfg.WEIGHT_DECAY)
     return AdamOneCycle(model, wd=optim_cfg.WEIGHT_DECAY)
 
 
@@ -163,7 +285,10 @@ def train_step(model, optimizer, scheduler, batch_dict, it, grad_norm_clip):
     ret, tb_dict, disp_dict = model(batch_dict)
     loss = ret["loss"].mean()
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm_clip)
+    if hasattr(optimizer, "clip_grad_norm"):          # flat optimiser: the clip coefficient stays on the device
+        optimizer.clip_grad_norm(grad_norm_clip)
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm_clip)
     optimizer.step()
     (model.module if hasattr(model, "module") else model).update_global_step()
     return loss.detach(), tb_dict

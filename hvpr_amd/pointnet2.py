@@ -1,7 +1,8 @@
 """PointNet++ point stream (training only) with the reference's interfaces:
 
-  * the ops of the absent native package pcdet/ops/pointnet2/pointnet2_batch (setup.py:94-109): index producers run as HIP
-    kernels (furthest point sampling, ball query, three-NN); gathers / interpolation are differentiable torch gathers;
+  * the ops of the absent native package pcdet/ops/pointnet2/pointnet2_batch (setup.py:94-109), all HIP kernels behind the
+    C-ABI: furthest point sampling, ball query, three-NN (indices) and grouping / gather / three-interpolate with their
+    backward (autograd.Function over hvpr_group_points_f32 / hvpr_three_interpolate_f32 and their _grad twins);
   * PointnetSAModuleMSG / PointnetFPModule with the constructor kwargs used at
     pcdet/models/backbones_3d/pointnet2_backbone.py:27-34,43-47 and OpenPCDet's parameter names (mlps.{i}.{j}, mlp.{j});
   * PointNet2MSG, pcdet/models/backbones_3d/pointnet2_backbone.py:9-95 (registry key of backbones_3d).
@@ -46,27 +47,78 @@ def three_nn(unknown, known):
     return dist, idx
 
 
-# ------------------------------------------------------------------------------------------------ differentiable gathers
+# ------------------------------------------------------------------------------------------------ differentiable gathers (HIP)
+class _GroupPoints(torch.autograd.Function):
+    """grouping_operation of pointnet2_batch: features (B,C,N), idx (B,np,ns) i32 -> (B,C,np,ns); backward = scatter-add."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        features = features.contiguous()
+        B, C, N = features.shape
+        _, np_, ns = idx.shape
+        out = torch.empty((B, C, np_, ns), dtype=torch.float32, device=features.device)
+        check(lib().hvpr_group_points_f32(kernels._ptr(features, torch.float32, "features"), kernels._ptr(idx, torch.int32, "idx"),
+                                          B, C, N, np_, ns, out.data_ptr(), kernels._stream()), "hvpr_group_points_f32")
+        ctx.save_for_backward(idx)
+        ctx.N = N
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx,) = ctx.saved_tensors
+        grad = grad.contiguous()
+        B, C, np_, ns = grad.shape
+        gf = torch.empty((B, C, ctx.N), dtype=torch.float32, device=grad.device)
+        check(lib().hvpr_group_points_grad_f32(kernels._ptr(grad, torch.float32, "grad_out"), idx.data_ptr(), B, C, ctx.N, np_, ns,
+                                               gf.data_ptr(), kernels._stream()), "hvpr_group_points_grad_f32")
+        return gf, None
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    """three_interpolate of pointnet2_batch: features (B,C,m), idx / weight (B,n,3) -> (B,C,n); the weights carry no gradient
+    (they come from three_nn distances, as in the reference's op)."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        features, weight = features.contiguous(), weight.contiguous()
+        B, C, m = features.shape
+        n = idx.shape[1]
+        out = torch.empty((B, C, n), dtype=torch.float32, device=features.device)
+        check(lib().hvpr_three_interpolate_f32(kernels._ptr(features, torch.float32, "features"), kernels._ptr(idx, torch.int32, "idx"),
+                                               kernels._ptr(weight, torch.float32, "weight"), B, C, m, n, out.data_ptr(),
+                                               kernels._stream()), "hvpr_three_interpolate_f32")
+        ctx.save_for_backward(idx, weight)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        idx, weight = ctx.saved_tensors
+        grad = grad.contiguous()
+        B, C, n = grad.shape
+        gf = torch.empty((B, C, ctx.m), dtype=torch.float32, device=grad.device)
+        check(lib().hvpr_three_interpolate_grad_f32(kernels._ptr(grad, torch.float32, "grad_out"), idx.data_ptr(), weight.data_ptr(),
+                                                    B, C, ctx.m, n, gf.data_ptr(), kernels._stream()), "hvpr_three_interpolate_grad_f32")
+        return gf, None, None
+
+
+def _i32(idx):
+    return (idx if idx.dtype == torch.int32 else idx.to(torch.int32)).contiguous()
+
+
 def gather_operation(features, idx):
-    """features (B,C,N), idx (B,np) -> (B,C,np)."""
-    B, C, _ = features.shape
-    return features.gather(2, idx.long().unsqueeze(1).expand(-1, C, -1))
+    """features (B,C,N), idx (B,np) -> (B,C,np) (hvpr_group_points_f32 with one sample per group)."""
+    return _GroupPoints.apply(features, _i32(idx).unsqueeze(-1)).squeeze(-1)
 
 
 def grouping_operation(features, idx):
-    """features (B,C,N), idx (B,np,ns) -> (B,C,np,ns); backward scatters-adds into (B,C,N)."""
-    B, C, _ = features.shape
-    _, np_, ns = idx.shape
-    flat = idx.long().reshape(B, 1, np_ * ns).expand(-1, C, -1)
-    return features.gather(2, flat).reshape(B, C, np_, ns)
+    """features (B,C,N), idx (B,np,ns) -> (B,C,np,ns); backward scatter-adds into (B,C,N)."""
+    return _GroupPoints.apply(features, _i32(idx))
 
 
 def three_interpolate(features, idx, weight):
     """features (B,C,m), idx (B,n,3), weight (B,n,3) -> (B,C,n)."""
-    B, C, _ = features.shape
-    n = idx.shape[1]
-    g = features.gather(2, idx.long().reshape(B, 1, n * 3).expand(-1, C, -1)).reshape(B, C, n, 3)
-    return (g * weight.unsqueeze(1)).sum(dim=-1)
+    return _ThreeInterpolate.apply(features, _i32(idx), weight.detach())
 
 
 # ------------------------------------------------------------------------------------------------ modules

@@ -251,6 +251,40 @@ int hvpr_three_nn_f32(const float *unknown, const float *known, int B, int n, in
                       hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a9 (training)  Differentiable gathers of the point stream, in the reference's channel-major layout.  Replace
+ *     grouping_operation / gather_operation / three_interpolate (+ their backward) of the absent
+ *     pcdet/ops/pointnet2/pointnet2_batch natives (setup.py:94-109; used by PointnetSAModuleMSG / PointnetFPModule,
+ *     pcdet/models/backbones_3d/pointnet2_backbone.py:27-34,43-47,82,86-89).
+ *     hvpr_group_points_f32:        features [B,C,N], idx [B,npoint,nsample] i32 -> out [B,C,npoint,nsample]
+ *                                   (nsample == 1: gather_operation).
+ *     hvpr_group_points_grad_f32:   grad_out [B,C,npoint,nsample] -> grad_features [B,C,N], overwritten (zeroed, then
+ *                                   scatter-added: fp32 atomics, summation order unspecified).
+ *     hvpr_three_interpolate_f32:   features [B,C,m], idx / weight [B,n,3] -> out [B,C,n] = (f0 w0 + f1 w1) + f2 w2.
+ *     hvpr_three_interpolate_grad_f32: grad_out [B,C,n] -> grad_features [B,C,m], overwritten as above.
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_group_points_f32(const float *features, const int32_t *idx, int B, int C, int N, int npoint, int nsample, float *out,
+                          hvpr_stream_t stream);
+int hvpr_group_points_grad_f32(const float *grad_out, const int32_t *idx, int B, int C, int N, int npoint, int nsample,
+                               float *grad_features, hvpr_stream_t stream);
+int hvpr_three_interpolate_f32(const float *features, const int32_t *idx, const float *weight, int B, int C, int m, int n,
+                               float *out, hvpr_stream_t stream);
+int hvpr_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx, const float *weight, int B, int C, int m, int n,
+                                    float *grad_features, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a14 (training)  Optimiser step over ONE flat fp32 parameter buffer (and matching flat gradient / moment buffers, all
+ *     16-byte aligned): decoupled weight decay p *= 1 - weight_decay * lr, then Adam with bias correction at `step` (1-based)
+ *     — OptimWrapper.step, tools/train_utils/optimization/fastai_optim.py:132-149 (true_wd, the optimiser's own weight_decay
+ *     forced to 0) around torch.optim.Adam(betas = (beta1, beta2)).  grad_scale_device (may be NULL): a device float every
+ *     gradient is multiplied by first — the clip coefficient min(1, clip / (||g|| + 1e-6)) of
+ *     clip_grad_norm_ (tools/train_utils/train_utils.py:41), so that clipping costs no extra pass and no host sync.
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_fused_adam_truewd_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long long n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int step,
+                               const float *grad_scale_device, hvpr_stream_t stream);
+
+
+/* ---------------------------------------------------------------------------------------------
  * a5 optional precision modes: 3x3 convolutions on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation)
  *     with split operands.  n_planes = 2 ("bf16x3"): x = hi + lo, x*w ~= hi*hi + hi*lo + lo*hi, error ~2^-16 relative per
  *     product — SURVEY.md §8d allows a reduced-precision path evidenced within the 1e-3 tolerance.  n_planes = 3 ("bf16x6"):

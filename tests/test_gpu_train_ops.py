@@ -1,0 +1,110 @@
+"""GPU: the training exports of SURVEY.md §8b that replace torch ops — grouping / gather / three-interpolate with their
+backward (vs differentiable torch gathers of the same definition) and the fused flat Adam-onecycle step (vs fixture G9 from
+the reference's OptimWrapper + OneCycle, and vs the per-tensor AdamOneCycle)."""
+import numpy as np
+import pytest
+import torch
+
+import train_fixture_cases as C
+from hvpr_amd import optim, pointnet2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _torch_group(features, idx):
+    B, Cc, _ = features.shape
+    _, np_, ns = idx.shape
+    return features.gather(2, idx.long().reshape(B, 1, np_ * ns).expand(-1, Cc, -1)).reshape(B, Cc, np_, ns)
+
+
+def _torch_interp(features, idx, weight):
+    B, Cc, _ = features.shape
+    n = idx.shape[1]
+    g = features.gather(2, idx.long().reshape(B, 1, n * 3).expand(-1, Cc, -1)).reshape(B, Cc, n, 3)
+    return (g * weight.unsqueeze(1)).sum(dim=-1)
+
+
+@pytest.mark.parametrize("B,Cc,N,np_,ns", [(2, 4, 500, 64, 16), (1, 67, 4096, 1024, 32), (3, 1, 33, 7, 1), (2, 131, 100, 1, 5)])
+def test_group_points_forward_and_backward(B, Cc, N, np_, ns):
+    g = torch.Generator().manual_seed(B * 1000 + Cc)
+    f = torch.randn(B, Cc, N, generator=g).to(DEV).requires_grad_(True)
+    idx = torch.randint(0, N, (B, np_, ns), generator=g, dtype=torch.int32).to(DEV)
+    idx[:, 0, :] = 5 % N                                   # heavy duplicates: the backward accumulates
+    out = pointnet2.grouping_operation(f, idx)
+    ref = _torch_group(f.detach().clone().requires_grad_(True), idx)
+    assert torch.equal(out, ref)                           # a gather: bit-exact
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    (gf,) = torch.autograd.grad(out, f, go)
+    f2 = f.detach().clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad(_torch_group(f2, idx), f2, go)
+    np.testing.assert_allclose(gf.cpu().numpy(), gr.cpu().numpy(), rtol=1e-5, atol=1e-5)      # atomics: order differs
+    # gather_operation = one sample per group
+    i1 = idx[:, :, 0].contiguous()
+    assert torch.equal(pointnet2.gather_operation(f, i1), f.gather(2, i1.long().unsqueeze(1).expand(-1, Cc, -1)))
+
+
+@pytest.mark.parametrize("B,Cc,m,n", [(2, 128, 1024, 4096), (1, 5, 10, 300), (2, 64, 4096, 16384)])
+def test_three_interpolate_forward_and_backward(B, Cc, m, n):
+    g = torch.Generator().manual_seed(m + n)
+    f = torch.randn(B, Cc, m, generator=g).to(DEV).requires_grad_(True)
+    idx = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    w = torch.rand(B, n, 3, generator=g).to(DEV)
+    w = w / w.sum(-1, keepdim=True)
+    out = pointnet2.three_interpolate(f, idx, w)
+    f2 = f.detach().clone().requires_grad_(True)
+    ref = _torch_interp(f2, idx, w)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    (gf,) = torch.autograd.grad(out, f, go)
+    (gr,) = torch.autograd.grad(ref, f2, go)
+    np.testing.assert_allclose(gf.cpu().numpy(), gr.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_fused_adam_reproduces_fixture_g9(golden_dir):
+    """Fixture G9 = 100 one-cycle steps + 3 optimiser steps of the reference's OptimWrapper(Adam, true_wd) + OneCycle, here
+    through hvpr_fused_adam_truewd_f32 on one flat buffer."""
+    made = []
+
+    def make(net, wd):
+        made.append(optim.FusedAdamOneCycle(net, wd=wd))
+        return made[-1]
+    C.run_g9(golden_dir, DEV, rtol=1e-4, make_optimizer=make)
+    assert made and made[0].steps == 3
+
+
+def test_fused_adam_equals_per_tensor_adam_with_clipping_and_checkpoint_interop():
+    torch.manual_seed(0)
+
+    def net():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 17, 3, bias=False), torch.nn.BatchNorm2d(17), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(17, 5, 1), torch.nn.Flatten(), torch.nn.Linear(5 * 6 * 6, 3)).to(DEV)
+    a, b = net(), net()
+    oa, ob = optim.AdamOneCycle(a, wd=0.01), optim.FusedAdamOneCycle(b, wd=0.01)
+    sa, sb = optim.OneCycle(oa, 20, 0.003, [0.95, 0.85], 10, 0.4), optim.OneCycle(ob, 20, 0.003, [0.95, 0.85], 10, 0.4)
+    xs = torch.randn(8, 4, 3, 8, 8, device=DEV) * 30       # large inputs: the 0.5 clip is active
+
+    def step(m, o, s, it, x):
+        s.step(it)
+        m.train(); o.zero_grad()
+        m(x).pow(2).mean().backward()
+        if hasattr(o, "clip_grad_norm"):
+            o.clip_grad_norm(0.5)
+        else:
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 0.5)
+        o.step()
+    for it in range(5):
+        step(a, oa, sa, it, xs[it]); step(b, ob, sb, it, xs[it])
+        for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+            np.testing.assert_allclose(v.float().cpu().numpy(), w.float().cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=f"step {it} {k}")
+    # checkpoints move between the two forms (torch.optim.Adam's state-dict layout in the same parameter order)
+    c, d = net(), net()
+    c.load_state_dict(b.state_dict()); d.load_state_dict(b.state_dict())
+    oc, od = optim.AdamOneCycle(c, wd=0.01), optim.FusedAdamOneCycle(d, wd=0.01)
+    oc.load_state_dict(ob.state_dict()); od.load_state_dict(oa.state_dict())
+    sc, sd = optim.OneCycle(oc, 20, 0.003, [0.95, 0.85], 10, 0.4), optim.OneCycle(od, 20, 0.003, [0.95, 0.85], 10, 0.4)
+    step(a, oa, sa, 5, xs[5]); step(c, oc, sc, 5, xs[5]); step(d, od, sd, 5, xs[5])
+    for (k, v), (_, w), (_, u) in zip(a.state_dict().items(), c.state_dict().items(), d.state_dict().items()):
+        np.testing.assert_allclose(v.float().cpu().numpy(), w.float().cpu().numpy(), rtol=5e-5, atol=1e-7, err_msg="fused -> torch " + k)
+        np.testing.assert_allclose(v.float().cpu().numpy(), u.float().cpu().numpy(), rtol=5e-5, atol=1e-7, err_msg="torch -> fused " + k)
