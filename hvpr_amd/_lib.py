@@ -48,6 +48,12 @@ SIGNATURES = {
     "hvpr_group_points_grad_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hvpr_three_interpolate_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "hvpr_three_interpolate_grad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "hvpr_conv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "hvpr_conv2d_wgrad_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _Z, _P]),
+    "hvpr_bn_workspace_bytes": (_Z, [_c.c_longlong, _I]),
+    "hvpr_bn_stats_nhwc_f32": (_I, [_P, _c.c_longlong, _I, _F, _P, _P, _P, _P, _Z, _P]),
+    "hvpr_bn_relu_fwd_nhwc_f32": (_I, [_P, _c.c_longlong, _I, _P, _P, _I, _P, _P]),
+    "hvpr_bn_relu_bwd_nhwc_f32": (_I, [_P, _P, _c.c_longlong, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "hvpr_fused_adam_truewd_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _F, _F, _F, _F, _F, _I, _P, _P]),
     "hvpr_split_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),
     "hvpr_unsplit_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),

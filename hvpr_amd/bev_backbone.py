@@ -178,7 +178,14 @@ class BaseBEVBackbone_Scale(nn.Module):
     def _forward_train(self, data_dict):
         """Training forward, base_bev_backbone.py:228-279: the memory-fed and the point-fed canvases go through the SAME
         weights (two streams, shared scale stream); BatchNorm uses batch statistics and every call of a shared BN layer
-        updates its running statistics.  Dense math through torch (MIOpen) with autograd."""
+        updates its running statistics.
+
+        Default (GPU): the library's own kernels through hvpr_amd.conv_train — forward / data-gradient convolutions on
+        hvpr_conv2d_nhwc_f32, weight gradients on hvpr_conv2d_wgrad_nhwc_f32, train-mode BatchNorm + ReLU on the hvpr_bn_*
+        kernels, NHWC activations end to end.  HVPR_TRAIN_CONV=torch keeps the torch (MIOpen) autograd form, the parity
+        reference of tests/test_gpu_conv_train.py."""
+        if data_dict["spatial_features"].is_cuda and os.environ.get("HVPR_TRAIN_CONV", "hip") != "torch":
+            return self._forward_train_hip(data_dict)
         x, xp, y = data_dict["spatial_features"], data_dict["spatial_features_point"], data_dict["spatial_scale_features"]
         ups, ups_p = [], []
         for i in range(len(self.blocks)):
@@ -191,6 +198,50 @@ class BaseBEVBackbone_Scale(nn.Module):
             ups_p.append(self.deblocks[i](xpa))
         data_dict["spatial_features_2d"] = torch.cat(ups, dim=1)
         data_dict["spatial_features_point_2d"] = torch.cat(ups_p, dim=1)
+        return data_dict
+
+    def _forward_train_hip(self, data_dict):
+        from . import conv_train as ct
+
+        def nhwc(t):
+            return t.permute(0, 2, 3, 1).contiguous()          # no copy for the channels_last canvases of the scatter
+
+        def cbr(seq, t):
+            """Sequential of [ZeroPad2d(1)?, Conv2d 3x3 (no bias), BatchNorm2d, ReLU] groups (:154-169, :171-175, :200-209): the
+            explicit zero pad + pad-0 conv of the strided entries is the same pad-1 convolution."""
+            mods, k = list(seq), 0
+            while k < len(mods):
+                if isinstance(mods[k], nn.ZeroPad2d):
+                    k += 1
+                conv, bn = mods[k], mods[k + 1]
+                t = ct.bn_relu(ct.conv(t, conv.weight, conv.stride[0]), bn)
+                k += 3
+            return t
+
+        def gate(pooled):
+            """SpatialAttention on the pooled scale stream (spatial_attention.py:57-63): a 2 -> 1 channel 3x3 conv + BatchNorm +
+            sigmoid on a (N,2,H,W) tensor — left to torch; called once per use, as the reference does, so that its BatchNorm
+            sees the same number of running-statistics updates."""
+            sp = self.attention.spatial
+            return torch.sigmoid(sp.norm(sp.conv(pooled))).permute(0, 2, 3, 1)       # (N,H,W,1)
+
+        x, xp = nhwc(data_dict["spatial_features"]), nhwc(data_dict["spatial_features_point"])
+        y = nhwc(data_dict["spatial_scale_features"])
+        ups, ups_p = [], []
+        for i in range(len(self.blocks)):
+            x = cbr(self.blocks[i], x)
+            xp = cbr(self.blocks[i], xp)
+            y = cbr(self.scale_layers[i], y)
+            pooled = torch.cat((y.amax(dim=-1, keepdim=True), y.mean(dim=-1, keepdim=True)), dim=-1).permute(0, 3, 1, 2)
+            xa, xpa = x, xp
+            for _ in range(self.sfm_layer_nums[i]):
+                xa = gate(pooled) * cbr(self.sfmblocks_down[i], xa) + xa
+                xpa = gate(pooled) * cbr(self.sfmblocks_down[i], xpa) + xpa
+            de = self.deblocks[i]
+            ups.append(ct.bn_relu(ct.deconv(xa, de[0].weight), de[1]))
+            ups_p.append(ct.bn_relu(ct.deconv(xpa, de[0].weight), de[1]))
+        data_dict["spatial_features_2d"] = torch.cat(ups, dim=-1).permute(0, 3, 1, 2)          # (B, 384, H, W), channels_last
+        data_dict["spatial_features_point_2d"] = torch.cat(ups_p, dim=-1).permute(0, 3, 1, 2)
         return data_dict
 
     def forward(self, data_dict):

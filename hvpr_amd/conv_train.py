@@ -1,0 +1,171 @@
+"""Training-mode convolution + BatchNorm + ReLU of the BEV backbone on the library's own kernels (SURVEY.md §8a row a11;
+reference: BaseBEVBackbone_Scale.forward in training mode, pcdet/models/backbones_2d/base_bev_backbone.py:228-279).
+
+Activations are NHWC tensors (N, H, W, C) — what torch calls channels_last — end to end.  Three autograd.Functions:
+
+  conv3x3 / conv1x1   forward  hvpr_conv2d_nhwc_f32 (fp32 matrix cores, raw output: no bias, no activation)
+                      dgrad    the same kernel on the flipped + transposed weights (stride 2: on the zero-upsampled gradient)
+                      wgrad    hvpr_conv2d_wgrad_nhwc_f32 (split-K over pixel tiles, deterministic)
+  deconv (k == s)     forward  the 1x1 GEMM with s*s*Cout columns + pixel shuffle in the epilogue (ConvTranspose2d, :177-188)
+                      backward 1x1 dgrad / wgrad on the space-to-depth view of the gradient
+  bn_relu             train-mode BatchNorm (batch statistics, differentiated through) + ReLU: hvpr_bn_stats_nhwc_f32,
+                      hvpr_bn_relu_fwd_nhwc_f32, hvpr_bn_relu_bwd_nhwc_f32; running statistics updated like nn.BatchNorm2d
+                      (momentum, unbiased variance, one update per CALL — SURVEY.md B.5).
+"""
+import torch
+
+from . import kernels
+from ._lib import check, lib
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """One grow-only scratch buffer per device: every kernel that takes it consumes it before the next one is enqueued on the
+    same stream (the training step runs on one stream)."""
+    buf = _ws_cache.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[device] = buf
+    return buf
+
+
+def _tile_cfg(cout):
+    return 0 if cout % 128 == 0 else 1        # 128 x 128 tiles win from batch 2 up; narrow layers keep 64 x 64
+
+
+def conv_fwd_raw(x, weight, stride=1):
+    """x (N,H,W,Cin) -> conv(x, weight) (N,OH,OW,Cout), no bias / activation.  weight (Cout,Cin,k,k), k in {1,3}, pad (k-1)/2."""
+    pc = kernels.pack_conv(weight, None, None, stride=stride, relu=False, tile_cfg=_tile_cfg(weight.shape[0]))
+    return kernels.conv2d_nhwc(x, pc)
+
+
+def conv_wgrad(x, dz, taps, stride, cout, cin):
+    N, H, W, _ = x.shape
+    OH, OW = dz.shape[1], dz.shape[2]
+    k = 3 if taps == 9 else 1
+    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
+    nbytes = lib().hvpr_conv2d_wgrad_workspace_bytes(N, OH, OW, cin, cout, taps, stride)
+    ws = _workspace(nbytes, x.device)
+    check(lib().hvpr_conv2d_wgrad_nhwc_f32(kernels._ptr(x, torch.float32, "x"), N, H, W, cin, kernels._ptr(dz, torch.float32, "dz"),
+                                           cout, taps, stride, dw.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()),
+          "hvpr_conv2d_wgrad_nhwc_f32")
+    return dw
+
+
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.stride = stride
+        return conv_fwd_raw(x, weight, stride)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight = ctx.saved_tensors
+        dz = dz.contiguous()
+        cout, cin, k, _ = weight.shape
+        s = ctx.stride
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().permute(1, 0, 2, 3).flip(2, 3)                 # (Cin, Cout, k, k): the adjoint kernel
+            if s == 1:
+                dx = conv_fwd_raw(dz, wt, 1)
+            else:            # y[o] = sum x[2 o + k - 1] w[k]  =>  dx = conv_stride1(zero-upsampled dz, flipped w)
+                N, H, W, _ = x.shape
+                OH, OW = dz.shape[1], dz.shape[2]
+                up = torch.zeros((N, H, W, cout), dtype=torch.float32, device=dz.device)
+                up[:, 0:2 * OH:2, 0:2 * OW:2] = dz
+                dx = conv_fwd_raw(up, wt, 1)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, dz, k * k, s, cout, cin)
+        return dx, dw, None
+
+
+class _Deconv(torch.autograd.Function):
+    """ConvTranspose2d(kernel == stride == s, no bias): x (N,H,W,Cin), weight (Cin,Cout,s,s) -> (N,H*s,W*s,Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        cin, cout, s, _ = weight.shape
+        ones, zeros = torch.ones(cout, device=x.device), torch.zeros(cout, device=x.device)
+        pc = kernels.pack_deconv(weight, ones, zeros, relu=False, tile_cfg=1 if s < 4 else 2)
+        ctx.save_for_backward(x, weight)
+        return kernels.conv2d_nhwc(x, pc)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight = ctx.saved_tensors
+        cin, cout, s, _ = weight.shape
+        N, H, W, _ = x.shape
+        # space-to-depth: column (sy * s + sx) * Cout + co of pixel (y, x) = dz[y * s + sy][x * s + sx][co]
+        cols = s * s * cout
+        dzs = dz.reshape(N, H, s, W, s, cout).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, cols).contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            g = weight.detach().permute(0, 2, 3, 1).reshape(cin, cols, 1, 1)     # dx[ci] = sum_col dzs[col] * g[ci][col]
+            dx = conv_fwd_raw(dzs, g, 1)
+        if ctx.needs_input_grad[1]:
+            dg = conv_wgrad(x, dzs, 1, 1, cols, cin)                              # (cols, Cin, 1, 1)
+            dw = dg.reshape(s, s, cout, cin).permute(3, 2, 0, 1).contiguous()
+        return dx, dw
+
+
+class _BNReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, eps, relu):
+        z = z.contiguous()
+        C = z.shape[-1]
+        P = z.numel() // C
+        dev = z.device
+        mean, var, invstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
+        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), dev)
+        check(lib().hvpr_bn_stats_nhwc_f32(kernels._ptr(z, torch.float32, "z"), P, C, float(eps), mean.data_ptr(), var.data_ptr(),
+                                           invstd.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_stats_nhwc_f32")
+        scale = (gamma.detach() * invstd).contiguous()
+        shift = (beta.detach() - mean * scale).contiguous()
+        y = torch.empty_like(z)
+        check(lib().hvpr_bn_relu_fwd_nhwc_f32(z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(), 1 if relu else 0, y.data_ptr(),
+                                              kernels._stream()), "hvpr_bn_relu_fwd_nhwc_f32")
+        ctx.save_for_backward(z, scale, shift, mean, invstd)
+        ctx.relu = relu
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        z, scale, shift, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = z.shape[-1]
+        P = z.numel() // C
+        dz = torch.empty_like(z)
+        dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
+        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), z.device)
+        check(lib().hvpr_bn_relu_bwd_nhwc_f32(kernels._ptr(dy, torch.float32, "dy"), z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(),
+                                              mean.data_ptr(), invstd.data_ptr(), 1 if ctx.relu else 0, dz.data_ptr(), dgamma.data_ptr(),
+                                              dbeta.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_relu_bwd_nhwc_f32")
+        return dz, dgamma, dbeta, None, None
+
+
+def conv(x, weight, stride=1):
+    """3x3 (pad 1) or 1x1 convolution without bias on NHWC activations, differentiable in x and weight."""
+    return _Conv.apply(x, weight, int(stride))
+
+
+def deconv(x, weight):
+    return _Deconv.apply(x, weight)
+
+
+def bn_relu(z, bn, relu=True):
+    """Train-mode nn.BatchNorm2d `bn` (its weight / bias / eps / momentum / running buffers) + optional ReLU on NHWC `z`."""
+    y, mean, var = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu)
+    if bn.track_running_stats:
+        with torch.no_grad():
+            n = z.numel() // z.shape[-1]
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
+    return y

@@ -1,0 +1,368 @@
+// a11 (training) — the pieces of the two-stream BEV backbone's training step that are not the forward implicit GEMM:
+//   * weight gradient of the 3x3 (stride 1 | 2, pad 1) and 1x1 convolutions on the fp32 matrix cores, split-K over pixel
+//     tiles with a deterministic two-stage reduction (hvpr_conv2d_wgrad_nhwc_f32),
+//   * train-mode BatchNorm + ReLU over NHWC activations: batch statistics, normalise + ReLU, and the two backward passes
+//     (per-channel reductions, then dz) — four bandwidth-bound kernels instead of torch's chain of element-wise launches.
+// Together with hvpr_conv2d_nhwc_f32 (forward; data gradient = the same kernel on flipped / transposed weights) they carry
+// BaseBEVBackbone_Scale.forward in training mode, pcdet/models/backbones_2d/base_bev_backbone.py:228-279 (conv + BN + ReLU
+// blocks :154-169, SFM steps :171-175, deblocks :177-188, scale layers :200-209).
+//
+// Weight gradient as a GEMM: dW[tap][co][ci] = sum_pixels dz[p][co] * x[p shifted by tap][ci]  — M = co, N = ci, K = pixels.
+// Both operands are pixel-major (NHWC), which is exactly what v_mfma_f32_32x32x2_f32 wants: a lane supplies ONE float per
+// operand, A[i = lane & 31][k = lane >> 5] and B[k][j = lane & 31] with k = the pixel of a pair — 32 consecutive channels of
+// one pixel per half-wave, a conflict-free ds_read_b32.  A workgroup (4 waves, 2 x 2) owns a (64 MB) x (64 NB) block of
+// (co, ci) for ALL taps and walks its share of the pixel tiles: the dz tile and the input halo patch of a tile are staged
+// once in LDS and feed TAPS x MB x NB accumulators per wave, so the arithmetic intensity is that of the forward kernel.
+// The pixel loop is fully unrolled: every LDS address is lane base + immediate, no vector-ALU instruction between the MFMAs
+// (fp32 MFMA issues on the vector ALU lanes — conv_igemm.hip).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float *x;     // [N, H, W, Cin]
+    const float *dz;    // [N, OH, OW, Cout]
+    float *part;        // [n_chunks][TAPS][Cout][Cin] partial sums
+    int N, H, W, Cin, OH, OW, Cout;
+    int tiles_x, tiles_y, n_pt, n_chunks, n_ci_tiles;
+};
+
+template <int TAPS, int S, int TH, int TW, int MB, int NB>
+__global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
+    constexpr int BM = 64 * MB, BN = 64 * NB;                 // co x ci block of the workgroup
+    constexpr int HALO = TAPS == 9 ? 2 : 0;
+    constexpr int PH = (TH - 1) * S + 1 + HALO, PW = (TW - 1) * S + 1 + HALO;
+    constexpr int NPX = TH * TW, NPP = PH * PW;
+    constexpr int DZ_V4 = NPX * BM / 4, X_V4 = NPP * BN / 4;
+    constexpr int NLD_D = (DZ_V4 + 255) / 256, NLD_X = (X_V4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float s_dz[NPX * BM];
+    __shared__ __attribute__((aligned(16))) float s_x[NPP * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
+    const int ot = blockIdx.x, chunk = blockIdx.y;
+    const int co0 = (ot / a.n_ci_tiles) * BM, ci0 = (ot % a.n_ci_tiles) * BN;
+
+    f32x16 acc[TAPS][MB][NB];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][mb][nb][r] = 0.f;
+
+    float4 rd[NLD_D], rx[NLD_X];
+    auto fetch = [&](int pt) {          // global -> registers (zeros outside the image / past the channel counts)
+        const int tx = pt % a.tiles_x, ty = (pt / a.tiles_x) % a.tiles_y, n = pt / (a.tiles_x * a.tiles_y);
+        const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - HALO / 2, ix0 = ox0 * S - HALO / 2;
+#pragma unroll
+        for (int i = 0; i < NLD_D; ++i) {
+            const int v = tid + i * 256, px = v / (BM / 4), c4 = (v % (BM / 4)) * 4;
+            const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+            const bool ok = v < DZ_V4 && oy < a.OH && ox < a.OW && co0 + c4 < a.Cout;
+            rd[i] = ok ? *(const float4 *)(a.dz + (((size_t)n * a.OH + oy) * a.OW + ox) * a.Cout + co0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD_X; ++i) {
+            const int v = tid + i * 256, px = v / (BN / 4), c4 = (v % (BN / 4)) * 4;
+            const int iy = iy0 + px / PW, ix = ix0 + px % PW;
+            const bool ok = v < X_V4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + c4 < a.Cin;
+            rx[i] = ok ? *(const float4 *)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.Cin + ci0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {               // registers -> LDS
+#pragma unroll
+        for (int i = 0; i < NLD_D; ++i) {
+            const int v = tid + i * 256;
+            if (v < DZ_V4) *(float4 *)(s_dz + v * 4) = rd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NLD_X; ++i) {
+            const int v = tid + i * 256;
+            if (v < X_V4) *(float4 *)(s_x + v * 4) = rx[i];
+        }
+    };
+
+    // lane bases: everything else in the unrolled pixel loop is an immediate offset
+    const float *pa = s_dz + half * BM + wm * (32 * MB) + l31;           // + (even pixel of the pair) * BM + mb * 32
+    const float *pb = s_x + half * (S * BN) + wn * (32 * NB) + l31;      // + patch pixel of the even one * BN + nb * 32
+    int pt = chunk;
+    if (pt < a.n_pt) fetch(pt);
+    for (; pt < a.n_pt; pt += a.n_chunks) {
+        __syncthreads();                 // everybody is done reading the previous tile
+        commit();
+        __syncthreads();
+        if (pt + a.n_chunks < a.n_pt) fetch(pt + a.n_chunks);   // the next tile travels while this one multiplies
+#pragma unroll
+        for (int m = 0; m < NPX / 2; ++m) {
+            // pixel of this lane half: q = 2m + half.  TW is even, so both pixels of a pair sit in the same tile row.
+            const int qy = (2 * m) / TW, qx0 = (2 * m) % TW;
+            float av[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = pa[(2 * m) * BM + mb * 32];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                float bv[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    bv[nb] = pb[((qy * S + ky) * PW + qx0 * S + kx) * BN + nb * 32];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[t][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb], acc[t][mb][nb], 0, 0, 0);
+            }
+        }
+    }
+    // partial sums of this chunk: [chunk][tap][co][ci], ci contiguous across the 32 lanes of a half-wave
+    // C/D map of 32x32: column (ci) = lane & 31, row (co) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float *out = a.part + (size_t)chunk * TAPS * a.Cout * a.Cin;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int ci = ci0 + wn * (32 * NB) + nb * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm * (32 * MB) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < a.Cout && ci < a.Cin) out[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[t][mb][nb][r];
+                }
+            }
+}
+
+// dW[co][ci][tap] (torch's (Cout, Cin, k, k) layout) = sum over chunks of part[chunk][tap][co][ci], in chunk order
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ part, int n_chunks, int taps, int Cout, int Cin,
+                                                      float *__restrict__ dw) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // over [tap][co][ci]
+    const long long per = (long long)taps * Cout * Cin;
+    if (i >= per) return;
+    float s = 0.f;
+    for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * per + i];
+    const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), t = (int)(i / ((long long)Cin * Cout));
+    dw[((size_t)co * Cin + ci) * taps + t] = s;
+}
+
+template <int TAPS, int S, int TH, int TW, int MB, int NB>
+int launch_wgrad(WgradArgs a, int target_wgs, hipStream_t s) {
+    a.tiles_x = (a.OW + TW - 1) / TW;
+    a.tiles_y = (a.OH + TH - 1) / TH;
+    a.n_pt = a.N * a.tiles_x * a.tiles_y;
+    a.n_ci_tiles = (a.Cin + 64 * NB - 1) / (64 * NB);
+    const int n_ot = a.n_ci_tiles * ((a.Cout + 64 * MB - 1) / (64 * MB));
+    hipLaunchKernelGGL((k_wgrad<TAPS, S, TH, TW, MB, NB>), dim3(n_ot, a.n_chunks), dim3(256), 0, s, a);
+    (void)target_wgs;
+    return 0;
+}
+
+int wgrad_chunks(int N, int OH, int OW, int Cin, int Cout, int taps, int stride) {
+    const int th = (taps == 9 && stride == 1) ? 8 : 4, tw = 8;
+    const long long n_pt = (long long)N * ((OH + th - 1) / th) * ((OW + tw - 1) / tw);
+    const int bm = taps == 9 ? 64 : 128;
+    const int n_ot = ((Cin + bm - 1) / bm) * ((Cout + bm - 1) / bm);
+    long long chunks = (512 + n_ot - 1) / n_ot;                 // ~2 workgroups per CU
+    if (chunks > n_pt) chunks = n_pt;
+    if (chunks < 1) chunks = 1;
+    return (int)chunks;
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm + ReLU (NHWC)
+// z [P, C] with C % 4 == 0.  A workgroup of 256 threads covers C/4 channel groups x (256 / (C/4)) pixel lanes and walks a
+// slab of pixels; per-thread fp32 partial sums over <= kSlab / lanes pixels, combined per workgroup in LDS in a fixed order,
+// one row per workgroup in the workspace, final sum in double by the finalising kernel: deterministic.
+constexpr int kBnSlab = 2048;       // pixels per workgroup
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bn_reduce(const float *__restrict__ z, const float *__restrict__ dy, long long P, int C,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                                                   float *__restrict__ ws /* [blocks][2][C] */) {
+    __shared__ float4 s_a[256], s_b[256];
+    const int groups = C / 4;                       // channel groups of 4
+    const int lanes = 256 / groups > 0 ? 256 / groups : 1;     // pixel lanes per workgroup (groups <= 256)
+    const int g = threadIdx.x % groups, pl = threadIdx.x / groups;
+    const long long p0 = (long long)blockIdx.x * kBnSlab;
+    const long long p1 = p0 + kBnSlab < P ? p0 + kBnSlab : P;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
+    if (pl < lanes) {
+        float4 sc = A, sh = A, mu = A, is = A;
+        if (BWD) { sc = *(const float4 *)(scale + 4 * g); sh = *(const float4 *)(shift + 4 * g); mu = *(const float4 *)(mean + 4 * g); is = *(const float4 *)(invstd + 4 * g); }
+        for (long long p = p0 + pl; p < p1; p += lanes) {
+            const float4 v = *(const float4 *)(z + p * C + 4 * g);
+            if (!BWD) {     // sum, sum of squares
+                A.x += v.x; A.y += v.y; A.z += v.z; A.w += v.w;
+                B.x = fmaf(v.x, v.x, B.x); B.y = fmaf(v.y, v.y, B.y); B.z = fmaf(v.z, v.z, B.z); B.w = fmaf(v.w, v.w, B.w);
+            } else {        // s1 = sum dy * mask, s2 = sum dy * mask * xhat; mask = the ReLU passed (scale * z + shift > 0)
+                float4 d = *(const float4 *)(dy + p * C + 4 * g);
+                if (relu) {
+                    if (!(fmaf(v.x, sc.x, sh.x) > 0.f)) d.x = 0.f;
+                    if (!(fmaf(v.y, sc.y, sh.y) > 0.f)) d.y = 0.f;
+                    if (!(fmaf(v.z, sc.z, sh.z) > 0.f)) d.z = 0.f;
+                    if (!(fmaf(v.w, sc.w, sh.w) > 0.f)) d.w = 0.f;
+                }
+                A.x += d.x; A.y += d.y; A.z += d.z; A.w += d.w;
+                B.x = fmaf(d.x, (v.x - mu.x) * is.x, B.x); B.y = fmaf(d.y, (v.y - mu.y) * is.y, B.y);
+                B.z = fmaf(d.z, (v.z - mu.z) * is.z, B.z); B.w = fmaf(d.w, (v.w - mu.w) * is.w, B.w);
+            }
+        }
+    }
+    s_a[threadIdx.x] = A; s_b[threadIdx.x] = B;
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        for (int l = 0; l < lanes; ++l) {
+            const float4 x = s_a[l * groups + g], y = s_b[l * groups + g];
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+        }
+        float *row = ws + (size_t)blockIdx.x * 2 * C;
+        *(float4 *)(row + 4 * g) = a;
+        *(float4 *)(row + C + 4 * g) = b;
+    }
+}
+
+// fwd: mean, biased variance and 1/sqrt(var + eps) per channel; bwd: s1, s2 per channel.  One thread per channel, double sums.
+__global__ void __launch_bounds__(256) k_bn_finalize(const float *__restrict__ ws, int blocks, int C, double count, float eps, int bwd,
+                                                     float *__restrict__ o0, float *__restrict__ o1, float *__restrict__ o2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < blocks; ++i) { a += (double)ws[(size_t)i * 2 * C + c]; b += (double)ws[(size_t)i * 2 * C + C + c]; }
+    if (bwd) { o0[c] = (float)a; o1[c] = (float)b; return; }
+    const double m = a / count;
+    double var = b / count - m * m;
+    if (var < 0.0) var = 0.0;
+    o0[c] = (float)m; o1[c] = (float)var; o2[c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = relu(z * scale + shift)   (scale = gamma * invstd, shift = beta - mean * scale)
+__global__ void __launch_bounds__(256) k_bn_apply(const float4 *__restrict__ z, long long n4, int groups, const float *__restrict__ scale,
+                                                  const float *__restrict__ shift, int relu, float4 *__restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const float4 sc = *(const float4 *)(scale + 4 * g), sh = *(const float4 *)(shift + 4 * g);
+        const float4 v = z[i];
+        float4 r = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        y[i] = r;
+    }
+}
+
+// dz = scale * (dy_m - s1 / n - xhat * s2 / n),  dy_m = dy where the ReLU passed, else 0
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4 *__restrict__ dy, const float4 *__restrict__ z, long long n4, int groups,
+                                                      const float *__restrict__ scale, const float *__restrict__ shift,
+                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                      const float *__restrict__ s1, const float *__restrict__ s2, float inv_n, int relu,
+                                                      float4 *__restrict__ dz) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const float4 sc = *(const float4 *)(scale + 4 * g), sh = *(const float4 *)(shift + 4 * g);
+        const float4 mu = *(const float4 *)(mean + 4 * g), is = *(const float4 *)(invstd + 4 * g);
+        const float4 a1 = *(const float4 *)(s1 + 4 * g), a2 = *(const float4 *)(s2 + 4 * g);
+        const float4 v = z[i];
+        float4 d = dy[i];
+        if (relu) {
+            if (!(fmaf(v.x, sc.x, sh.x) > 0.f)) d.x = 0.f;
+            if (!(fmaf(v.y, sc.y, sh.y) > 0.f)) d.y = 0.f;
+            if (!(fmaf(v.z, sc.z, sh.z) > 0.f)) d.z = 0.f;
+            if (!(fmaf(v.w, sc.w, sh.w) > 0.f)) d.w = 0.f;
+        }
+        float4 r;
+        r.x = sc.x * (d.x - a1.x * inv_n - (v.x - mu.x) * is.x * (a2.x * inv_n));
+        r.y = sc.y * (d.y - a1.y * inv_n - (v.y - mu.y) * is.y * (a2.y * inv_n));
+        r.z = sc.z * (d.z - a1.z * inv_n - (v.z - mu.z) * is.z * (a2.z * inv_n));
+        r.w = sc.w * (d.w - a1.w * inv_n - (v.w - mu.w) * is.w * (a2.w * inv_n));
+        dz[i] = r;
+    }
+}
+
+int bn_blocks(long long P) { return (int)((P + kBnSlab - 1) / kBnSlab); }
+
+}  // namespace
+
+extern "C" size_t hvpr_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int taps, int stride) {
+    if (N < 1 || OH < 1 || OW < 1 || Cin < 1 || Cout < 1 || (taps != 9 && taps != 1)) return 0;
+    return (size_t)wgrad_chunks(N, OH, OW, Cin, Cout, taps, stride) * taps * Cout * Cin * sizeof(float);
+}
+
+extern "C" int hvpr_conv2d_wgrad_nhwc_f32(const float *x, int N, int H, int W, int Cin, const float *dz, int Cout, int taps, int stride,
+                                          float *dw, void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
+    if (!x || !dz || !dw || !workspace || N < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return HVPR_ERR_INVALID_ARG;
+    if ((taps != 9 && taps != 1) || (stride != 1 && stride != 2) || (taps == 1 && stride != 1)) return HVPR_ERR_UNSUPPORTED;
+    if (Cin % 4 != 0 || Cout % 4 != 0) return HVPR_ERR_UNSUPPORTED;
+    WgradArgs a;
+    a.x = x; a.dz = dz; a.part = (float *)workspace;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.OH = taps == 9 ? (H + 2 - 3) / stride + 1 : H;
+    a.OW = taps == 9 ? (W + 2 - 3) / stride + 1 : W;
+    a.n_chunks = wgrad_chunks(N, a.OH, a.OW, Cin, Cout, taps, stride);
+    if (workspace_bytes < hvpr_conv2d_wgrad_workspace_bytes(N, a.OH, a.OW, Cin, Cout, taps, stride)) return HVPR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (taps == 9 && stride == 1) launch_wgrad<9, 1, 8, 8, 1, 1>(a, 512, s);
+    else if (taps == 9) launch_wgrad<9, 2, 4, 8, 1, 1>(a, 512, s);
+    else launch_wgrad<1, 1, 4, 8, 2, 2>(a, 512, s);
+    const long long per = (long long)taps * Cout * Cin;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(hvpr_cdiv(per, 256)), dim3(256), 0, s, a.part, a.n_chunks, taps, Cout, Cin, dw);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" size_t hvpr_bn_workspace_bytes(long long P, int C) {
+    if (P < 1 || C < 4) return 0;
+    return (size_t)bn_blocks(P) * 2 * C * sizeof(float);
+}
+
+extern "C" int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float eps, float *mean, float *var, float *invstd,
+                                      void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
+    if (!z || !mean || !var || !invstd || !workspace || P < 1) return HVPR_ERR_INVALID_ARG;
+    if (C < 4 || C % 4 != 0 || C > 1024) return HVPR_ERR_UNSUPPORTED;
+    if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
+    const int blocks = bn_blocks(P);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, s, z, nullptr, P, C, nullptr, nullptr, nullptr, nullptr, 0,
+                       (float *)workspace);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 256)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, eps, 0, mean,
+                       var, invstd);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, float *y,
+                                         hvpr_stream_t stream) {
+    if (!z || !scale || !shift || !y || P < 1) return HVPR_ERR_INVALID_ARG;
+    if (C < 4 || C % 4 != 0) return HVPR_ERR_UNSUPPORTED;
+    const long long n4 = P * (C / 4);
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)z, n4, C / 4, scale, shift, relu,
+                       (float4 *)y);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
+                                         const float *mean, const float *invstd, int relu, float *dz, float *dgamma, float *dbeta,
+                                         void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
+    if (!dy || !z || !scale || !shift || !mean || !invstd || !dz || !dgamma || !dbeta || !workspace || P < 1) return HVPR_ERR_INVALID_ARG;
+    if (C < 4 || C % 4 != 0 || C > 1024) return HVPR_ERR_UNSUPPORTED;
+    if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
+    const int blocks = bn_blocks(P);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, s, z, dy, P, C, scale, shift, mean, invstd, relu, (float *)workspace);
+    // s1 -> dbeta, s2 -> dgamma  (d beta = sum dy_m, d gamma = sum dy_m * xhat)
+    hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 256)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, 0.f, 1, dbeta,
+                       dgamma, (float *)nullptr);
+    const long long n4 = P * (C / 4);
+    long long g = (n4 + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, s, (const float4 *)dy, (const float4 *)z, n4, C / 4, scale, shift, mean,
+                       invstd, dbeta, dgamma, (float)(1.0 / (double)P), relu, (float4 *)dz);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}

@@ -272,6 +272,32 @@ int hvpr_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx, c
                                     float *grad_features, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a11 (training)  Two-stream BEV backbone, pcdet/models/backbones_2d/base_bev_backbone.py:228-279.
+ *     Forward convolution and data gradient: hvpr_conv2d_nhwc_f32 (the data gradient of a stride-1 3x3 conv is the same conv
+ *     on the flipped, transposed weights; stride 2 on the zero-upsampled gradient; ConvTranspose k = s as the 1x1 GEMM).
+ *     hvpr_conv2d_wgrad_nhwc_f32: weight gradient on the fp32 matrix cores.  x [N,H,W,Cin] and dz [N,OH,OW,Cout] NHWC
+ *         (OH = (H + 2 - 3) / stride + 1 for taps == 9 (3x3, pad 1), = H for taps == 1) -> dw [Cout, Cin, k, k] (torch layout),
+ *         overwritten.  Split-K over pixel tiles into `workspace` partials, summed in a fixed order: deterministic.
+ *     hvpr_bn_stats_nhwc_f32: per-channel batch mean, biased variance and 1/sqrt(var + eps) of z [P, C] (train-mode BatchNorm,
+ *         double-precision final sums).
+ *     hvpr_bn_relu_fwd_nhwc_f32: y = max(0, z * scale + shift) (relu == 0: no max); scale = gamma * invstd, shift = beta - mean * scale.
+ *     hvpr_bn_relu_bwd_nhwc_f32: dz, dgamma, dbeta of y = relu(gamma * (z - mean) * invstd + beta) with BATCH statistics
+ *         (the mean / variance terms are differentiated through).
+ *     C % 4 == 0, C <= 1024 for the reductions.
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int taps, int stride);
+int hvpr_conv2d_wgrad_nhwc_f32(const float *x, int N, int H, int W, int Cin, const float *dz, int Cout, int taps, int stride, float *dw,
+                               void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+size_t hvpr_bn_workspace_bytes(long long P, int C);
+int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float eps, float *mean, float *var, float *invstd, void *workspace,
+                           size_t workspace_bytes, hvpr_stream_t stream);
+int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, float *y,
+                              hvpr_stream_t stream);
+int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
+                              const float *mean, const float *invstd, int relu, float *dz, float *dgamma, float *dbeta, void *workspace,
+                              size_t workspace_bytes, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a14 (training)  Optimiser step over ONE flat fp32 parameter buffer (and matching flat gradient / moment buffers, all
  *     16-byte aligned): decoupled weight decay p *= 1 - weight_decay * lr, then Adam with bias correction at `step` (1-based)
  *     — OptimWrapper.step, tools/train_utils/optimization/fastai_optim.py:132-149 (true_wd, the optimiser's own weight_decay
