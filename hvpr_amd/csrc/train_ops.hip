@@ -81,6 +81,16 @@ __global__ void __launch_bounds__(256) k_three_interpolate_grad(const float *__r
     }
 }
 
+// dst[idx[r]] += src[r]  (backward of the row gather dst[r] = src[idx[r]])
+__global__ void __launch_bounds__(256) k_scatter_add_rows(const float *__restrict__ src, const int *__restrict__ idx, long long m, int row,
+                                                          int n_dst, float *__restrict__ dst) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * row) return;
+    const long long r = t / row;
+    const int j = (int)(t % row), d = idx[r];
+    if (d >= 0 && d < n_dst) atomicAdd(dst + (size_t)d * row + j, src[t]);
+}
+
 __global__ void __launch_bounds__(256) k_zero(float *__restrict__ p, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
@@ -174,6 +184,21 @@ extern "C" int hvpr_three_interpolate_grad_f32(const float *grad_out, const int3
         if (!grad_out || !idx || !weight) return HVPR_ERR_INVALID_ARG;
         hipLaunchKernelGGL(k_three_interpolate_grad, dim3(hvpr_cdiv(n, 256), hvpr_cdiv(C, kStrip), B), dim3(256), 0,
                            (hipStream_t)stream, grad_out, idx, weight, C, m, n, grad_features);
+    }
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_scatter_add_rows_f32(const float *src, const int32_t *idx, long long m, int row_floats, int n_dst, float *dst,
+                                         hvpr_stream_t stream) {
+    if (m < 0 || row_floats < 1 || n_dst < 0) return HVPR_ERR_INVALID_ARG;
+    if (n_dst == 0) return HVPR_OK;
+    if (!dst) return HVPR_ERR_INVALID_ARG;
+    zero_floats(dst, (long long)n_dst * row_floats, (hipStream_t)stream);
+    if (m > 0) {
+        if (!src || !idx) return HVPR_ERR_INVALID_ARG;
+        hipLaunchKernelGGL(k_scatter_add_rows, dim3(hvpr_cdiv(m * row_floats, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, m, row_floats,
+                           n_dst, dst);
     }
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;

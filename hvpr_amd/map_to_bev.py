@@ -4,6 +4,7 @@ Eval forward = memory read-out (hvpr_memory_readout_fwd_f32) + gather-form scatt
 whole batch: no python loop over frames, no `.item()` host sync (the reference has both: pointpillar_scatter.py:176-178).
 The canvases come back as (B, C, ny, nx) tensors in channels_last memory format."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -51,6 +52,12 @@ class MemoryUnit_Agg(nn.Module):
 
     def _forward_train(self, pillars, k, positives):
         nv, _, d = positives.shape
+        if positives.is_cuda and d == 64 and self.mem_dim <= 2048 and self.shrink_thres > 0 and os.environ.get("HVPR_TRAIN_MEMORY", "hip") != "torch":
+            # hard-shrink addressing through hvpr_memory_train_fwd/bwd_f32: the (nv*k, items) attention is never materialised
+            # ('att' is not returned in this form: nothing on the path consumes it, pointpillar_scatter.py:133-138)
+            mem = _MemoryTrain.apply(positives.reshape(-1, d), self.weight, float(self.shrink_thres)).reshape(nv, k, d)
+            agg = torch.softmax((mem * pillars.unsqueeze(1)).sum(dim=2), dim=1)
+            return {"output": (agg.detach().unsqueeze(2) * mem).sum(dim=1)}
         att = torch.softmax(F.linear(positives.reshape(-1, d), self.weight), dim=1)          # (nv*k, items)
         if self.shrink_thres > 0:
             att = hard_shrink_relu(att, self.shrink_thres)
@@ -63,9 +70,71 @@ class MemoryUnit_Agg(nn.Module):
         return f"mem_dim={self.mem_dim}, fea_dim={self.fea_dim}"
 
 
+class _MemoryTrain(torch.autograd.Function):
+    """y = normalize_1(hard_shrink(softmax(x W^T))) W  (memory_module.py:36-48) on hvpr_memory_train_fwd_f32 / _bwd_f32."""
+
+    @staticmethod
+    def _ws(n_items, device):
+        return torch.empty(kernels.lib().hvpr_memory_train_workspace_bytes(n_items), dtype=torch.uint8, device=device)
+
+    @staticmethod
+    def forward(ctx, x, weight, lambd):
+        x, w = x.contiguous(), weight.detach().contiguous()
+        R, n_items = x.shape[0], w.shape[0]
+        y = torch.empty_like(x)
+        stats = torch.empty((R, 4), dtype=torch.float32, device=x.device)
+        ws = _MemoryTrain._ws(n_items, x.device)
+        kernels.check(kernels.lib().hvpr_memory_train_fwd_f32(kernels._ptr(x, torch.float32, "x"), R, kernels._ptr(w, torch.float32, "memory.weight"),
+                                                              n_items, lambd, y.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                              kernels._stream()), "hvpr_memory_train_fwd_f32")
+        ctx.save_for_backward(x, w, stats)
+        ctx.lambd = lambd
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, n_items = x.shape[0], w.shape[0]
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        scratch = torch.empty((max(R, 1),), dtype=torch.float32, device=x.device)
+        ws = _MemoryTrain._ws(n_items, x.device)
+        kernels.check(kernels.lib().hvpr_memory_train_bwd_f32(x.data_ptr(), kernels._ptr(dy, torch.float32, "dy"), R, w.data_ptr(), n_items, ctx.lambd,
+                                                              stats.data_ptr(), dx.data_ptr(), dw.data_ptr(), scratch.data_ptr(), ws.data_ptr(),
+                                                              ws.numel(), kernels._stream()), "hvpr_memory_train_bwd_f32")
+        return dx, dw, None
+
+
 def hard_shrink_relu(x, lambd=0.0, epsilon=1e-12):
     """relu(x - l) * x / (|x - l| + eps) — memory_module.py:85-87."""
     return (F.relu(x - lambd) * x) / (torch.abs(x - lambd) + epsilon)
+
+
+class _GatherRows(torch.autograd.Function):
+    """rows[idx] for a (N, C) feature matrix and an integer index tensor of any shape — `points[idx]` of get_score
+    (pointpillar_scatter.py:76): hvpr_gather_rows_f32 forward, hvpr_scatter_add_rows_f32 backward (torch's index backward sorts
+    the 1.2 M indices of a batch first: 26 ms of a training step)."""
+
+    @staticmethod
+    def forward(ctx, rows, idx):
+        rows = rows.contiguous()
+        flat = idx.reshape(-1).to(torch.int32).contiguous()
+        out = torch.empty((flat.numel(), rows.shape[1]), dtype=torch.float32, device=rows.device)
+        kernels.check(kernels.lib().hvpr_gather_rows_f32(kernels._ptr(rows, torch.float32, "rows"), rows.shape[0], rows.shape[1], flat.data_ptr(),
+                                                         flat.numel(), out.data_ptr(), kernels._stream()), "hvpr_gather_rows_f32")
+        ctx.save_for_backward(flat)
+        ctx.n = rows.shape[0]
+        return out.view(*idx.shape, rows.shape[1])
+
+    @staticmethod
+    def backward(ctx, grad):
+        (flat,) = ctx.saved_tensors
+        grad = grad.contiguous()
+        c = grad.shape[-1]
+        g = torch.empty((ctx.n, c), dtype=torch.float32, device=grad.device)
+        kernels.check(kernels.lib().hvpr_scatter_add_rows_f32(kernels._ptr(grad, torch.float32, "grad"), flat.data_ptr(), flat.numel(), c, ctx.n,
+                                                              g.data_ptr(), kernels._stream()), "hvpr_scatter_add_rows_f32")
+        return g, None
 
 
 class _ScatterCanvas(torch.autograd.Function):
@@ -157,7 +226,7 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         # formed transposed so that the top-k runs along the contiguous dimension.
         with torch.no_grad():
             idx = self._topk_points(pillars.detach(), points.detach())            # (M, k), descending
-        positives = points[idx]                                                    # (M, k, C)
+        positives = _GatherRows.apply(points, idx) if points.is_cuda else points[idx]      # (M, k, C)
         w = torch.softmax(torch.bmm(pillars.unsqueeze(1), positives.transpose(1, 2)).squeeze(1), dim=1)
         return (w.detach().unsqueeze(2) * positives).sum(dim=1), positives
 

@@ -270,6 +270,28 @@ int hvpr_three_interpolate_f32(const float *features, const int32_t *idx, const 
                                float *out, hvpr_stream_t stream);
 int hvpr_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx, const float *weight, int B, int C, int m, int n,
                                     float *grad_features, hvpr_stream_t stream);
+/* a10 (training)  backward of the row gather `points[idx]` of get_score (pointpillar_scatter.py:76): dst [n_dst, row_floats] is
+ * overwritten with the scatter-add of src [m, row_floats] at rows idx [m] (fp32 atomics; out-of-range ids are ignored).  The
+ * forward is hvpr_gather_rows_f32. */
+int hvpr_scatter_add_rows_f32(const float *src, const int32_t *idx, long long m, int row_floats, int n_dst, float *dst,
+                              hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a10 (training)  MemAE memory addressing with hard shrinkage, MemoryUnit_Agg.forward training branch,
+ *     map_to_bev/memory_module.py:31-48 (+ hard_shrink_relu :85-87), without materialising the (R, n_items) attention:
+ *         a = softmax(x W^T), s = relu(a - l) a / (|a - l| + 1e-12), t = s / max(||s||_1, 1e-12), y = t W
+ *     x [R,64] (the k positive point features of every pillar, flattened), bank [n_items <= 2048, 64], shrink_thres l > 0.
+ *     fwd: y [R,64]; row_stats [R,4] (softmax max, partition sum, ||s||_1) is what the backward needs.
+ *     bwd: dx [R,64] and dbank [n_items,64] (overwritten) from dy [R,64]; row_scratch [R] floats; the sparse part of dbank
+ *          uses fp32 atomics (summation order unspecified), the dense part is reduced in a fixed order.
+ *     workspace: hvpr_memory_train_workspace_bytes(n_items), no state between calls.
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_memory_train_workspace_bytes(int n_items);
+int hvpr_memory_train_fwd_f32(const float *x, long long R, const float *bank, int n_items, float shrink_thres, float *y, float *row_stats,
+                              void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+int hvpr_memory_train_bwd_f32(const float *x, const float *dy, long long R, const float *bank, int n_items, float shrink_thres,
+                              const float *row_stats, float *dx, float *dbank, float *row_scratch, void *workspace,
+                              size_t workspace_bytes, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a11 (training)  Two-stream BEV backbone, pcdet/models/backbones_2d/base_bev_backbone.py:228-279.

@@ -108,3 +108,52 @@ def test_fused_adam_equals_per_tensor_adam_with_clipping_and_checkpoint_interop(
     for (k, v), (_, w), (_, u) in zip(a.state_dict().items(), c.state_dict().items(), d.state_dict().items()):
         np.testing.assert_allclose(v.float().cpu().numpy(), w.float().cpu().numpy(), rtol=5e-5, atol=1e-7, err_msg="fused -> torch " + k)
         np.testing.assert_allclose(v.float().cpu().numpy(), u.float().cpu().numpy(), rtol=5e-5, atol=1e-7, err_msg="torch -> fused " + k)
+
+
+def test_gather_rows_forward_and_scatter_add_backward():
+    from hvpr_amd.map_to_bev import _GatherRows
+    g = torch.Generator().manual_seed(9)
+    rows = torch.randn(5000, 64, generator=g).to(DEV).requires_grad_(True)
+    idx = torch.randint(0, 5000, (700, 20), generator=g).to(DEV)
+    idx[:50] = 7                                            # one hot row: the backward accumulates 1000 times into it
+    out = _GatherRows.apply(rows, idx)
+    assert out.shape == (700, 20, 64) and torch.equal(out, rows[idx])
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    (gr,) = torch.autograd.grad(out, rows, go)
+    r2 = rows.detach().clone().requires_grad_(True)
+    (gt,) = torch.autograd.grad(r2[idx], r2, go)
+    np.testing.assert_allclose(gr.cpu().numpy(), gt.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("R,n_items,scale", [(700, 2000, 6.0), (33, 2000, 9.0), (1200, 777, 5.0), (4096, 2000, 1.0), (16, 2048, 12.0)])
+def test_memory_train_forward_backward_match_the_reference_formula(R, n_items, scale):
+    """hvpr_memory_train_fwd/bwd vs torch autograd (float64) of memory_module.py:36-48 + hard_shrink_relu :85-87.  `scale` sets
+    the feature norm: small -> every softmax value is below the shrink threshold (empty support: zero output, zero gradients),
+    large -> a few items per row survive."""
+    from hvpr_amd.map_to_bev import _MemoryTrain, hard_shrink_relu
+    g = torch.Generator().manual_seed(R + n_items)
+    x = (torch.relu(torch.randn(R, 64, generator=g)) * scale / 4).to(DEV).requires_grad_(True)
+    w = ((torch.rand(n_items, 64, generator=g) * 2 - 1) / 8).to(DEV).requires_grad_(True)
+    lam = 0.0025
+    y = _MemoryTrain.apply(x, w, lam)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    att = torch.softmax(xd @ wd.t(), dim=1)
+    sh = torch.nn.functional.normalize(hard_shrink_relu(att, lam), p=1, dim=1)
+    yr = sh @ wd
+    nnz = (att > lam).sum(1)
+    if scale >= 5:
+        assert int((nnz > 0).sum()) > R // 4                 # the case really exercises non-empty supports
+    # rows whose support decision sits within fp32 noise of the threshold may legitimately differ: compare the others
+    margin = ((att - lam).abs() / lam).min(dim=1)[0]
+    ok = (margin > 1e-4).cpu().numpy()
+    assert ok.mean() > 0.9
+    rms = float(yr.detach().pow(2).mean().sqrt()) + 1e-30
+    np.testing.assert_allclose(y.detach().cpu().numpy()[ok], yr.detach().cpu().numpy()[ok], rtol=1e-3, atol=1e-3 * rms)
+    dy = torch.randn(R, 64, generator=g).to(DEV) * torch.from_numpy(ok).to(DEV).float()[:, None]      # no gradient into the excluded rows
+    dx, dw = torch.autograd.grad(y, (x, w), dy)
+    dxr, dwr = torch.autograd.grad(yr, (xd, wd), dy.double())
+    for got, ref, what in ((dx, dxr, "dx"), (dw, dwr, "dW")):
+        err = float((got.double() - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert err < 1e-3 or float(ref.norm()) < 1e-12, (what, err)
+        if float(ref.norm()) < 1e-12:
+            assert float(got.abs().max()) < 1e-12
