@@ -135,22 +135,157 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cfg, params, n_timed=5):
+def cpu_baseline(cfg, params, n_timed=10, n_warm=3):
+    """the CPU restatement of a1..a8 on this box's host cores, 3 warm-up + 10 timed frames."""
     from oracle import hvpr_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
     ocfg = O.cfg_from_model_cfg(cfg)
-    frames = [synthetic.hvpr_frame(1000 + i) for i in range(n_timed + 1)]
-    O.forward_frames(frames[:1], params, ocfg)          # warm-up (allocators, oneDNN primitives)
+    frames = [synthetic.hvpr_frame(1000 + i) for i in range(n_timed + n_warm)]
+    for f in frames[:n_warm]:
+        O.forward_frames([f], params, ocfg)             # warm-up (allocators, oneDNN primitives)
     timings = {}
     t0 = time.perf_counter()
-    for f in frames[1:]:
+    for f in frames[n_warm:]:
         O.forward_frames([f], params, ocfg, timings=timings)
     dt = time.perf_counter() - t0
     return {"value": n_timed / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_timed} synthetic hvpr_car frames (batch=1, a1..a8) after 1 warm-up frame; torch CPU fp32, "
-                      f"{cores} threads; C voxelizer/NMS",
+            "sample": f"{n_timed} synthetic hvpr_car frames (batch=1, a1..a8) after {n_warm} warm-up frames",
+            "threads": {"dense stages (VFE, memory, scatter, backbone, head, decode)": f"torch CPU fp32, {cores} threads",
+                        "voxelize, top-k + rotated NMS": "C restatement, 1 thread (sequential algorithms)"},
             "stage_ms": {k: round(1e3 * v / n_timed, 2) for k, v in timings.items()}}
+
+
+class GroupGraphs:
+    """The VFE+scatter group (hvpr_encode_fwd_f32) captured once per pool frame — every graph reads its own static copy of a
+    DIFFERENT frame and all of them write the same persistent canvas pair — so that back-to-back replays are what a stream of
+    frames costs: the stale-cell clear of the previous frame's pillars is inside the timed interval."""
+
+    def __init__(self, model, batches):
+        own = model.persistent_canvases(batches[0])
+        self.inputs = [{**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}, **own} for b in batches]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for inp in self.inputs:
+                model.stage_encode(dict(inp))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graphs, pool = [], None
+        for inp in self.inputs:
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g, pool=pool):
+                self.bd = model.stage_encode(dict(inp))
+            pool = g.pool()
+            self.graphs.append(g)
+        self.captured = detector._CapturedState(model)
+
+    def time_us(self, rounds=5):
+        self.captured.check()
+        n = len(self.graphs)
+        for g in self.graphs:
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rounds):
+            for g in self.graphs:
+                g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (rounds * n)
+
+
+def group_bytes(n_pts, nx, ny, batch):
+    """Algorithmic bytes of the VFE+scatter group: raw points read once + dense canvases written once (zeros
+    included) + VFE weights and memory bank read once."""
+    w_bytes = 4 * (16 * 10 + 16 + 64 * 32 + 64 + 16 * 5 + 16 + 32 * 16 + 32) + 2000 * 64 * 4
+    return 16 * n_pts + 4 * (128 + 32) * nx * ny * batch + w_bytes
+
+
+def batch_of(frames, device):
+    pts = np.concatenate([np.concatenate([np.full((len(f), 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    offs = np.cumsum([0] + [len(f) for f in frames]).astype(np.int32)
+    return {"points": torch.from_numpy(pts).to(device), "point_frame_offsets": torch.from_numpy(offs).to(device), "batch_size": len(frames)}
+
+
+def extra_group_lines(device):
+    """The same group at hvpr_car batch 16 and on BASELINE.json configs[4] (dense scene: 200 k uniform points per frame,
+    512 x 512 grid, 20 points / pillar, 60 000-pillar cap, batch 4), each as hipGraphs over two alternating batches."""
+    import copy
+    out = {}
+    car = hvpr_car_cfg()
+    dense = copy.deepcopy(car)
+    rng = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+    dense.DATA_CONFIG.POINT_CLOUD_RANGE = rng
+    for p in dense.DATA_CONFIG.DATA_PROCESSOR:
+        if p.NAME == "transform_points_to_voxels":
+            p.VOXEL_SIZE, p.MAX_POINTS_PER_VOXEL, p.MAX_NUMBER_OF_VOXELS = [0.2, 0.2, 8.0], 20, {"train": 60000, "test": 60000}
+    for key, cfg, make in (("hvpr_car_batch16", car, lambda k: [synthetic.hvpr_frame(500 + 16 * k + i) for i in range(16)]),
+                           ("dense_scene", dense, lambda k: [synthetic.uniform_frame(70 + 4 * k + b, 200000, rng) for b in range(4)])):
+        model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg))
+        synthetic_weights.load_synthetic(model, seed=0)
+        model = model.to(device).eval()
+        batches = [batch_of(make(k), device) for k in range(2)]
+        gg = GroupGraphs(model, batches)
+        us = gg.time_us(rounds=10)
+        B, _, ny, nx = gg.bd["spatial_features"].shape
+        n_pts = int(batches[0]["points"].shape[0])
+        alg = group_bytes(n_pts, nx, ny, B)
+        out[key] = {"workload": f"{B} frames x {n_pts // B} points, grid {nx}x{ny}, {int(gg.bd['voxel_offsets'][-1])} pillars",
+                    "group_ms": round(us / 1e3, 4), "algorithmic_bytes": alg, "algorithmic_GBps": round(alg / us / 1e3, 1),
+                    "frac_of_hbm_peak": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4)}
+        del gg, model, batches
+        torch.cuda.empty_cache()
+    return out
+
+
+def train_step_line(device, batch=16, steps=3, warmup=2):
+    """BASELINE.json configs[2]: hvpr_car full train step (a1..a15: fwd + bwd + Adam-onecycle), 16 frames per step, a bounded
+    number of steps; MFMA fraction against 2.71 TFLOP/frame of convolution work."""
+    from hvpr_amd import optim
+    cfg = hvpr_car_cfg()
+    model = detector.build_network(cfg.MODEL, len(cfg.CLASS_NAMES), detector.SyntheticDataset(cfg, training=True))
+    synthetic_weights.load_synthetic(model, seed=0, cls_bias=-4.59511985013459)
+    model = model.to(device)
+    opt = optim.build_optimizer(model, cfg.OPTIMIZATION)
+    sched, _ = optim.build_scheduler(opt, total_iters_each_epoch=steps + warmup, total_epochs=1, last_epoch=-1, optim_cfg=cfg.OPTIMIZATION)
+    rng = np.random.default_rng(0)
+
+    def gt(B, per=8):
+        g = np.zeros((B, per, 8), np.float32)
+        g[..., 0] = rng.uniform(3, 44, (B, per)); g[..., 1] = rng.uniform(-17, 17, (B, per)); g[..., 2] = rng.uniform(-1.2, -0.8, (B, per))
+        g[..., 3:6] = np.array([3.9, 1.6, 1.56], np.float32) * rng.uniform(0.9, 1.1, (B, per, 3))
+        g[..., 6] = rng.uniform(-np.pi, np.pi, (B, per)); g[..., 7] = 1
+        return g
+    pool = []
+    for k in range(2):
+        b = batch_of([synthetic.hvpr_frame(2000 + batch * k + i, shuffle=True) for i in range(batch)], device)
+        b.pop("point_frame_offsets")
+        b["gt_boxes"] = torch.from_numpy(gt(batch)).to(device)
+        pool.append(b)
+    torch.cuda.reset_peak_memory_stats()
+    losses = []
+    for it in range(warmup):
+        optim.train_step(model, opt, sched, dict(pool[it % 2]), it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        loss, _ = optim.train_step(model, opt, sched, dict(pool[it % 2]), warmup + it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        losses.append(loss)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flops_frame = 2.71e12
+    res = {"workload": f"hvpr_car.yaml full train step a1..a15, batch={batch}, 8 GT boxes/frame, {warmup} warm-up + {steps} timed steps",
+           "steps_per_s": round(1.0 / dt, 3), "frames_per_s": round(batch / dt, 2), "ms_per_step": round(1e3 * dt, 1),
+           "conv_TFLOPs": round(flops_frame * batch / dt / 1e12, 1), "mfma_frac_of_f32_peak": round(flops_frame * batch / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+           "kernels": "backbone conv fwd/dgrad/wgrad + train-mode BN on the library's HIP kernels (HVPR_TRAIN_CONV=hip), memory addressing on "
+                      "hvpr_memory_train_*, flat fused Adam; head 1x1 convs / PointNet++ MLPs / losses through torch"}
+    del model, opt, pool
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -159,6 +294,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch-16 / dense-scene group lines and the train-step line")
     ap.add_argument("--probe-steps", type=int, default=30, help="extra untimed steps with per-stage HIP events")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -301,20 +437,9 @@ def main():
         # its ~50 kernels, not per group (rocprofv3 kernel durations of the same command: profiles/).
         group_us = None
         if staged is not None:
-            R, reps = 10, 5
-            tot = 0.0
-            for rep in range(reps):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                for k, v in batches[rep % N_POOL].items():
-                    if torch.is_tensor(v):
-                        staged.static_in[k].copy_(v, non_blocking=True)
-                e0.record()
-                for r in range(R):
-                    staged.graphs[0].replay()
-                e1.record()
-                torch.cuda.synchronize()
-                tot += e0.elapsed_time(e1) * 1e3 / R
-            group_us = tot / reps
+            # eight captured copies of the group, one per pool frame, on ONE persistent canvas pair: consecutive replays see
+            # consecutive DIFFERENT frames (the stale-cell clear of the previous frame's pillars is inside the interval)
+            group_us = GroupGraphs(model, batches).time_us(rounds=5)
         kept = int(out[0][0]["pred_count"].item()) if args.probe_steps > 0 else -1
 
     rccl_ranks = distributed.ranks_seen(device)                       # all-reduce of ones over RCCL
@@ -326,8 +451,7 @@ def main():
     fps = world * args.steps / dt
     # algorithmic bytes of the VFE+scatter group per frame (SURVEY.md §8d / BASELINE.md §6): raw points read once +
     # dense canvases written once (zeros included) + VFE weights and memory bank read once
-    w_bytes = 4 * (16 * 10 + 16 + 64 * 32 + 64 + 16 * 5 + 16 + 32 * 16 + 32) + 2000 * 64 * 4
-    group_bytes = 16 * n_pts + 4 * (128 + 32) * nx * ny + w_bytes
+    group_bytes_ = group_bytes(n_pts, nx, ny, 1)
     group_s = (group_us * 1e-6) if group_us else stage[0] * 1e-3
     flops = conv_flops(model, ny, nx)
     traffic = None
@@ -337,7 +461,7 @@ def main():
     # per-kernel averages of the committed rocprofv3 --kernel-trace --stats run of this command (serial frame graph): the group
     # above is timed live; its members, and the one bandwidth-bound kernel among them, are quoted from the profile
     members = {}
-    spath = os.path.join(ROOT, "profiles", "r01_kernel_stats_single_graph.csv")
+    spath = os.path.join(ROOT, "profiles", "r02_kernel_stats_single_graph.csv")
     if os.path.exists(spath):
         import csv
         for r in csv.DictReader(open(spath)):
@@ -364,14 +488,20 @@ def main():
         "stage_ms": {"voxelize+vfe+memory+scatter": round(float(stage[0]), 4), "backbone+head+decode": round(float(stage[1]), 4),
                      "topk+nms": round(float(stage[2]), 4)},
         "roofline": {"kernel": "VFE+scatter group = hvpr_encode_fwd_f32: K1 keys, K2 rank scan, K3 arena fill, gather + pillar VFE + canvas clear, memory read-out (+ canvas cells): 5 launches",
-                     "bound": "hbm", "achieved": round(group_bytes / group_s / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(group_bytes / group_s / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": group_bytes,
+                     "bound": "hbm", "achieved": round(group_bytes_ / group_s / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(group_bytes_ / group_s / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": group_bytes_,
                      "avg_duration_us": round(group_s * 1e6, 2),
                      "single_replay_between_events_us": round(float(stage[0]) * 1e3, 2),
-                     "timing": "HIP events around 10 consecutive replays of the captured group, / 10, mean of 5 frames (the replays of one "
-                               "repetition see the same frame: no stale canvas cells to clear; a new frame adds ~2.4 MB of zeros); "
-                               "single_replay_between_events_us additionally holds the start-up of one graph launch",
+                     "timing": "HIP events around 40 back-to-back replays of the captured group (8 graphs, one per pool frame, on ONE persistent "
+                               "canvas pair: every replay encodes a DIFFERENT frame, so the stale-cell clear of the previous frame is inside the "
+                               "interval), / 40; single_replay_between_events_us additionally holds the start-up of one graph launch",
                      "traffic": None if traffic is None else traffic.get("vfe_scatter_group_bytes"),
+                     "achieved_physical": None if traffic is None else round(traffic.get("vfe_scatter_group_bytes") / group_s / 1e9, 2),
+                     "frac_physical": None if traffic is None else round(traffic.get("vfe_scatter_group_bytes") / group_s / 1e9 / HBM_PEAK_GBPS, 5),
+                     "note": "`achieved` / `frac` = ALGORITHMIC bytes (SURVEY.md §8d: points read once + dense canvases written once + weights) / "
+                             "measured group time; `achieved_physical` = HBM bytes the counters saw (`traffic`, rocprofv3 --pmc of the committed "
+                             "profile, FETCH_SIZE doubled per the gfx950 correction) / the same time — lower, because persistent canvases are not "
+                             "re-written where nothing changed",
                      "member_kernels_avg_us_from_profile": members,
                      "canvas": "persistent canvases + occupancy state (hvpr_encode_fwd_f32 canvas_state): the dense result is the same, "
                                "but only stale cells are cleared — `traffic` (PMC) is therefore BELOW the algorithmic bytes, which still "
@@ -385,6 +515,13 @@ def main():
                                   "s_memrealtime inside the kernel, DESIGN.md §4.2), i.e. ~132 TFLOP/s attainable"},
     }
     res["alt_precision"] = alt
+    if world == 1 and not args.no_extras:
+        # driver-visible numbers for the other BASELINE.json configs (bounded step counts): the same group at batch 16 and on
+        # the dense scene (configs[4]); the full train step (configs[2])
+        del model, batches, staged
+        torch.cuda.empty_cache()
+        res["group_other_configs"] = extra_group_lines(device)
+        res["train_step"] = train_step_line(device)
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, params)
     else:

@@ -36,6 +36,20 @@ def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
     return selected, box_scores[selected]
 
 
+def multi_classes_nms(cls_scores, box_preds, nms_config, score_thresh=None):
+    """model_nms_utils.py:28-65: per class k — score filter, top NMS_PRE_MAXSIZE, rotated NMS, first NMS_POST_MAXSIZE — on the
+    same kernels as the class-agnostic path.  cls_scores (N, num_class), box_preds (N, 7+).  Returns (scores, labels = class
+    index k as int64, boxes), classes concatenated in order."""
+    pred_scores, pred_labels, pred_boxes = [], [], []
+    for k in range(cls_scores.shape[1]):
+        col = cls_scores[:, k].contiguous()
+        selected, sc = class_agnostic_nms(col, box_preds, nms_config, score_thresh=score_thresh)
+        pred_scores.append(sc)
+        pred_labels.append(torch.full((selected.shape[0],), k, dtype=torch.long, device=col.device))
+        pred_boxes.append(box_preds[selected])
+    return torch.cat(pred_scores, dim=0), torch.cat(pred_labels, dim=0), torch.cat(pred_boxes, dim=0)
+
+
 # ---------------------------------------------------------------------------------------------- detectors
 class Detector3DTemplate(nn.Module):
     """detectors/detector3d_template.py:13-132 (construction), :168-318 (post-processing, recall)."""
@@ -150,7 +164,8 @@ class Detector3DTemplate(nn.Module):
         """
         cfg = self.model_cfg.POST_PROCESSING
         ncfg = cfg.NMS_CONFIG
-        assert not ncfg.MULTI_CLASSES_NMS, "hvpr path: class-agnostic NMS (hvpr.yaml:144)"
+        if ncfg.MULTI_CLASSES_NMS:
+            return self._post_processing_multi_class(batch_dict)
         B = batch_dict["batch_size"]
         boxes_all = batch_dict["batch_box_preds"]
         assert boxes_all.dim() == 3 and boxes_all.shape[0] == B
@@ -185,6 +200,23 @@ class Detector3DTemplate(nn.Module):
                 n = int(kc.item())
                 rec = {k: (v[:n] if k != "pred_count" else v) for k, v in rec.items()}
                 recall_dict = self.generate_recall_record(rec["pred_boxes"], recall_dict, b, batch_dict, cfg.RECALL_THRESH_LIST)
+            pred_dicts.append(rec)
+        return pred_dicts, recall_dict, batch_dict
+
+    def _post_processing_multi_class(self, batch_dict):
+        """MULTI_CLASSES_NMS branch, detector3d_template.py:214-239 (single head): one NMS per class on the sigmoid scores.
+        Labels are 1-based class ids (the reference's single-head label mapping `arange(1, num_class)` is one short for its own
+        assert at :224; `arange(1, num_class + 1)` is what upstream OpenPCDet has).  Host-synchronising, like the reference."""
+        cfg = self.model_cfg.POST_PROCESSING
+        pred_dicts, recall_dict = [], {}
+        for b in range(batch_dict["batch_size"]):
+            cls = batch_dict["batch_cls_preds"][b]
+            cls = cls if batch_dict["cls_preds_normalized"] else torch.sigmoid(cls)
+            boxes = batch_dict["batch_box_preds"][b]
+            mapping = torch.arange(1, cls.shape[1] + 1, device=cls.device)
+            sc, lab, bx = multi_classes_nms(cls.float(), boxes, cfg.NMS_CONFIG, score_thresh=cfg.SCORE_THRESH)
+            rec = {"pred_boxes": bx, "pred_scores": sc, "pred_labels": mapping[lab]}
+            recall_dict = self.generate_recall_record(bx, recall_dict, b, batch_dict, cfg.RECALL_THRESH_LIST)
             pred_dicts.append(rec)
         return pred_dicts, recall_dict, batch_dict
 

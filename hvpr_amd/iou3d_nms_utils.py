@@ -43,4 +43,9 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
 
 
 def nms_normal_gpu(boxes, scores, thresh, **kwargs):
-    raise NotImplementedError("axis-aligned nms_normal_gpu is not on the hvpr path (NMS_TYPE: nms_gpu)")
+    """Axis-aligned BEV NMS ([upstream] nms_normal_gpu: IoU of the boxes with their headings ignored).  Runs the rotated kernel on
+    heading-zeroed copies: the overlap of two axis-aligned rectangles through the polygon routine equals the closed form up to
+    fp32 rounding.  Returns (LongTensor keep indices, None) like nms_gpu."""
+    b = boxes[:, :7].float().clone()
+    b[:, 6] = 0.0
+    return nms_gpu(b, scores, thresh, **kwargs)

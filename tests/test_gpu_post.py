@@ -120,3 +120,48 @@ def test_pairwise_overlap_and_iou():
     np.testing.assert_allclose(np.diag(same), 1.0, atol=1e-3)
     far = a.copy(); far[:, 0] += 500
     assert (kernels.boxes_pairwise(ta, torch.from_numpy(far).to(DEV), 0).cpu().numpy() == 0).all()
+
+
+def test_multi_classes_nms_and_nms_normal_gpu():
+    """model_nms_utils.multi_classes_nms (model_nms_utils.py:28-65) = one class-agnostic pass per class column, and the axis-aligned
+    nms_normal_gpu wrapper, both against greedy NMS on the CPU oracle's IoU."""
+    from hvpr_amd import detector, iou3d_nms_utils
+    from hvpr_amd.config import AttrDict
+    rng = np.random.default_rng(5)
+    n = 900
+    xy = rng.uniform([0, -20], [46, 20], (n, 2))
+    boxes = np.concatenate([xy, np.full((n, 1), -1.0), rng.uniform(0.9, 1.1, (n, 3)) * [3.9, 1.6, 1.56], rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)
+    cls = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    ncfg = AttrDict(NMS_TYPE="nms_gpu", NMS_THRESH=0.2, NMS_PRE_MAXSIZE=300, NMS_POST_MAXSIZE=40, MULTI_CLASSES_NMS=True)
+    sc, lab, bx = detector.multi_classes_nms(torch.from_numpy(cls).to(DEV), torch.from_numpy(boxes).to(DEV), ncfg, score_thresh=0.3)
+    want_s, want_l, want_b = [], [], []
+    for k in range(3):
+        sel, s = O.class_agnostic_nms(cls[:, k], boxes, 0.3, 0.2, 300, 40)
+        want_s.append(s); want_l.append(np.full(len(sel), k)); want_b.append(boxes[sel])
+    np.testing.assert_array_equal(sc.cpu().numpy(), np.concatenate(want_s))
+    np.testing.assert_array_equal(lab.cpu().numpy(), np.concatenate(want_l))
+    np.testing.assert_array_equal(bx.cpu().numpy(), np.concatenate(want_b))
+    # axis-aligned NMS: closed-form IoU of the heading-less boxes, greedy in descending score
+    b = boxes[:400]
+    s = cls[:400, 0]
+    keep, none = iou3d_nms_utils.nms_normal_gpu(torch.from_numpy(b).to(DEV), torch.from_numpy(s).to(DEV), 0.1)
+    assert none is None
+    order = np.lexsort((np.arange(len(s)), -s))
+    x1, x2, y1, y2 = b[:, 0] - b[:, 3] / 2, b[:, 0] + b[:, 3] / 2, b[:, 1] - b[:, 4] / 2, b[:, 1] + b[:, 4] / 2
+    area = b[:, 3] * b[:, 4]
+    kept, near = [], 0
+    for i in order:
+        ok = True
+        for j in kept:
+            inter = max(min(x2[i], x2[j]) - max(x1[i], x1[j]), 0) * max(min(y2[i], y2[j]) - max(y1[i], y1[j]), 0)
+            iou = inter / max(area[i] + area[j] - inter, 1e-8)
+            near += abs(iou - 0.1) < 1e-4
+            if iou > 0.1:
+                ok = False
+                break
+        if ok:
+            kept.append(i)
+    if near == 0:          # no decision within rounding of the threshold: the survivor list is exact
+        np.testing.assert_array_equal(keep.cpu().numpy(), np.array(kept))
+    else:
+        assert len(set(keep.cpu().numpy().tolist()) ^ set(kept)) <= 2 * near
