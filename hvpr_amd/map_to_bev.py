@@ -24,6 +24,8 @@ class MemoryUnit_Agg(nn.Module):
         self.weight.data.uniform_(-stdv, stdv)
         self._packed = None
 
+    allow_torch_reference = False      # see PointPillarScatter_Agg_Memory_1_scale.allow_torch_reference
+
     def train(self, mode=True):
         self._packed = None
         return super().train(mode)
@@ -58,6 +60,11 @@ class MemoryUnit_Agg(nn.Module):
             mem = _MemoryTrain.apply(positives.reshape(-1, d), self.weight, float(self.shrink_thres)).reshape(nv, k, d)
             agg = torch.softmax((mem * pillars.unsqueeze(1)).sum(dim=2), dim=1)
             return {"output": (agg.detach().unsqueeze(2) * mem).sum(dim=1)}
+        if positives.is_cuda and os.environ.get("HVPR_TRAIN_MEMORY", "hip") != "torch":
+            raise ValueError("hvpr_amd: the memory training branch is built for 64 channels, <= 2048 items and SHRINK_TH > 0 (hvpr.yaml:83-85)")
+        if not positives.is_cuda and not self.allow_torch_reference:
+            raise RuntimeError("hvpr_amd: the memory training branch needs GPU tensors (the HIP path has no CPU fallback)")
+        # torch form: the parity reference of the tests (materialises the (nv*k, items) attention)
         att = torch.softmax(F.linear(positives.reshape(-1, d), self.weight), dim=1)          # (nv*k, items)
         if self.shrink_thres > 0:
             att = hard_shrink_relu(att, self.shrink_thres)
@@ -230,14 +237,26 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         w = torch.softmax(torch.bmm(pillars.unsqueeze(1), positives.transpose(1, 2)).squeeze(1), dim=1)
         return (w.detach().unsqueeze(2) * positives).sum(dim=1), positives
 
+    # CPU tensors have no kernel to run on: the torch form below is a REFERENCE for the host-logic unit tests only and has to be
+    # switched on explicitly (tests/train_fixture_cases.py); the product path raises instead of silently computing on the CPU.
+    allow_torch_reference = False
+
     def _topk_points(self, pillars, points):
-        """Indices (M, k) of the k points with the largest pillar . point logits, descending.  On the GPU the (M, N) logits are
-        never materialised: the memory read-out kernel (logits on the matrix cores into LDS + exact wave-level top-k) runs
-        over the points in blocks of <= 2048 "items", and the k * blocks candidates per pillar are re-ranked exactly."""
+        """Indices (M, k) of the k points with the largest pillar . point logits, descending.  The (M, N) logits are never
+        materialised: the memory read-out kernel (half-precision matrix-core pre-filter + exact fp32 re-check of the candidates)
+        runs over the points in blocks of <= 2048 "items", and the k * blocks candidates per pillar are re-ranked exactly."""
         k, N = self.k, points.shape[0]
         nb = (N + 2047) // 2048                                        # blocks of (almost) equal size, each <= 2048 items
-        if not pillars.is_cuda or pillars.shape[1] != 64 or pillars.shape[0] == 0 or N < k * max(nb, 1):
+        if not pillars.is_cuda:
+            if not self.allow_torch_reference:
+                raise RuntimeError("hvpr_amd: get_score needs GPU tensors (the HIP path has no CPU fallback)")
             return torch.topk(pillars @ points.t(), k, dim=1)[1]
+        if pillars.shape[1] != 64:
+            raise ValueError("hvpr_amd: get_score is built for 64-channel point / pillar features (hvpr.yaml:81)")
+        if pillars.shape[0] == 0:
+            return torch.zeros((0, k), dtype=torch.long, device=pillars.device)
+        if N < k * max(nb, 1):
+            raise ValueError(f"hvpr_amd: get_score needs at least k = {k} points per sample, got {N}")
         bounds = [(i * N) // nb for i in range(nb + 1)]
         pf = pillars.contiguous()
         cand = []

@@ -158,3 +158,63 @@ def test_config3_full_train_step_batch16():
     json.dump({"config": "hvpr_car full train step, batch 16", "loss": [float(loss), float(loss2)], "peak_mem_GiB": round(peak, 1)},
               open(os.path.join("gpurun_out", "config3_train_step_test.json"), "w"))
     assert peak < 200.0
+
+
+def test_pointnet2_msg_whole_module_matches_a_torch_plus_oracle_reference():
+    """Row a9 as a whole: PointNet2MSG (4 SA-MSG scales + 2 FP levels) with every op of the absent pointnet2_batch package on
+    HIP kernels — FPS, ball query, three-NN, grouping / gather / three-interpolate and their backward — against the SAME module
+    with the index ops taken from the CPU oracle and the gathers done by differentiable torch indexing: point features and
+    every parameter gradient."""
+    import copy
+    cfg = hvpr_car_cfg()
+    model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg, training=True))
+    synthetic_weights.load_synthetic(model, seed=21)
+    a = model.backbone_3d.to(DEV).train()
+    b = copy.deepcopy(a)
+    B, N = 2, 4096
+    frames = [synthetic.hvpr_frame(70 + i, num_points=N, shuffle=True) for i in range(B)]
+    pts = np.concatenate([np.concatenate([np.full((N, 1), i, np.float32), f], 1) for i, f in enumerate(frames)])
+    # the SA levels sample 4096 and 1024 points (hvpr.yaml:61-66): with N = 4096 the first level keeps every point
+
+    def run(mod):
+        p = torch.from_numpy(pts).to(DEV)
+        out = mod({"points": p, "batch_size": B})["point_features"]
+        w = torch.linspace(0.5, 1.5, out.shape[1], device=DEV)
+        (out * w).pow(2).mean().backward()
+        return out.detach(), {k: v.grad.detach().clone() for k, v in mod.named_parameters()}
+    got, ggot = run(a)
+
+    def t_group(features, idx):
+        Bn, C, _ = features.shape
+        _, np_, ns = idx.shape
+        return features.gather(2, idx.long().reshape(Bn, 1, np_ * ns).expand(-1, C, -1)).reshape(Bn, C, np_, ns)
+
+    def t_interp(features, idx, weight):
+        Bn, C, _ = features.shape
+        n = idx.shape[1]
+        g = features.gather(2, idx.long().reshape(Bn, 1, n * 3).expand(-1, C, -1)).reshape(Bn, C, n, 3)
+        return (g * weight.unsqueeze(1)).sum(dim=-1)
+    ref_ops = {
+        "furthest_point_sample": lambda xyz, n: torch.from_numpy(O.furthest_point_sample(xyz.cpu().numpy(), n)).to(DEV),
+        "ball_query": lambda r, ns, xyz, new: torch.from_numpy(O.ball_query(r, ns, xyz.cpu().numpy(), new.cpu().numpy())).to(DEV),
+        "three_nn": lambda u, k: tuple(torch.from_numpy(t).to(DEV) for t in O.three_nn(u.cpu().numpy(), k.cpu().numpy())),
+        "grouping_operation": t_group,
+        "gather_operation": lambda f, idx: f.gather(2, idx.long().unsqueeze(1).expand(-1, f.shape[1], -1)),
+        "three_interpolate": t_interp,
+    }
+    saved = {k: getattr(pointnet2, k) for k in ref_ops}
+    try:
+        for k, v in ref_ops.items():
+            setattr(pointnet2, k, v)
+        want, gwant = run(b)
+    finally:
+        for k, v in saved.items():
+            setattr(pointnet2, k, v)
+    assert got.shape == (B * N, 64)
+    rms = float(want.pow(2).mean().sqrt())
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-3, atol=1e-3 * rms)
+    assert set(ggot) == set(gwant)
+    for k in gwant:
+        ref = gwant[k]
+        err = float((ggot[k] - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert err < 2e-3, (k, err)
