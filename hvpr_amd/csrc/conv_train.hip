@@ -227,13 +227,21 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float *__restrict__ z, 
     }
 }
 
-// fwd: mean, biased variance and 1/sqrt(var + eps) per channel; bwd: s1, s2 per channel.  One thread per channel, double sums.
+// fwd: mean, biased variance and 1/sqrt(var + eps) per channel; bwd: s1, s2 per channel.  One wave per channel: lanes stride over
+// the workgroup rows in double, then a fixed butterfly — deterministic.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __global__ void __launch_bounds__(256) k_bn_finalize(const float *__restrict__ ws, int blocks, int C, double count, float eps, int bwd,
                                                      float *__restrict__ o0, float *__restrict__ o1, float *__restrict__ o2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (c >= C) return;
     double a = 0.0, b = 0.0;
-    for (int i = 0; i < blocks; ++i) { a += (double)ws[(size_t)i * 2 * C + c]; b += (double)ws[(size_t)i * 2 * C + C + c]; }
+    for (int i = lane; i < blocks; i += 64) { a += (double)ws[(size_t)i * 2 * C + c]; b += (double)ws[(size_t)i * 2 * C + C + c]; }
+    a = wave_sum_f64(a); b = wave_sum_f64(b);
+    if (lane != 0) return;
     if (bwd) { o0[c] = (float)a; o1[c] = (float)b; return; }
     const double m = a / count;
     double var = b / count - m * m;
@@ -327,7 +335,7 @@ extern "C" int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, s, z, nullptr, P, C, nullptr, nullptr, nullptr, nullptr, 0,
                        (float *)workspace);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 256)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, eps, 0, mean,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, eps, 0, mean,
                        var, invstd);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
@@ -356,7 +364,7 @@ extern "C" int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long l
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, s, z, dy, P, C, scale, shift, mean, invstd, relu, (float *)workspace);
     // s1 -> dbeta, s2 -> dgamma  (d beta = sum dy_m, d gamma = sum dy_m * xhat)
-    hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 256)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, 0.f, 1, dbeta,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, 0.f, 1, dbeta,
                        dgamma, (float *)nullptr);
     const long long n4 = P * (C / 4);
     long long g = (n4 + 255) / 256;

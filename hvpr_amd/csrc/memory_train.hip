@@ -150,7 +150,6 @@ __global__ void __launch_bounds__(kThreads) k_memtrain_bwd_rows(const float *__r
     float *s_logit = (float *)smem;                      // [16][kPitch]: logits, then a_j in place
     float *s_f = s_logit + kRows * kPitch;               // [16][64]
     float *s_abar = s_f + kRows * kC;                    // [16][64]  a . W
-    float *s_part = s_abar + kRows * kC;                 // [16 waves][16 x 16] partial products
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const long long r0 = (long long)blockIdx.x * kRows;
     const int nr = (int)min((long long)kRows, R - r0);
@@ -217,36 +216,55 @@ __global__ void __launch_bounds__(kThreads) k_memtrain_bwd_rows(const float *__r
             if (lane == 0) crow[r0 + p] = c_row;
         }
     }
-    __syncthreads();          // every row of s_logit now holds a_j
-    // a . W for the 16 rows: D (16 rows x 16 channels) += A (rows x 4 items) . B (4 items x channels) on v_mfma_f32_16x16x4_f32.
-    // wave w: channel block cb = w & 3, item quarter w >> 2; the four quarters are added through LDS.
+    // every row of s_logit now holds a_j.  The dense product is only needed by rows with a non-empty support (c != 0 only there):
+    // a workgroup without any (the state right after initialisation, where no softmax value reaches the threshold) is done.
+    if (!__syncthreads_or(live ? 1 : 0)) {
+        if (wid < nr) dx[(r0 + wid) * kC + lane] = 0.f;
+        return;
+    }
+    // abar = a . W for the 16 rows on v_mfma_f32_16x16x4_f32: D (16 rows x 16 channels) += A (rows x 4 items) . B (4 items x 16
+    // channels).  Lane (l15, q) of B supplies channels 4 l15 .. 4 l15 + 3 of item 4 s + q — ONE float4 of the row-major bank,
+    // 256 contiguous bytes per item over the 16 lanes — to four MFMAs (channel = 4 l15 + r for accumulator r: which 16
+    // channels an MFMA covers is a free choice).  Every wave covers all 64 channels for its sixteenth of the items; the sixteen
+    // partial results are added through LDS (the logits area: nobody reads a_j any more after the barrier).
     {
-        const int l15 = lane & 15, q = lane >> 4, cb = wid & 3, part = wid >> 2;
-        const int n4 = (n_items + 3) >> 2, per = (n4 + 3) / 4;
-        const int k_lo = part * per, k_hi = min(n4, k_lo + per);
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int k4 = k_lo; k4 < k_hi; k4 += 8) {             // eight k steps per round: the bank loads of a round are in flight together
-            float av[8], bv[8];
+        const int l15 = lane & 15, q = lane >> 4;
+        const int n4 = (n_items + 3) >> 2, per = (n4 + kWaves - 1) / kWaves;
+        const int k_lo = wid * per, k_hi = min(n4, k_lo + per);
+        f32x4 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k4 = k_lo; k4 < k_hi; k4 += 8) {             // eight k steps per round: their bank loads are in flight together
+            float av[8];
+            float4 bv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int item = 4 * (k4 + u) + q;
                 const bool ok = k4 + u < k_hi && item < n_items;
-                av[u] = ok ? s_logit[l15 * kPitch + item] : 0.f;                                 // A[row = l15][k = q]
-                bv[u] = ok ? bank[(size_t)item * kC + 16 * cb + l15] : 0.f;                      // B[k = q][channel = l15]
+                av[u] = ok ? s_logit[l15 * kPitch + item] : 0.f;                                                   // A[row = l15][k = q]
+                bv[u] = ok ? *(const float4 *)(bank + (size_t)item * kC + 4 * l15) : make_float4(0.f, 0.f, 0.f, 0.f);   // B[k = q][channels 4 l15 ..]
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u].w, acc[3], 0, 0, 0);
+            }
         }
-        // C/D map: column (channel) = l15, row (row of x) = 4 q + reg
+        __syncthreads();          // all waves are done with a_j: the logits area becomes the partial-sum area [wave][row][channel]
+        // C/D map: column j = l15 (channel 4 l15 + r of accumulator r), row (row of x) = 4 q + reg
+        float *part = s_logit + wid * (kRows * kC);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_part[wid * 256 + (4 * q + r) * 16 + l15] = acc[r];
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[(4 * q + g) * kC + 4 * l15 + r] = acc[r][g];
     }
     __syncthreads();
     for (int i = tid; i < kRows * kC; i += kThreads) {
-        const int rr = i / kC, ch = i % kC, cb = ch >> 4, c16 = ch & 15;
         float s = 0.f;
 #pragma unroll
-        for (int part = 0; part < 4; ++part) s += s_part[(part * 4 + cb) * 256 + rr * 16 + c16];
+        for (int w = 0; w < kWaves; ++w) s += s_logit[w * (kRows * kC) + i];
         s_abar[i] = s;
     }
     __syncthreads();
@@ -353,7 +371,7 @@ __global__ void __launch_bounds__(256) k_zero_f(float *__restrict__ p, long long
 
 constexpr int kSplits = 32;
 size_t fwd_lds() { return (size_t)kRows * kPitch * 4 + kRows * kC * 4; }
-size_t bwd_lds() { return (size_t)kRows * kPitch * 4 + 2 * kRows * kC * 4 + kWaves * 256 * 4; }
+size_t bwd_lds() { return (size_t)kRows * kPitch * 4 + 2 * kRows * kC * 4; }
 
 }  // namespace
 
