@@ -14,10 +14,12 @@
 //   backward rows    recomputes the logits, then per row  q = sum_S t dt,  ds = (dt - q) / n,  da = ds hs'(a),  c = sum_S a da,
 //                    dl_j = a_j (da_j - c)  for EVERY item (softmax couples them all),
 //                    dx = sum_S a da w  -  c * (a . W)          (the dense product a . W: a second matrix-core pass over LDS)
-//                    dW_j += t_j dy + a_j da_j x   for j in S  (fp32 atomics: a few rows of the bank per row of x)
-//   backward items   the dense remainder  dW_j -= sum_r a_rj c_r x_r : item-block-stationary, the attention tile is recomputed
-//                    (x W_blk^T on the matrix cores), scaled to a c in registers and fed back as the A operand of the second
-//                    product without leaving the accumulator layout.
+//                    and the per-row scalars (c, q) for the bank gradient.
+//   backward items   dW_j = sum_r [ a_rj (da_rj - c_r) x_r + t_rj dy_r ]: item-block-stationary; the logits tile x W_blk^T AND the
+//                    tile dy W_blk^T (= dt) are recomputed on the matrix cores, turned into the two coefficient tiles in the
+//                    accumulator registers and fed back as the A operands of the two second products without leaving the
+//                    accumulator layout.  No atomics anywhere: a first version scatter-added the support terms from the row
+//                    kernel (64 atomics per hit, 15 M per call on a few hot bank rows: 1.5 ms of its 2.3 ms).
 #include "common.h"
 
 namespace {
@@ -144,8 +146,7 @@ __global__ void __launch_bounds__(kThreads) k_memtrain_fwd(const float *__restri
 __global__ void __launch_bounds__(kThreads) k_memtrain_bwd_rows(const float *__restrict__ x, const float *__restrict__ dy, long long R,
                                                                 const float *__restrict__ bank, const float4 *__restrict__ bank_packed,
                                                                 int n_items, float lambd, const float *__restrict__ stats,
-                                                                float *__restrict__ dx, float *__restrict__ dW /* atomics */,
-                                                                float *__restrict__ crow /* [R] */) {
+                                                                float *__restrict__ dx, float *__restrict__ crow /* [R][2]: c, q */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_logit = (float *)smem;                      // [16][kPitch]: logits, then a_j in place
     float *s_f = s_logit + kRows * kPitch;               // [16][64]
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(kThreads) k_memtrain_bwd_rows(const float *__r
     __syncthreads();
     logits_to_lds(s_f, s_logit, bank_packed, n_items);
     __syncthreads();
-    float c_row = 0.f, dxs = 0.f;          // of the row this wave owns (p = wid)
+    float c_row = 0.f, dxs = 0.f, q_row = 0.f;          // of the row this wave owns (p = wid)
     bool live = false;
     {
         const int p = wid;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(kThreads) k_memtrain_bwd_rows(const float *__r
             float *row = s_logit + p * kPitch;
             const float4 st = *(const float4 *)(stats + (r0 + p) * 4);
             const float mx = st.x, inv_z = 1.f / st.y, n = st.z;
-            const float dyc = dy[(r0 + p) * kC + lane], xc = s_f[p * kC + lane];
+            const float dyc = dy[(r0 + p) * kC + lane];
             live = n > 0.f;
             const float inv_n = 1.f / fmaxf(n, 1e-12f);
             float v[kItemsPad / 64];
@@ -188,14 +189,14 @@ __global__ void __launch_bounds__(kThreads) k_memtrain_bwd_rows(const float *__r
                         q = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(tj), src)), dt, q);
                     }
                 }
-                // pass 2: da, c, the sparse parts of dx and dW
+                q_row = q;
+                // pass 2: da, c, the sparse part of dx
 #pragma unroll
                 for (int t = 0; t < kItemsPad / 64; ++t) {
                     const float a = v[t];
                     const bool hit = a > lambd;
                     unsigned long long m = __ballot(hit);
                     if (m == 0ull) continue;
-                    const float tj = hit ? hard_shrink(a, lambd) * inv_n : 0.f;
                     const float hg = hit ? hard_shrink_grad(a, lambd) : 0.f;
                     while (m) {
                         const int src = __ffsll((long long)m) - 1;
@@ -204,16 +205,14 @@ __global__ void __launch_bounds__(kThreads) k_memtrain_bwd_rows(const float *__r
                         const float w = bank[(size_t)j * kC + lane];
                         const float dt = hvpr_reduce_sum<64>(dyc * w);
                         const float aj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), src));
-                        const float t_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tj), src));
                         const float da = (dt - q) * inv_n * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hg), src));
                         const float ada = aj * da;
                         c_row += ada;
                         dxs = fmaf(ada, w, dxs);
-                        atomicAdd(dW + (size_t)j * kC + lane, fmaf(t_j, dyc, ada * xc));
                     }
                 }
             }
-            if (lane == 0) crow[r0 + p] = c_row;
+            if (lane == 0) *(float2 *)(crow + 2 * (r0 + p)) = make_float2(c_row, q_row);
         }
     }
     // every row of s_logit now holds a_j.  The dense product is only needed by rows with a non-empty support (c != 0 only there):
@@ -271,21 +270,23 @@ __global__ void __launch_bounds__(kThreads) k_memtrain_bwd_rows(const float *__r
     if (wid < nr) dx[(r0 + wid) * kC + lane] = live ? dxs - c_row * s_abar[wid * kC + lane] : 0.f;
 }
 
-// ------------------------------------------------------------------------------------------------ backward, dense dW term
-// dW[j] -= sum_r a_rj c_r x_r.  Workgroup = 128 items (4 waves x 32) x a contiguous slice of the rows, walked 64 rows at a time:
-//   P^T (rows x items) = x W_blk^T            32x32x2 MFMA, M = rows, N = items, K = 64 channels
-//   P <- exp(P - max_r) / Z_r * c_r           in the accumulator registers
-//   dWpart (items x channels) += P (items x rows) . x (rows x channels): an accumulator register r of P^T holds (row rho(r) + 4 *
-//   half, item lane & 31) — exactly the A operand A[i = item][k = half] of a 32x32x2 MFMA whose two k are rows rho(r) and
-//   rho(r) + 4, so P never leaves its registers.
+// ------------------------------------------------------------------------------------------------ backward, bank gradient
+// dW[j] = sum_r [ cx_rj x_r + cy_rj dy_r ],  cx = a (da - c),  cy = t   (da, t = 0 outside the support a > lambda).
+// Workgroup = 128 items (4 waves x 32) x a contiguous slice of the rows, walked 64 rows at a time:
+//   P^T (rows x items) = x W_blk^T, D^T = dy W_blk^T      32x32x2 MFMA, M = rows, N = items, K = 64 channels
+//   a = exp(P - max_r) / Z_r;  cx, cy from (a, D, q_r, 1/n_r, c_r)   in the accumulator registers
+//   dWpart (items x channels) += CX (items x rows) . x + CY . dy: an accumulator register r of P^T holds (row rho(r) + 4 * half,
+//   item lane & 31) — exactly the A operand A[i = item][k = half] of a 32x32x2 MFMA whose two k are rows rho(r) and rho(r) + 4,
+//   so the coefficient tiles never leave their registers.
 constexpr int kIB = 128, kRT = 64, kXP = kC + 1;      // LDS row pitch 65: a column of 32 rows hits 32 different banks
 
-__global__ void __launch_bounds__(256) k_memtrain_bwd_items(const float *__restrict__ x, long long R, const float *__restrict__ bank, int n_items,
+__global__ void __launch_bounds__(256) k_memtrain_bwd_items(const float *__restrict__ x, const float *__restrict__ dy, long long R,
+                                                            const float *__restrict__ bank, int n_items, float lambd,
                                                             const float *__restrict__ stats, const float *__restrict__ crow, int n_splits,
                                                             float *__restrict__ part /* [n_splits][n_items_pad128][64] */) {
-    __shared__ float s_x[kRT * kXP];        // 16.6 KB
-    __shared__ float s_w[kIB * kXP];        // 33 KB, the item block (zero rows past n_items)
-    __shared__ float s_mx[kRT], s_iz[kRT], s_c[kRT];
+    __shared__ float s_x[kRT * kXP], s_dy[kRT * kXP];   // 2 x 16.6 KB
+    __shared__ float s_w[kIB * kXP];                    // 33 KB, the item block (zero rows past n_items)
+    __shared__ float s_mx[kRT], s_iz[kRT], s_c[kRT], s_q[kRT], s_in[kRT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int ib = blockIdx.x, split = blockIdx.y;
     const int j0 = ib * kIB;
@@ -304,43 +305,63 @@ __global__ void __launch_bounds__(256) k_memtrain_bwd_items(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) dw[b][r] = 0.f;
     const int item_l = wid * 32 + l31;          // this lane's item inside the block (B column / A row)
+    const bool item_ok = j0 + item_l < n_items;
     for (long long rt = rt_lo; rt < rt_hi; ++rt) {
         const long long row0 = rt * kRT;
         __syncthreads();
         for (int i = tid; i < kRT * kC / 4; i += 256) {
             const long long rr = row0 + i / (kC / 4);
-            const float4 xv = rr < R ? *(const float4 *)(x + rr * kC + (i % (kC / 4)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float *d = s_x + (i / (kC / 4)) * kXP + (i % (kC / 4)) * 4;
+            const int c4 = (i % (kC / 4)) * 4;
+            const float4 xv = rr < R ? *(const float4 *)(x + rr * kC + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 dv = rr < R ? *(const float4 *)(dy + rr * kC + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float *d = s_x + (i / (kC / 4)) * kXP + c4, *e = s_dy + (i / (kC / 4)) * kXP + c4;
             d[0] = xv.x; d[1] = xv.y; d[2] = xv.z; d[3] = xv.w;
+            e[0] = dv.x; e[1] = dv.y; e[2] = dv.z; e[3] = dv.w;
         }
         if (tid < kRT) {
             const long long rr = row0 + tid;
-            const float4 st = rr < R ? *(const float4 *)(stats + rr * 4) : make_float4(0.f, 1.f, 0.f, 0.f);
-            s_mx[tid] = st.x; s_iz[tid] = 1.f / st.y; s_c[tid] = rr < R ? crow[rr] : 0.f;
+            const bool ok = rr < R;
+            const float4 st = ok ? *(const float4 *)(stats + rr * 4) : make_float4(0.f, 1.f, 0.f, 0.f);
+            const float2 cq = ok ? *(const float2 *)(crow + 2 * rr) : make_float2(0.f, 0.f);
+            s_mx[tid] = st.x; s_iz[tid] = ok ? 1.f / st.y : 0.f; s_c[tid] = cq.x; s_q[tid] = cq.y;
+            s_in[tid] = st.z > 0.f ? 1.f / fmaxf(st.z, 1e-12f) : 0.f;          // rows without support: t = 0 and da = 0
         }
         __syncthreads();
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {        // 32 rows at a time
             // P^T[row][item] = sum_ch x[row][ch] W[item][ch]: A[i = row = l31][k] = x, B[k][j = item = l31] = W, k = channel pair
-            f32x16 p;
+            f32x16 p, d;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { p[r] = 0.f; d[r] = 0.f; }
 #pragma unroll
-            for (int kk = 0; kk < kC / 2; ++kk)
-                p = __builtin_amdgcn_mfma_f32_32x32x2f32(s_x[(rb * 32 + l31) * kXP + 2 * kk + half], s_w[item_l * kXP + 2 * kk + half], p, 0, 0, 0);
-            // C/D map: column (item) = l31, row (row of x) = (r & 3) + 8 (r >> 2) + 4 half
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                p[r] = expf(p[r] - s_mx[rr]) * s_iz[rr] * s_c[rr];
+            for (int kk = 0; kk < kC / 2; ++kk) {
+                const float wv = s_w[item_l * kXP + 2 * kk + half];
+                p = __builtin_amdgcn_mfma_f32_32x32x2f32(s_x[(rb * 32 + l31) * kXP + 2 * kk + half], wv, p, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(s_dy[(rb * 32 + l31) * kXP + 2 * kk + half], wv, d, 0, 0, 0);
             }
-            // dw[item][ch] += sum_rows P[item][row] x[row][ch]: A[i = item = l31][k = half] = p[r] (rows rho(r), rho(r) + 4),
-            // B[k = half][j = ch = l31] = x[row rho(r) + 4 half][ch]
+            // C/D map: column (item) = l31, row (row of x) = (r & 3) + 8 (r >> 2) + 4 half.   p -> cx, d -> cy
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float a = item_ok ? expf(p[r] - s_mx[rr]) * s_iz[rr] : 0.f;
+                float cx = -a * s_c[rr], cy = 0.f;
+                if (a > lambd) {
+                    const float in = s_in[rr];
+                    cy = hard_shrink(a, lambd) * in;
+                    cx = a * ((d[r] - s_q[rr]) * in * hard_shrink_grad(a, lambd) - s_c[rr]);
+                }
+                p[r] = cx; d[r] = cy;
+            }
+            // dw[item][ch] += sum_rows CX[item][row] x[row][ch] + CY[item][row] dy[row][ch]: A[i = item = l31][k = half] = the
+            // coefficient register (rows rho(r), rho(r) + 4), B[k = half][j = ch = l31] = x / dy [row rho(r) + 4 half][ch]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) dw[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], s_x[rr * kXP + b * 32 + l31], dw[b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) {
+                    dw[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], s_x[rr * kXP + b * 32 + l31], dw[b], 0, 0, 0);
+                    dw[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[r], s_dy[rr * kXP + b * 32 + l31], dw[b], 0, 0, 0);
+                }
             }
         }
     }
@@ -355,14 +376,14 @@ __global__ void __launch_bounds__(256) k_memtrain_bwd_items(const float *__restr
         }
 }
 
-// dW[j][c] -= sum over splits of part[split][j][c]
+// dW[j][c] = sum over splits of part[split][j][c], in split order
 __global__ void __launch_bounds__(256) k_memtrain_items_reduce(const float *__restrict__ part, int n_splits, int n_items, int ipad,
                                                                float *__restrict__ dW) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items * kC) return;
     float s = 0.f;
     for (int k = 0; k < n_splits; ++k) s += part[(size_t)k * ipad * kC + i];
-    dW[i] -= s;
+    dW[i] = s;
 }
 
 __global__ void __launch_bounds__(256) k_zero_f(float *__restrict__ p, long long n) {
@@ -409,8 +430,11 @@ extern "C" int hvpr_memory_train_bwd_f32(const float *x, const float *dy, long l
     if (n_items > kItemsPad || !(shrink_thres > 0.f)) return HVPR_ERR_UNSUPPORTED;
     if (!dbank || !bank) return HVPR_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_zero_f, dim3(hvpr_cdiv((long long)n_items * kC, 256)), dim3(256), 0, s, dbank, (long long)n_items * kC);
-    if (R == 0) { HVPR_CHECK_LAUNCH(); return HVPR_OK; }
+    if (R == 0) {
+        hipLaunchKernelGGL(k_zero_f, dim3(hvpr_cdiv((long long)n_items * kC, 256)), dim3(256), 0, s, dbank, (long long)n_items * kC);
+        HVPR_CHECK_LAUNCH();
+        return HVPR_OK;
+    }
     if (!x || !dy || !row_stats || !dx || !row_scratch || !workspace) return HVPR_ERR_INVALID_ARG;
     if (workspace_bytes < hvpr_memory_train_workspace_bytes(n_items)) return HVPR_ERR_WORKSPACE;
     float4 *packed = (float4 *)workspace;
@@ -421,9 +445,10 @@ extern "C" int hvpr_memory_train_bwd_f32(const float *x, const float *dy, long l
     static unsigned long long lds_set = 0ull;
     if (hvpr_ensure_dyn_lds((const void *)k_memtrain_bwd_rows, (int)bwd_lds(), &lds_set) != 0) return HVPR_ERR_LAUNCH;
     hipLaunchKernelGGL(k_memtrain_bwd_rows, dim3((unsigned)hvpr_cdiv(R, kRows)), dim3(kThreads), bwd_lds(), s, x, dy, R, bank, packed, n_items,
-                       shrink_thres, row_stats, dx, dbank, row_scratch);
+                       shrink_thres, row_stats, dx, row_scratch);
     const int ipad = (n_items + kIB - 1) / kIB * kIB;
-    hipLaunchKernelGGL(k_memtrain_bwd_items, dim3(ipad / kIB, kSplits), dim3(256), 0, s, x, R, bank, n_items, row_stats, row_scratch, kSplits, part);
+    hipLaunchKernelGGL(k_memtrain_bwd_items, dim3(ipad / kIB, kSplits), dim3(256), 0, s, x, dy, R, bank, n_items, shrink_thres, row_stats,
+                       row_scratch, kSplits, part);
     hipLaunchKernelGGL(k_memtrain_items_reduce, dim3(hvpr_cdiv((long long)n_items * kC, 256)), dim3(256), 0, s, part, kSplits, n_items, ipad, dbank);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;

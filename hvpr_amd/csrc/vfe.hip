@@ -400,8 +400,11 @@ int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxe
                       spatial_scale, 0, n_cells, canvas_state};
     GatherSrc g{a.points, a.point_stride, a.xyz_col, a.batch, a.nx, a.ny, a.nz, a.max_voxels, a.cap_mode, capacity, w,
                 voxel_offsets, voxels, coords, num_points, spatial, spatial_channels, spatial_scale, blocks, cj, idx_bits};
-    long long fill = (n_cells + 767) / 768;       // three 64-cell steps per wave: few, long-lived workgroups — they hold slots
-    if (fill > 1024) fill = 1024;                 // the pillar workgroups want
+    // three 64-cell steps per wave: few, long-lived workgroups — they hold slots the pillar workgroups want.  (One or two steps
+    // per wave with correspondingly more workgroups, tried for the sparse clear of persistent canvases: 48.8 / 49.0 vs 48.3 us
+    // for the group — no difference.)
+    long long fill = (n_cells + 767) / 768;
+    if (fill > 1024) fill = 1024;
     hipLaunchKernelGGL(k_vfe<true>, dim3(blocks + (int)fill), dim3(256), 0, s, nullptr, nullptr, nullptr, capacity, a.max_points,
                        voxel_offsets + a.batch, v.vs_x, v.vs_y, v.vs_z, v.off_x, v.off_y, v.off_z, v.w0, v.b0, v.w1, v.b1, v.ws0,
                        v.bs0, v.ws1, v.bs1, pillar_features, scale_features, pillar_mask, g);

@@ -104,7 +104,7 @@ class _MemoryTrain(torch.autograd.Function):
         dy = dy.contiguous()
         R, n_items = x.shape[0], w.shape[0]
         dx, dw = torch.empty_like(x), torch.empty_like(w)
-        scratch = torch.empty((max(R, 1),), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((2 * max(R, 1),), dtype=torch.float32, device=x.device)
         ws = _MemoryTrain._ws(n_items, x.device)
         kernels.check(kernels.lib().hvpr_memory_train_bwd_f32(x.data_ptr(), kernels._ptr(dy, torch.float32, "dy"), R, w.data_ptr(), n_items, ctx.lambd,
                                                               stats.data_ptr(), dx.data_ptr(), dw.data_ptr(), scratch.data_ptr(), ws.data_ptr(),

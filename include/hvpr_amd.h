@@ -282,8 +282,8 @@ int hvpr_scatter_add_rows_f32(const float *src, const int32_t *idx, long long m,
  *         a = softmax(x W^T), s = relu(a - l) a / (|a - l| + 1e-12), t = s / max(||s||_1, 1e-12), y = t W
  *     x [R,64] (the k positive point features of every pillar, flattened), bank [n_items <= 2048, 64], shrink_thres l > 0.
  *     fwd: y [R,64]; row_stats [R,4] (softmax max, partition sum, ||s||_1) is what the backward needs.
- *     bwd: dx [R,64] and dbank [n_items,64] (overwritten) from dy [R,64]; row_scratch [R] floats; the sparse part of dbank
- *          uses fp32 atomics (summation order unspecified), the dense part is reduced in a fixed order.
+ *     bwd: dx [R,64] and dbank [n_items,64] (overwritten) from dy [R,64]; row_scratch [2 R] floats; no atomics — every sum
+ *          is formed in a fixed order (deterministic).
  *     workspace: hvpr_memory_train_workspace_bytes(n_items), no state between calls.
  * ------------------------------------------------------------------------------------------- */
 size_t hvpr_memory_train_workspace_bytes(int n_items);
