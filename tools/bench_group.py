@@ -56,10 +56,14 @@ def run(name, cfg, frames, iters=50):
 
 if __name__ == "__main__":
     car = hvpr_car_cfg()
-    run("hvpr_car batch 1", car, [synthetic.hvpr_frame(0)])
+    if "--only16" not in sys.argv and "--only-dense" not in sys.argv:
+        run("hvpr_car batch 1", car, [synthetic.hvpr_frame(0)])
     if "--car1" in sys.argv:
         sys.exit(0)
-    run("hvpr_car batch 16", car, [synthetic.hvpr_frame(i) for i in range(16)])
+    if "--only-dense" not in sys.argv:
+        run("hvpr_car batch 16", car, [synthetic.hvpr_frame(i) for i in range(16)])
+    if "--only16" in sys.argv:
+        sys.exit(0)
     dense = copy.deepcopy(car)
     rng = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
     dense.DATA_CONFIG.POINT_CLOUD_RANGE = rng
