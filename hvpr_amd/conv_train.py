@@ -12,6 +12,8 @@ Activations are NHWC tensors (N, H, W, C) — what torch calls channels_last —
                       hvpr_bn_relu_fwd_nhwc_f32, hvpr_bn_relu_bwd_nhwc_f32; running statistics updated like nn.BatchNorm2d
                       (momentum, unbiased variance, one update per CALL — SURVEY.md B.5).
 """
+import os
+
 import torch
 
 from . import kernels
@@ -31,7 +33,12 @@ def _workspace(nbytes, device):
 
 
 def _tile_cfg(cout):
-    return 0 if cout % 128 == 0 else 1        # 128 x 128 tiles win from batch 2 up; narrow layers keep 64 x 64
+    """Workgroup tile of hvpr_conv2d_nhwc_f32 (0 = 128 px x 128 ch, 1 = 64 x 64, 2 = 128 x 64).  Measured on the batch-16 training
+    step: 612 / 593 / 595 ms — the 64 x 64 tile the kernel was tuned on at batch 1 also wins here.  HVPR_TRAIN_TILE overrides."""
+    forced = os.environ.get("HVPR_TRAIN_TILE")
+    if forced is not None and (int(forced) != 0 or cout % 128 == 0):
+        return int(forced)
+    return 1
 
 
 def conv_fwd_raw(x, weight, stride=1):
