@@ -206,15 +206,17 @@ class BaseBEVBackbone_Scale(nn.Module):
         def nhwc(t):
             return t.permute(0, 2, 3, 1).contiguous()          # no copy for the channels_last canvases of the scatter
 
-        def cbr(seq, t):
+        def cbr(seq, t, gate=None, resid=None):
             """Sequential of [ZeroPad2d(1)?, Conv2d 3x3 (no bias), BatchNorm2d, ReLU] groups (:154-169, :171-175, :200-209): the
-            explicit zero pad + pad-0 conv of the strided entries is the same pad-1 convolution."""
+            explicit zero pad + pad-0 conv of the strided entries is the same pad-1 convolution.  gate / resid: the SFM step
+            gate * cbr(t) + resid folded into the last BatchNorm + ReLU."""
             mods, k = list(seq), 0
             while k < len(mods):
                 if isinstance(mods[k], nn.ZeroPad2d):
                     k += 1
                 conv, bn = mods[k], mods[k + 1]
-                t = ct.bn_relu(ct.conv(t, conv.weight, conv.stride[0]), bn)
+                last = k + 3 >= len(mods)
+                t = ct.bn_relu(ct.conv(t, conv.weight, conv.stride[0]), bn, gate=gate if last else None, resid=resid if last else None)
                 k += 3
             return t
 
@@ -223,7 +225,7 @@ class BaseBEVBackbone_Scale(nn.Module):
             sigmoid on a (N,2,H,W) tensor — left to torch; called once per use, as the reference does, so that its BatchNorm
             sees the same number of running-statistics updates."""
             sp = self.attention.spatial
-            return torch.sigmoid(sp.norm(sp.conv(pooled))).permute(0, 2, 3, 1)       # (N,H,W,1)
+            return torch.sigmoid(sp.norm(sp.conv(pooled))).permute(0, 2, 3, 1).contiguous()       # (N,H,W,1)
 
         x, xp = nhwc(data_dict["spatial_features"]), nhwc(data_dict["spatial_features_point"])
         y = nhwc(data_dict["spatial_scale_features"])
@@ -235,8 +237,8 @@ class BaseBEVBackbone_Scale(nn.Module):
             pooled = torch.cat((y.amax(dim=-1, keepdim=True), y.mean(dim=-1, keepdim=True)), dim=-1).permute(0, 3, 1, 2)
             xa, xpa = x, xp
             for _ in range(self.sfm_layer_nums[i]):
-                xa = gate(pooled) * cbr(self.sfmblocks_down[i], xa) + xa
-                xpa = gate(pooled) * cbr(self.sfmblocks_down[i], xpa) + xpa
+                xa = cbr(self.sfmblocks_down[i], xa, gate=gate(pooled), resid=xa)
+                xpa = cbr(self.sfmblocks_down[i], xpa, gate=gate(pooled), resid=xpa)
             de = self.deblocks[i]
             ups.append(ct.bn_relu(ct.deconv(xa, de[0].weight), de[1]))
             ups_p.append(ct.bn_relu(ct.deconv(xpa, de[0].weight), de[1]))

@@ -121,8 +121,11 @@ class _Deconv(torch.autograd.Function):
 
 
 class _BNReLU(torch.autograd.Function):
+    """y = relu(BN_train(z)); with (gate (N,H,W,1), resid (N,H,W,C)): y = gate * relu(BN_train(z)) + resid — the SFM step
+    x_att = attention(sfm(x_att), y) + x_att (base_bev_backbone.py:250-255) in the same two kernels."""
+
     @staticmethod
-    def forward(ctx, z, gamma, beta, eps, relu):
+    def forward(ctx, z, gamma, beta, eps, relu, gate, resid):
         z = z.contiguous()
         C = z.shape[-1]
         P = z.numel() // C
@@ -134,26 +137,32 @@ class _BNReLU(torch.autograd.Function):
         scale = (gamma.detach() * invstd).contiguous()
         shift = (beta.detach() - mean * scale).contiguous()
         y = torch.empty_like(z)
-        check(lib().hvpr_bn_relu_fwd_nhwc_f32(z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(), 1 if relu else 0, y.data_ptr(),
-                                              kernels._stream()), "hvpr_bn_relu_fwd_nhwc_f32")
-        ctx.save_for_backward(z, scale, shift, mean, invstd)
+        if gate is not None:
+            gate, resid = gate.detach().contiguous(), resid.detach().contiguous()
+            assert gate.numel() == P and resid.shape == z.shape
+        check(lib().hvpr_bn_relu_fwd_nhwc_f32(z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(), 1 if relu else 0,
+                                              kernels._ptr(gate, torch.float32, "gate"), kernels._ptr(resid, torch.float32, "resid"),
+                                              y.data_ptr(), kernels._stream()), "hvpr_bn_relu_fwd_nhwc_f32")
+        ctx.save_for_backward(z, scale, shift, mean, invstd, gate)
         ctx.relu = relu
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
-        z, scale, shift, mean, invstd = ctx.saved_tensors
+        z, scale, shift, mean, invstd, gate = ctx.saved_tensors
         dy = dy.contiguous()
         C = z.shape[-1]
         P = z.numel() // C
         dz = torch.empty_like(z)
         dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
+        dgate = torch.empty_like(gate) if gate is not None else None
         ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), z.device)
         check(lib().hvpr_bn_relu_bwd_nhwc_f32(kernels._ptr(dy, torch.float32, "dy"), z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(),
-                                              mean.data_ptr(), invstd.data_ptr(), 1 if ctx.relu else 0, dz.data_ptr(), dgamma.data_ptr(),
-                                              dbeta.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_relu_bwd_nhwc_f32")
-        return dz, dgamma, dbeta, None, None
+                                              mean.data_ptr(), invstd.data_ptr(), 1 if ctx.relu else 0, kernels._ptr(gate), kernels._ptr(dgate),
+                                              dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              kernels._stream()), "hvpr_bn_relu_bwd_nhwc_f32")
+        return dz, dgamma, dbeta, None, None, dgate, (dy if gate is not None else None)
 
 
 def conv(x, weight, stride=1):
@@ -165,9 +174,10 @@ def deconv(x, weight):
     return _Deconv.apply(x, weight)
 
 
-def bn_relu(z, bn, relu=True):
-    """Train-mode nn.BatchNorm2d `bn` (its weight / bias / eps / momentum / running buffers) + optional ReLU on NHWC `z`."""
-    y, mean, var = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu)
+def bn_relu(z, bn, relu=True, gate=None, resid=None):
+    """Train-mode nn.BatchNorm2d `bn` (its weight / bias / eps / momentum / running buffers) + optional ReLU on NHWC `z`; with
+    gate (N,H,W,1) and resid (N,H,W,C): gate * relu(bn(z)) + resid, differentiable in all of them."""
+    y, mean, var = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu, gate, resid)
     if bn.track_running_stats:
         with torch.no_grad():
             n = z.numel() // z.shape[-1]

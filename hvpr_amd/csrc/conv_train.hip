@@ -182,6 +182,7 @@ template <bool BWD>
 __global__ void __launch_bounds__(256) k_bn_reduce(const float *__restrict__ z, const float *__restrict__ dy, long long P, int C,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                    const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                                                   const float *__restrict__ gate /* [P] or null: dy is multiplied by it */,
                                                    float *__restrict__ ws /* [blocks][2][C] */) {
     __shared__ float4 s_a[256], s_b[256];
     const int groups = C / 4;                       // channel groups of 4
@@ -200,6 +201,7 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float *__restrict__ z, 
                 B.x = fmaf(v.x, v.x, B.x); B.y = fmaf(v.y, v.y, B.y); B.z = fmaf(v.z, v.z, B.z); B.w = fmaf(v.w, v.w, B.w);
             } else {        // s1 = sum dy * mask, s2 = sum dy * mask * xhat; mask = the ReLU passed (scale * z + shift > 0)
                 float4 d = *(const float4 *)(dy + p * C + 4 * g);
+                if (gate) { const float gp = gate[p]; d.x *= gp; d.y *= gp; d.z *= gp; d.w *= gp; }
                 if (relu) {
                     if (!(fmaf(v.x, sc.x, sh.x) > 0.f)) d.x = 0.f;
                     if (!(fmaf(v.y, sc.y, sh.y) > 0.f)) d.y = 0.f;
@@ -249,15 +251,22 @@ __global__ void __launch_bounds__(256) k_bn_finalize(const float *__restrict__ w
     o0[c] = (float)m; o1[c] = (float)var; o2[c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// y = relu(z * scale + shift)   (scale = gamma * invstd, shift = beta - mean * scale)
+// y = relu(z * scale + shift)   (scale = gamma * invstd, shift = beta - mean * scale);  with a gate: y = gate[p] * relu(..) + resid
+// (the SFM step x_att = attention(sfm(x_att), y) + x_att, base_bev_backbone.py:250-255)
 __global__ void __launch_bounds__(256) k_bn_apply(const float4 *__restrict__ z, long long n4, int groups, const float *__restrict__ scale,
-                                                  const float *__restrict__ shift, int relu, float4 *__restrict__ y) {
+                                                  const float *__restrict__ shift, int relu, const float *__restrict__ gate,
+                                                  const float4 *__restrict__ resid, float4 *__restrict__ y) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(i % groups);
         const float4 sc = *(const float4 *)(scale + 4 * g), sh = *(const float4 *)(shift + 4 * g);
         const float4 v = z[i];
         float4 r = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
         if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        if (gate) {
+            const float gp = gate[i / groups];
+            const float4 q = resid[i];
+            r = make_float4(fmaf(gp, r.x, q.x), fmaf(gp, r.y, q.y), fmaf(gp, r.z, q.z), fmaf(gp, r.w, q.w));
+        }
         y[i] = r;
     }
 }
@@ -267,14 +276,30 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4 *__restrict__
                                                       const float *__restrict__ scale, const float *__restrict__ shift,
                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
                                                       const float *__restrict__ s1, const float *__restrict__ s2, float inv_n, int relu,
+                                                      const float *__restrict__ gate, float *__restrict__ dgate /* zeroed, atomics */,
                                                       float4 *__restrict__ dz) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    // grid-stride loop with trip counts that are uniform per wave (the stride is a multiple of 64 and of `groups`): the lanes of
+    // one pixel stay together, so the per-pixel sum for dgate is a butterfly inside the wave
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n_iter = (n4 + stride - 1) / stride;
+    for (long long it = 0; it < n_iter; ++it) {
+        const long long i = it * stride + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = i < n4;
+        float ga = 0.f;
+        if (live) {
         const int g = (int)(i % groups);
         const float4 sc = *(const float4 *)(scale + 4 * g), sh = *(const float4 *)(shift + 4 * g);
         const float4 mu = *(const float4 *)(mean + 4 * g), is = *(const float4 *)(invstd + 4 * g);
         const float4 a1 = *(const float4 *)(s1 + 4 * g), a2 = *(const float4 *)(s2 + 4 * g);
         const float4 v = z[i];
         float4 d = dy[i];
+        if (gate) {          // y = gate * a + resid: d a = gate * dy, d gate = sum_c a * dy
+            const float4 a = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+            ga = (relu ? fmaxf(a.x, 0.f) : a.x) * d.x + (relu ? fmaxf(a.y, 0.f) : a.y) * d.y + (relu ? fmaxf(a.z, 0.f) : a.z) * d.z +
+                 (relu ? fmaxf(a.w, 0.f) : a.w) * d.w;
+            const float gp = gate[i / groups];
+            d.x *= gp; d.y *= gp; d.z *= gp; d.w *= gp;
+        }
         if (relu) {
             if (!(fmaf(v.x, sc.x, sh.x) > 0.f)) d.x = 0.f;
             if (!(fmaf(v.y, sc.y, sh.y) > 0.f)) d.y = 0.f;
@@ -287,10 +312,22 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4 *__restrict__
         r.z = sc.z * (d.z - a1.z * inv_n - (v.z - mu.z) * is.z * (a2.z * inv_n));
         r.w = sc.w * (d.w - a1.w * inv_n - (v.w - mu.w) * is.w * (a2.w * inv_n));
         dz[i] = r;
+        }
+        if (gate) {          // wave-uniform branch
+            // sum over the lanes of one pixel: `groups` consecutive lanes (a power of two <= 64 inside the wave; wider pixels span
+            // several waves and meet in the atomic)
+            const int w = groups < 64 ? groups : 64;
+            for (int o = w >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
+            if (live && ((threadIdx.x & 63) & (w - 1)) == 0) atomicAdd(dgate + i / groups, ga);
+        }
     }
 }
 
 int bn_blocks(long long P) { return (int)((P + kBnSlab - 1) / kBnSlab); }
+
+__global__ void __launch_bounds__(256) k_zero_p(float *__restrict__ p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
 
 }  // namespace
 
@@ -333,7 +370,7 @@ extern "C" int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float 
     if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
     const int blocks = bn_blocks(P);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, s, z, nullptr, P, C, nullptr, nullptr, nullptr, nullptr, 0,
+    hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, s, z, nullptr, P, C, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                        (float *)workspace);
     hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, eps, 0, mean,
                        var, invstd);
@@ -341,28 +378,32 @@ extern "C" int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float 
     return HVPR_OK;
 }
 
-extern "C" int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, float *y,
-                                         hvpr_stream_t stream) {
-    if (!z || !scale || !shift || !y || P < 1) return HVPR_ERR_INVALID_ARG;
+extern "C" int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu,
+                                         const float *gate, const float *resid, float *y, hvpr_stream_t stream) {
+    if (!z || !scale || !shift || !y || P < 1 || ((gate == nullptr) != (resid == nullptr))) return HVPR_ERR_INVALID_ARG;
     if (C < 4 || C % 4 != 0) return HVPR_ERR_UNSUPPORTED;
     const long long n4 = P * (C / 4);
     long long blocks = (n4 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)z, n4, C / 4, scale, shift, relu,
-                       (float4 *)y);
+                       gate, (const float4 *)resid, (float4 *)y);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
 
 extern "C" int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
-                                         const float *mean, const float *invstd, int relu, float *dz, float *dgamma, float *dbeta,
-                                         void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
+                                         const float *mean, const float *invstd, int relu, const float *gate, float *dgate, float *dz,
+                                         float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
     if (!dy || !z || !scale || !shift || !mean || !invstd || !dz || !dgamma || !dbeta || !workspace || P < 1) return HVPR_ERR_INVALID_ARG;
+    if ((gate == nullptr) != (dgate == nullptr)) return HVPR_ERR_INVALID_ARG;
     if (C < 4 || C % 4 != 0 || C > 1024) return HVPR_ERR_UNSUPPORTED;
+    const int groups_ = C / 4;
+    if (gate && (groups_ & (groups_ - 1)) != 0) return HVPR_ERR_UNSUPPORTED;       // the gated form needs C / 4 to be a power of two
     if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
     const int blocks = bn_blocks(P);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, s, z, dy, P, C, scale, shift, mean, invstd, relu, (float *)workspace);
+    if (dgate) hipLaunchKernelGGL(k_zero_p, dim3(hvpr_cdiv(P, 256) > 8192 ? 8192 : hvpr_cdiv(P, 256)), dim3(256), 0, s, dgate, P);
+    hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, s, z, dy, P, C, scale, shift, mean, invstd, relu, gate, (float *)workspace);
     // s1 -> dbeta, s2 -> dgamma  (d beta = sum dy_m, d gamma = sum dy_m * xhat)
     hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, 0.f, 1, dbeta,
                        dgamma, (float *)nullptr);
@@ -370,7 +411,7 @@ extern "C" int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long l
     long long g = (n4 + 255) / 256;
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, s, (const float4 *)dy, (const float4 *)z, n4, C / 4, scale, shift, mean,
-                       invstd, dbeta, dgamma, (float)(1.0 / (double)P), relu, (float4 *)dz);
+                       invstd, dbeta, dgamma, (float)(1.0 / (double)P), relu, gate, dgate, (float4 *)dz);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }

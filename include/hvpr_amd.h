@@ -305,6 +305,9 @@ int hvpr_memory_train_bwd_f32(const float *x, const float *dy, long long R, cons
  *     hvpr_bn_relu_fwd_nhwc_f32: y = max(0, z * scale + shift) (relu == 0: no max); scale = gamma * invstd, shift = beta - mean * scale.
  *     hvpr_bn_relu_bwd_nhwc_f32: dz, dgamma, dbeta of y = relu(gamma * (z - mean) * invstd + beta) with BATCH statistics
  *         (the mean / variance terms are differentiated through).
+ *     gate [P] + resid [P,C] (both or neither; may be NULL): the SFM step fused in, y = gate[p] * relu(...) + resid
+ *         (x_att = attention(sfm(x_att), y) + x_att, base_bev_backbone.py:250-255); the backward then also returns dgate [P]
+ *         (= sum_c relu(...) * dy, overwritten) and propagates gate * dy; d resid = dy.  Needs C / 4 to be a power of two.
  *     C % 4 == 0, C <= 1024 for the reductions.
  * ------------------------------------------------------------------------------------------- */
 size_t hvpr_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int taps, int stride);
@@ -313,11 +316,11 @@ int hvpr_conv2d_wgrad_nhwc_f32(const float *x, int N, int H, int W, int Cin, con
 size_t hvpr_bn_workspace_bytes(long long P, int C);
 int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float eps, float *mean, float *var, float *invstd, void *workspace,
                            size_t workspace_bytes, hvpr_stream_t stream);
-int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, float *y,
-                              hvpr_stream_t stream);
+int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, const float *gate,
+                              const float *resid, float *y, hvpr_stream_t stream);
 int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
-                              const float *mean, const float *invstd, int relu, float *dz, float *dgamma, float *dbeta, void *workspace,
-                              size_t workspace_bytes, hvpr_stream_t stream);
+                              const float *mean, const float *invstd, int relu, const float *gate, float *dgate, float *dz, float *dgamma,
+                              float *dbeta, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a14 (training)  Optimiser step over ONE flat fp32 parameter buffer (and matching flat gradient / moment buffers, all

@@ -158,3 +158,27 @@ def test_backbone_training_forward_backward_hip_equals_torch_autograd():
     assert eh.max() < 3 * et.max() + 2e-3 and eh.max() < 3e-2, (eh.max(), et.max())
     for k in r[4]:          # running statistics, incl. the shared SFM / gate BatchNorms updated once per call
         _close(h[4][k].float(), r[4][k].float(), rtol=1e-4, what="buffer " + k)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 48, 128), (1, 31, 45, 256), (2, 9, 7, 512), (3, 5, 6, 32)])
+def test_bn_relu_with_fused_sfm_gate_matches_torch(shape):
+    """gate * relu(BN_train(z)) + resid in one forward / one backward kernel pair (the SFM step, base_bev_backbone.py:250-255):
+    output and the gradients of z, gamma, beta, gate and resid vs torch autograd."""
+    g = torch.Generator().manual_seed(shape[2])
+    C = shape[-1]
+    z = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(DEV).requires_grad_(True)
+    gate = torch.rand(shape[:3] + (1,), generator=g).to(DEV).requires_grad_(True)
+    resid = torch.randn(shape, generator=g).to(DEV).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    ref = copy.deepcopy(bn)
+    y = ct.bn_relu(z, bn, gate=gate, resid=resid)
+    zr, gr, rr = (t.detach().clone().requires_grad_(True) for t in (z, gate, resid))
+    yr = gr * torch.relu(ref(zr.permute(0, 3, 1, 2))).permute(0, 2, 3, 1) + rr
+    _close(y, yr, what="forward")
+    dy = torch.randn(shape, generator=g).to(DEV)
+    got = torch.autograd.grad(y, (z, bn.weight, bn.bias, gate, resid), dy)
+    want = torch.autograd.grad(yr, (zr, ref.weight, ref.bias, gr, rr), dy)
+    for a_, b_, what in zip(got, want, ("dz", "dgamma", "dbeta", "dgate", "dresid")):
+        _close(a_, b_, what=what)
