@@ -459,9 +459,17 @@ __global__ void __launch_bounds__(kRingThreads) k_nms_sweep_ring(const unsigned 
                     const int pos = b * 64 + lane;
                     keep[base + __popcll(kbits & ((1ull << lane) - 1ull))] = (order && map_through_order) ? order[pos] : pos;
                 }
-                for (unsigned long long kb = kbits; kb; kb &= kb - 1) {   // rows of the kept boxes, straight from LDS
-                    const int i = __ffsll((long long)kb) - 1;
-                    remv |= rows[(size_t)(bb * 64 + i) * kRingWords + lane];
+                // rows of the kept boxes, straight from LDS, four at a time: the reads of a round are issued together (one LDS
+                // latency per round instead of one per kept box — the resolve of a block is what bounds this kernel)
+                for (unsigned long long kb = kbits; kb;) {
+                    unsigned long long t4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = kb ? __ffsll((long long)kb) - 1 : -1;
+                        kb &= kb - 1ull;
+                        t4[u] = i >= 0 ? rows[(size_t)(bb * 64 + i) * kRingWords + lane] : 0ull;
+                    }
+                    remv |= (t4[0] | t4[1]) | (t4[2] | t4[3]);
                 }
             }
             if (kept >= max_keep && lane == 0) s_done = 1;
