@@ -505,7 +505,14 @@ __global__ void __launch_bounds__(1024) k_bank_wmax(const float *__restrict__ ba
     __shared__ float s[16][kC];
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
     float m = 0.f;
-    for (int j = part; j < n_items; j += 16) m = fmaxf(m, fabsf(bank[(size_t)j * kC + c]));
+    // eight independent loads per round (a one-load-per-iteration loop is one L2 round trip per item: 24 us for 2000 items)
+    for (int j0 = part; j0 < n_items; j0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = j0 + 16 * u < n_items ? fabsf(bank[(size_t)(j0 + 16 * u) * kC + c]) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+    }
     s[part][c] = m;
     __syncthreads();
     if (part == 0) {

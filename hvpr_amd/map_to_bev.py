@@ -158,16 +158,21 @@ class _ScatterCanvas(torch.autograd.Function):
             assert c < 64
             pad = torch.cat([feats, feats.new_zeros(feats.shape[0], 64 - c)], dim=1)
             sp = kernels.scatter_bev_fwd(pad, None, None, coords_i32, batch, nx, ny, ws)[0][:, :c]
-        rows = (coords_i32[:, 0].long() * ny + coords_i32[:, 2].long()) * nx + coords_i32[:, 3].long()
+        rows = ((coords_i32[:, 0] * ny + coords_i32[:, 2]) * nx + coords_i32[:, 3]).contiguous()      # int32 cell of every pillar
         ctx.save_for_backward(rows)
         ctx.c = c
         return sp
 
     @staticmethod
     def backward(ctx, grad):
+        """Every pillar reads its cell back: hvpr_gather_rows_f32 over the NHWC gradient canvas (one row = one BEV cell)."""
         (rows,) = ctx.saved_tensors
-        g = grad.permute(0, 2, 3, 1).reshape(-1, grad.shape[1])       # NHWC rows (a view when grad is channels_last)
-        return g.index_select(0, rows)[:, :ctx.c].contiguous(), None, None, None, None, None
+        g = grad.permute(0, 2, 3, 1).contiguous()                     # NHWC (a view when grad is channels_last)
+        cells, ch = g.shape[0] * g.shape[1] * g.shape[2], g.shape[3]
+        out = torch.empty((rows.shape[0], ch), dtype=torch.float32, device=g.device)
+        kernels.check(kernels.lib().hvpr_gather_rows_f32(kernels._ptr(g, torch.float32, "grad canvas"), cells, ch, rows.data_ptr(), rows.shape[0],
+                                                         out.data_ptr(), kernels._stream()), "hvpr_gather_rows_f32")
+        return (out if ch == ctx.c else out[:, :ctx.c].contiguous()), None, None, None, None, None
 
 
 class _ScatterBase(nn.Module):

@@ -157,3 +157,26 @@ def test_memory_train_forward_backward_match_the_reference_formula(R, n_items, s
         assert err < 1e-3 or float(ref.norm()) < 1e-12, (what, err)
         if float(ref.norm()) < 1e-12:
             assert float(got.abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("c", [128, 64, 32])
+def test_scatter_canvas_forward_and_gather_backward(c):
+    """The differentiable scatter of the training branch (pointpillar_scatter.py:87-167: rows -> dense canvases): forward through
+    hvpr_scatter_bev_fwd_f32, backward = every pillar reads its cell of the gradient canvas through hvpr_gather_rows_f32."""
+    from hvpr_amd import kernels
+    from hvpr_amd.map_to_bev import _ScatterCanvas
+    g = torch.Generator().manual_seed(c)
+    B, nx, ny, M = 2, 40, 24, 300
+    cells = torch.randperm(B * nx * ny, generator=g)[:M]
+    coords = torch.stack([cells // (nx * ny), torch.zeros(M, dtype=torch.long), (cells // nx) % ny, cells % nx], 1).to(torch.int32).to(DEV)
+    feats = torch.randn(M, c, generator=g).to(DEV).requires_grad_(True)
+    ws = kernels.scatter_workspace(B, nx, ny, DEV)
+    canvas = _ScatterCanvas.apply(feats, coords, B, nx, ny, ws)
+    assert canvas.shape == (B, c, ny, nx)
+    ref = torch.zeros(B, ny, nx, c, device=DEV)
+    ref[coords[:, 0].long(), coords[:, 2].long(), coords[:, 3].long()] = feats.detach()
+    assert torch.equal(canvas.permute(0, 2, 3, 1), ref)
+    go = torch.randn(canvas.shape, generator=g).to(DEV)
+    (gf,) = torch.autograd.grad(canvas, feats, go)
+    want = go.permute(0, 2, 3, 1)[coords[:, 0].long(), coords[:, 2].long(), coords[:, 3].long()]
+    assert torch.equal(gf, want)
