@@ -247,11 +247,11 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
     allow_torch_reference = False
 
     def _topk_points(self, pillars, points):
-        """Indices (M, k) of the k points with the largest pillar . point logits, descending.  The (M, N) logits are never
-        materialised: the memory read-out kernel (half-precision matrix-core pre-filter + exact fp32 re-check of the candidates)
-        runs over the points in blocks of <= 2048 "items", and the k * blocks candidates per pillar are re-ranked exactly."""
+        """Indices (M, k) of the k points with the largest pillar . point logits, descending — hvpr_point_pillar_topk_f32: the
+        (M, N) logits are never materialised (half-precision matrix-core pre-filter over blocks of 2048 points with a rising
+        bound, exact fp32 re-check of the surviving candidates)."""
         k, N = self.k, points.shape[0]
-        nb = (N + 2047) // 2048                                        # blocks of (almost) equal size, each <= 2048 items
+        nb = 1
         if not pillars.is_cuda:
             if not self.allow_torch_reference:
                 raise RuntimeError("hvpr_amd: get_score needs GPU tensors (the HIP path has no CPU fallback)")
@@ -262,15 +262,13 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
             return torch.zeros((0, k), dtype=torch.long, device=pillars.device)
         if N < k * max(nb, 1):
             raise ValueError(f"hvpr_amd: get_score needs at least k = {k} points per sample, got {N}")
-        bounds = [(i * N) // nb for i in range(nb + 1)]
-        pf = pillars.contiguous()
-        cand = []
-        for s, e in zip(bounds[:-1], bounds[1:]):
-            _, idx = kernels.memory_readout_fwd(pf, points[s:e].contiguous(), k, want_idx=True)
-            cand.append(idx.long() + s)
-        cand = torch.cat(cand, dim=1)                                  # (M, k * blocks): a superset of the global top-k
-        logit = (points[cand] * pf.unsqueeze(1)).sum(dim=2)            # exact re-ranking of the candidates
-        return cand.gather(1, torch.topk(logit, k, dim=1)[1])
+        pf, pts = pillars.contiguous(), points.contiguous()
+        packed = kernels.PackedBank(pts)                               # fp16 operand tiles + channel maxima of this sample's points
+        idx = torch.empty((pf.shape[0], k), dtype=torch.int32, device=pf.device)
+        kernels.check(kernels.lib().hvpr_point_pillar_topk_f32(kernels._ptr(pf, torch.float32, "pillars"), pf.shape[0], packed.rows.data_ptr(),
+                                                               packed.data.data_ptr(), N, k, idx.data_ptr(), kernels._stream()),
+                      "hvpr_point_pillar_topk_f32")
+        return idx.long()
 
     def _forward_train(self, batch_dict):
         """Training branch, pointpillar_scatter.py:87-167: three canvases (memory-fed, point-fed, scale)."""

@@ -270,6 +270,12 @@ int hvpr_three_interpolate_f32(const float *features, const int32_t *idx, const 
                                float *out, hvpr_stream_t stream);
 int hvpr_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx, const float *weight, int B, int C, int m, int n,
                                     float *grad_features, hvpr_stream_t stream);
+/* a10 (training)  the index half of get_score (pointpillar_scatter.py:70-75): for every pillar row of `pillars` [M,64] the k
+ * rows of `points` [N,64] with the largest dot product, idx [M,k] i32 in DESCENDING order (ties: lower index first).  N is
+ * unlimited (items are walked in blocks of 2048); points_packed = hvpr_memory_bank_pack_f32(points, N) (fp16 operand tiles +
+ * channel maxima).  Exact fp32 top-k through the same pre-filter + re-check scheme as hvpr_memory_readout_fwd_f32. */
+int hvpr_point_pillar_topk_f32(const float *pillars, int M, const float *points, const float *points_packed, int N, int k,
+                               int32_t *idx, hvpr_stream_t stream);
 /* a10 (training)  backward of the row gather `points[idx]` of get_score (pointpillar_scatter.py:76): dst [n_dst, row_floats] is
  * overwritten with the scatter-add of src [m, row_floats] at rows idx [m] (fp32 atomics; out-of-range ids are ignored).  The
  * forward is hvpr_gather_rows_f32. */

@@ -220,3 +220,47 @@ def test_pointnet2_msg_whole_module_matches_a_torch_plus_oracle_reference():
     errs = {k: float((ggot[k] - gwant[k]).norm() / gwant[k].norm().clamp_min(1e-30)) for k in gwant}
     assert np.median(list(errs.values())) < 1e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     assert max(errs.values()) < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
+def test_point_pillar_topk_ties_duplicates_and_order():
+    """hvpr_point_pillar_topk_f32 beyond random data: 200 copies of one point (more near-ties than the candidate list holds: the
+    exact pass over all items), an all-zero pillar row (k lowest indices), an item count that is not a multiple of 16 / 2048,
+    and the output order (logit descending, index ascending on exact ties)."""
+    from hvpr_amd.map_to_bev import PointPillarScatter_Agg_Memory_1_scale
+    cfg = hvpr_car_cfg()
+    mod = PointPillarScatter_Agg_Memory_1_scale(cfg.MODEL.MAP_TO_BEV, grid_size=np.array([296, 248, 1])).to(DEV)
+    g = torch.Generator().manual_seed(12)
+    N, M = 5003, 70
+    points = torch.randn(N, 64, generator=g)
+    pillars = torch.randn(M, 64, generator=g)
+    dup = torch.randperm(N, generator=g)[:200]
+    points[dup] = points[int(dup[0])].clone()                      # 200 identical rows
+    pillars[3] = 2.0 * points[int(dup[0])]                 # ... which are this pillar's best match: a 200-way exact tie at the top
+    pillars[5] = 0.0
+    def check(pillars, points):
+        got = mod._topk_points(pillars.to(DEV), points.to(DEV)).cpu().numpy()
+        logits = (pillars.double() @ points.double().t()).numpy()
+        for m in range(pillars.shape[0]):
+            row = logits[m]
+            vals = row[got[m]]
+            assert np.all(np.diff(vals) <= 1e-6 * np.abs(row).max() + 1e-12), m            # descending (up to fp32 round-off)
+            kth = np.sort(row)[-mod.k]
+            assert vals.min() >= kth - 1e-5 * max(np.abs(row).max(), 1.0), m               # the k largest values (fp32 round-off)
+            assert len(set(got[m].tolist())) == mod.k
+        return got
+
+    got = check(pillars, points)
+    np.testing.assert_array_equal(got[5], np.arange(mod.k))                             # zero row: the k lowest indices
+    np.testing.assert_array_equal(got[3], np.sort(dup.numpy())[:mod.k])                 # exact ties: lowest indices first
+    # a frame padded by repetition (sample_points, data_processor.py:77-108): 16384 rows drawn from 3000 distinct points, and
+    # non-negative, correlated features (post-ReLU) whose logits crowd together
+    base = torch.relu(torch.randn(3000, 64, generator=g) + 1.0) * torch.rand(1, 64, generator=g)
+    rep = base[torch.randint(0, 3000, (16384,), generator=g)]
+    got = check(torch.relu(torch.randn(M, 64, generator=g) + 1.0), rep)
+    for m in range(0, M, 9):                  # exact ties among copies: the lower index comes first
+        rows = rep[got[m]]
+        for a in range(mod.k - 1):
+            if torch.equal(rows[a], rows[a + 1]):
+                assert got[m][a] < got[m][a + 1], (m, a)
+    # features outside the fp16 range of the pre-filter: every item is a candidate
+    check(pillars[:20] * 1e5, points)
