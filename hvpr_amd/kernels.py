@@ -383,6 +383,50 @@ def pack_conv(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=0):
     return PackedConv(wp.contiguous(), b, taps, stride, cout, cout_pad, 1, cin, relu, tile_cfg)
 
 
+class PackedConvWino:
+    """Stride-1 3x3 conv weights in the Winograd kernel's stage image (hvpr_conv2d_wino_pack_f32) with BatchNorm folded."""
+
+    __slots__ = ("w", "bias", "cout", "cout_pad", "cin", "relu", "px_groups")
+    taps, stride, up = 9, 1, 1
+
+    def __init__(self, w, bias, cout, cout_pad, cin, relu, px_groups):
+        self.w, self.bias, self.cout, self.cout_pad, self.cin, self.relu, self.px_groups = w, bias, cout, cout_pad, cin, relu, px_groups
+
+
+def pack_conv_wino(weight, scale=None, shift=None, relu=True, px_groups=1, adjoint=False):
+    """weight (Cout, Cin, 3, 3) [adjoint: (Cin, Cout, 3, 3) of the layer whose data gradient is wanted]; scale / shift as in
+    pack_conv.  Packs on the device (one small kernel), so the training step can repack every call."""
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    cout, cin = (w.shape[1], w.shape[0]) if adjoint else (w.shape[0], w.shape[1])
+    assert w.shape[2:] == (3, 3) and cin % 8 == 0 and cout % 4 == 0
+    cout_pad = (cout + 63) // 64 * 64
+    wp = torch.empty((lib().hvpr_conv2d_wino_packed_floats(cin, cout),), dtype=torch.float32, device=w.device)
+    sc = None if scale is None else scale.detach().float().contiguous()
+    check(lib().hvpr_conv2d_wino_pack_f32(_ptr(w, torch.float32, "conv weight"), _ptr(sc, torch.float32, "scale"), cout, cin,
+                                          1 if adjoint else 0, wp.data_ptr(), _stream()), "hvpr_conv2d_wino_pack_f32")
+    b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
+    if shift is not None:
+        b[:cout] = shift.detach().float()
+    return PackedConvWino(wp, b, cout, cout_pad, cin, relu, px_groups)
+
+
+def conv2d_wino_nhwc(x, pc, out=None, out_coff=0, gate=None, resid=None):
+    """x (N,H,W,Cin) contiguous f32 -> (N,H,W,C): 3x3 / stride 1 / pad 1 by Winograd F(2x2,3x3); arguments as conv2d_nhwc."""
+    N, H, W, cin = x.shape
+    assert cin == pc.cin
+    if out is None:
+        out = torch.empty((N, H, W, pc.cout), dtype=torch.float32, device=x.device)
+    assert out.shape[:3] == (N, H, W) and out.is_contiguous()
+    check(lib().hvpr_conv2d_wino_nhwc_f32(_ptr(x, torch.float32, "conv input"), N, H, W, cin, pc.w.data_ptr(), pc.bias.data_ptr(),
+                                          pc.cout, 1 if pc.relu else 0, _ptr(gate, torch.float32, "gate"),
+                                          _ptr(resid, torch.float32, "resid"), 0 if resid is None else resid.shape[-1],
+                                          out.data_ptr(), out.shape[-1], int(out_coff), pc.px_groups, _stream()),
+          "hvpr_conv2d_wino_nhwc_f32")
+    return out
+
+
 def pack_deconv(weight, scale, shift, relu=True, tile_cfg=0):
     """ConvTranspose2d weight (Cin, Cout, s, s) with kernel == stride == s -> 1x1 GEMM with s*s*Cout columns."""
     cin, cout, s, s2 = weight.shape

@@ -342,6 +342,29 @@ int hvpr_fused_adam_truewd_f32(float *params, const float *grads, float *exp_avg
 
 
 /* ---------------------------------------------------------------------------------------------
+ * a5 / a11  Stride-1 3x3 convolution (pad 1) by Winograd F(2x2, 3x3) on the fp32 matrix cores: the same operation as
+ *     hvpr_conv2d_nhwc_f32 with taps = 9, stride = 1, up = 1 — BaseBEVBackbone_Scale's Conv3x3 + BN + ReLU and the SFM step
+ *     (pcdet/models/backbones_2d/base_bev_backbone.py:228-315) — with 16 instead of 36 fp32 multiplies per 2x2 output block and
+ *     (cin, cout) pair.  All arithmetic is fp32; the result differs from the direct kernel by summation order only
+ *     (observed <= 2e-6 relative to the output scale per layer, tests/test_gpu_conv_wino.py).
+ *
+ *     hvpr_conv2d_wino_pack_f32: weight [cout, cin, 3, 3] f32 (torch OIHW), optional per-output-channel scale [cout] (folded
+ *         BatchNorm), -> packed [hvpr_conv2d_wino_packed_floats(cin, cout)] f32 = U = G g Gt in the kernel's stage image
+ *         [cout_pad/64][cin/8][16][2][64][4] (cout_pad = cout rounded up to 64; transform evaluated in double, rounded once).
+ *         adjoint != 0: `weight` is the [cin, cout, 3, 3] filter of the layer whose DATA GRADIENT is wanted: packs
+ *         w'[o][i][u][v] = weight[i][o][2-u][2-v].
+ *     hvpr_conv2d_wino_nhwc_f32: in [N,H,W,Cin] (Cin % 8 == 0), bias [cout_pad], gate / resid / out / out_cstride / out_coff as
+ *         in hvpr_conv2d_nhwc_f32 (cout % 4 == 0).  px_groups: 1 = 8 x 16 output pixels x 64 channels per workgroup (4 waves),
+ *         2 = 16 x 16 pixels x 64 channels (8 waves sharing the filter stage).
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_conv2d_wino_packed_floats(int cin, int cout);
+int hvpr_conv2d_wino_pack_f32(const float *weight, const float *scale, int cout, int cin, int adjoint, float *packed,
+                              hvpr_stream_t stream);
+int hvpr_conv2d_wino_nhwc_f32(const float *in, int N, int H, int W, int Cin, const float *w_packed, const float *bias, int cout,
+                              int relu, const float *gate, const float *resid, int resid_cstride, float *out, int out_cstride,
+                              int out_coff, int px_groups, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a5 optional precision modes: 3x3 convolutions on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation)
  *     with split operands.  n_planes = 2 ("bf16x3"): x = hi + lo, x*w ~= hi*hi + hi*lo + lo*hi, error ~2^-16 relative per
  *     product — SURVEY.md §8d allows a reduced-precision path evidenced within the 1e-3 tolerance.  n_planes = 3 ("bf16x6"):

@@ -1,0 +1,67 @@
+"""hvpr_conv2d_wino_nhwc_f32 (Winograd F(2x2,3x3), fp32 matrix cores) against torch's conv2d in float64 and against the direct
+kernel hvpr_conv2d_nhwc_f32: BaseBEVBackbone_Scale's Conv3x3 + BN + ReLU and SFM step (base_bev_backbone.py:228-315)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(x, w, scale, shift, relu, gate=None, resid=None):
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w.double() * scale.double().view(-1, 1, 1, 1), padding=1).permute(0, 2, 3, 1)
+    y = y + shift.double()
+    if relu:
+        y = torch.relu(y)
+    if gate is not None:
+        y = gate.double().unsqueeze(-1) * y + resid.double()
+    return y
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,groups,relu,gated", [
+    (1, 8, 16, 8, 64, 1, False, False),          # one tile, one chunk
+    (1, 16, 16, 16, 64, 2, False, False),
+    (2, 13, 21, 24, 68, 1, True, False),         # ragged image, cout not a multiple of 64, odd chunk count
+    (2, 13, 21, 24, 68, 2, True, True),
+    (1, 62, 74, 64, 128, 1, True, True),         # level-2 geometry, SFM epilogue
+    (3, 31, 37, 128, 128, 2, True, False),
+])
+def test_wino_conv_matches_float64(N, H, W, cin, cout, groups, relu, gated):
+    from hvpr_amd import kernels
+    g = torch.Generator().manual_seed(H * 131 + cin)
+    x = torch.randn(N, H, W, cin, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(DEV)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    gate = torch.rand(N, H, W, generator=g).to(DEV) if gated else None
+    resid = torch.randn(N, H, W, cout, generator=g).to(DEV) if gated else None
+    pc = kernels.pack_conv_wino(w, scale, shift, relu=relu, px_groups=groups)
+    y = kernels.conv2d_wino_nhwc(x, pc, gate=gate, resid=resid)
+    ref = _ref(x, w, scale, shift, relu, gate, resid)
+    pd = kernels.pack_conv(w, scale, shift, stride=1, relu=relu, tile_cfg=1)
+    yd = kernels.conv2d_nhwc(x, pd, gate=gate, resid=resid)
+    s = float(ref.abs().max())
+    err_w, err_d = float((y.double() - ref).abs().max()) / s, float((yd.double() - ref).abs().max()) / s
+    print(f"winograd {err_w:.2e}  direct {err_d:.2e} (max abs error / output scale)")
+    assert err_w < 5e-6, (err_w, err_d)
+    # written into a channel slice of a wider tensor (the concat of the 2D backbone)
+    wide = torch.full((N, H, W, cout + 24), 7.0, device=DEV)
+    kernels.conv2d_wino_nhwc(x, pc, out=wide, out_coff=12, gate=gate, resid=resid)
+    assert torch.equal(wide[..., 12:12 + cout], y) and bool((wide[..., :12] == 7).all()) and bool((wide[..., 12 + cout:] == 7).all())
+
+
+def test_wino_adjoint_pack_is_the_data_gradient():
+    """pack(adjoint) + the same kernel = d(conv)/d(input) (a11: base_bev_backbone.py:228-279 in training)."""
+    from hvpr_amd import kernels
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 20, 28, 32, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(64, 32, 3, 3, generator=g) / 17.0).to(DEV)
+    dy = torch.randn(2, 20, 28, 64, generator=g).to(DEV)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    (y * dy.double()).sum().backward()
+    pc = kernels.pack_conv_wino(w, relu=False, adjoint=True)
+    assert (pc.cin, pc.cout) == (64, 32)
+    dx = kernels.conv2d_wino_nhwc(dy, pc)
+    err = float((dx.double() - x.grad.double()).abs().max() / x.grad.abs().max())
+    assert err < 5e-6, err
