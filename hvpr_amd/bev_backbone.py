@@ -66,6 +66,11 @@ def _tile_cfg(kind, level):
     return _TILES[kind][min(level, 2)]
 
 
+def _wino_groups(level):
+    """Pixel groups per workgroup of the Winograd kernel per level (1: 8 x 16 px, 2: 16 x 16 px); HVPR_WINO_GROUPS="111"."""
+    return int(os.environ.get("HVPR_WINO_GROUPS", "111")[min(level, 2)])
+
+
 class BaseBEVBackbone_Scale(nn.Module):
     """base_bev_backbone.py:116-315."""
 
@@ -140,12 +145,14 @@ class BaseBEVBackbone_Scale(nn.Module):
             cfg = _tile_cfg("trunk", i)
             lv = {"convs": []}
             sc, sh = bn_scale_shift(blk[2])
-            lv["convs"].append(kernels.pack_conv(blk[1].weight, sc, sh, stride=s, tile_cfg=cfg))
+            # stride-1 3x3 layers: Winograd F(2x2,3x3) kernel unless HVPR_CONV_ALGO=direct (kernels.pack_conv_auto)
+            wg = _wino_groups(i)
+            lv["convs"].append(kernels.pack_conv_auto(blk[1].weight, sc, sh, stride=s, tile_cfg=cfg, px_groups=wg))
             for k in range(self.layer_nums[i]):
                 sc, sh = bn_scale_shift(blk[5 + 3 * k])
-                lv["convs"].append(kernels.pack_conv(blk[4 + 3 * k].weight, sc, sh, tile_cfg=cfg))
+                lv["convs"].append(kernels.pack_conv_auto(blk[4 + 3 * k].weight, sc, sh, tile_cfg=cfg, px_groups=wg))
             sc, sh = bn_scale_shift(self.sfmblocks_down[i][1])
-            lv["sfm"] = kernels.pack_conv(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=_tile_cfg("sfm", i))
+            lv["sfm"] = kernels.pack_conv_auto(self.sfmblocks_down[i][0].weight, sc, sh, tile_cfg=_tile_cfg("sfm", i), px_groups=wg)
             planes = self.PRECISIONS[self.conv_precision]
             if planes:
                 c3 = 4                                # 64 px x 64 ch tiles, weights staged per kernel row (2-3 workgroups per CU)
@@ -164,7 +171,7 @@ class BaseBEVBackbone_Scale(nn.Module):
                     if (planes == 2 and de[0].weight.shape[0] % 64 == 0) else None
             sl = self.scale_layers[i]
             sc, sh = bn_scale_shift(sl[2])
-            lv["scale"] = kernels.pack_conv(sl[1].weight, sc, sh, stride=s, tile_cfg=_tile_cfg("scale", i))
+            lv["scale"] = kernels.pack_conv_auto(sl[1].weight, sc, sh, stride=s, tile_cfg=_tile_cfg("scale", i), px_groups=wg)
             de = self.deblocks[i]
             sc, sh = bn_scale_shift(de[1])
             us = int(self.upsample_strides[i])

@@ -3,8 +3,9 @@ reference: BaseBEVBackbone_Scale.forward in training mode, pcdet/models/backbone
 
 Activations are NHWC tensors (N, H, W, C) — what torch calls channels_last — end to end.  Three autograd.Functions:
 
-  conv3x3 / conv1x1   forward  hvpr_conv2d_nhwc_f32 (fp32 matrix cores, raw output: no bias, no activation)
-                      dgrad    the same kernel on the flipped + transposed weights (stride 2: on the zero-upsampled gradient)
+  conv3x3 / conv1x1   forward  hvpr_conv2d_wino_nhwc_f32 (3x3 stride 1: Winograd F(2x2,3x3)) / hvpr_conv2d_nhwc_f32 (the rest);
+                               fp32 matrix cores, raw output: no bias, no activation
+                      dgrad    the same kernels on the flipped + transposed weights (stride 2: on the zero-upsampled gradient)
                       wgrad    hvpr_conv2d_wgrad_nhwc_f32 (split-K over pixel tiles, deterministic)
   deconv (k == s)     forward  the 1x1 GEMM with s*s*Cout columns + pixel shuffle in the epilogue (ConvTranspose2d, :177-188)
                       backward 1x1 dgrad / wgrad on the space-to-depth view of the gradient
@@ -41,8 +42,18 @@ def _tile_cfg(cout):
     return 1
 
 
-def conv_fwd_raw(x, weight, stride=1):
-    """x (N,H,W,Cin) -> conv(x, weight) (N,OH,OW,Cout), no bias / activation.  weight (Cout,Cin,k,k), k in {1,3}, pad (k-1)/2."""
+def _wino_groups():
+    return int(os.environ.get("HVPR_TRAIN_WINO_GROUPS", "1"))
+
+
+def conv_fwd_raw(x, weight, stride=1, adjoint=False):
+    """x (N,H,W,Cin) -> conv(x, weight) (N,OH,OW,Cout), no bias / activation.  weight (Cout,Cin,k,k), k in {1,3}, pad (k-1)/2.
+    adjoint: weight is the (Cin', Cout', 3, 3) filter of the layer whose data gradient is wanted and x its output gradient.
+    Stride-1 3x3: the Winograd kernel (packed on the device per call) unless HVPR_CONV_ALGO=direct."""
+    if weight.shape[2] == 3 and stride == 1 and kernels.conv_algo() == "winograd" and weight.shape[1 if adjoint else 0] % 4 == 0:
+        return kernels.conv2d_wino_nhwc(x, kernels.pack_conv_wino(weight, relu=False, px_groups=_wino_groups(), adjoint=adjoint))
+    if adjoint:
+        weight = weight.detach().permute(1, 0, 2, 3).flip(2, 3)                 # (Cin, Cout, k, k): the adjoint kernel
     pc = kernels.pack_conv(weight, None, None, stride=stride, relu=False, tile_cfg=_tile_cfg(weight.shape[0]))
     return kernels.conv2d_nhwc(x, pc)
 
@@ -76,15 +87,14 @@ class _Conv(torch.autograd.Function):
         s = ctx.stride
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().permute(1, 0, 2, 3).flip(2, 3)                 # (Cin, Cout, k, k): the adjoint kernel
             if s == 1:
-                dx = conv_fwd_raw(dz, wt, 1)
+                dx = conv_fwd_raw(dz, weight, 1, adjoint=True)
             else:            # y[o] = sum x[2 o + k - 1] w[k]  =>  dx = conv_stride1(zero-upsampled dz, flipped w)
                 N, H, W, _ = x.shape
                 OH, OW = dz.shape[1], dz.shape[2]
                 up = torch.zeros((N, H, W, cout), dtype=torch.float32, device=dz.device)
                 up[:, 0:2 * OH:2, 0:2 * OW:2] = dz
-                dx = conv_fwd_raw(up, wt, 1)
+                dx = conv_fwd_raw(up, weight, 1, adjoint=True)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(x, dz, k * k, s, cout, cin)
         return dx, dw, None

@@ -3,6 +3,8 @@
 Every wrapper validates its tensors (device, dtype, contiguity), passes raw pointers plus the current HIP
 stream, and raises on a non-zero status.  There is no CPU path: CPU tensors are rejected.
 """
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -445,8 +447,26 @@ def pack_deconv(weight, scale, shift, relu=True, tile_cfg=0):
     return PackedConv(wp.contiguous(), b, 1, 1, cout, cout_pad, s, cin, relu, tile_cfg)
 
 
+def conv_algo():
+    """Algorithm of the stride-1 3x3 convolutions: "winograd" (hvpr_conv2d_wino_nhwc_f32, default) or "direct"
+    (hvpr_conv2d_nhwc_f32; HVPR_CONV_ALGO=direct).  Every other shape always takes the direct kernel."""
+    algo = os.environ.get("HVPR_CONV_ALGO", "winograd")
+    if algo not in ("winograd", "direct"):
+        raise ValueError(f"HVPR_CONV_ALGO must be 'winograd' or 'direct', got {algo!r}")
+    return algo
+
+
+def pack_conv_auto(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=1, px_groups=1):
+    """pack_conv_wino for a 3x3 / stride-1 layer when conv_algo() is "winograd", pack_conv otherwise; conv2d_nhwc takes either."""
+    if weight.shape[2] == 3 and stride == 1 and weight.shape[0] % 4 == 0 and conv_algo() == "winograd":
+        return pack_conv_wino(weight, scale, shift, relu=relu, px_groups=px_groups)
+    return pack_conv(weight, scale, shift, stride=stride, relu=relu, tile_cfg=tile_cfg)
+
+
 def conv2d_nhwc(x, pc, out=None, out_coff=0, gate=None, resid=None):
     """x (N,H,W,Cin) contiguous f32 -> (N,OH*up,OW*up,C) ; optional fused y = gate*y + resid (SFM step)."""
+    if isinstance(pc, PackedConvWino):
+        return conv2d_wino_nhwc(x, pc, out=out, out_coff=out_coff, gate=gate, resid=resid)
     N, H, W, cin = x.shape
     assert cin == pc.cin
     if pc.taps == 9:
