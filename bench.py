@@ -64,6 +64,29 @@ def conv_flops(model, H, W):
     return fl
 
 
+def wino_conv_flops(model, H, W):
+    """2*MACs (direct-convolution count) of the stride-1 3x3 layers that run on the Winograd F(2x2,3x3) kernel, which executes
+    16/36 of them (kernels.pack_conv_auto: every 3x3 / stride-1 layer unless HVPR_CONV_ALGO=direct)."""
+    from hvpr_amd import kernels
+    if kernels.conv_algo() != "winograd":
+        return 0
+    bb = model.backbone_2d
+    fl = 0
+    h, w = H, W
+    for i, blk in enumerate(bb.blocks):
+        s = bb.layer_strides[i]
+        h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        for c in [m for m in blk if isinstance(m, torch.nn.Conv2d)]:
+            if c.stride[0] == 1:
+                fl += 2 * c.in_channels * c.out_channels * 9 * h * w
+        sf = bb.sfmblocks_down[i][0]
+        fl += bb.sfm_layer_nums[i] * 2 * sf.in_channels * sf.out_channels * 9 * h * w
+        sc = bb.scale_layers[i][1]
+        if sc.stride[0] == 1:
+            fl += 2 * sc.in_channels * sc.out_channels * 9 * h * w
+    return fl
+
+
 def split_conv_flops(model, H, W, precision):
     """2*MACs of the layers the split-bf16 modes run on the bf16 matrix cores: trunk + SFM 3x3 (and the deconvolutions in bf16x3)."""
     bb = model.backbone_2d
@@ -279,9 +302,11 @@ def train_step_line(device, batch=16, steps=3, warmup=2):
     res = {"workload": f"hvpr_car.yaml full train step a1..a15, batch={batch}, 8 GT boxes/frame, {warmup} warm-up + {steps} timed steps",
            "steps_per_s": round(1.0 / dt, 3), "frames_per_s": round(batch / dt, 2), "ms_per_step": round(1e3 * dt, 1),
            "conv_TFLOPs": round(flops_frame * batch / dt / 1e12, 1), "mfma_frac_of_f32_peak": round(flops_frame * batch / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+           "flops_note": "direct-convolution count, 2.71 TFLOP per frame (fwd + dgrad + wgrad); the stride-1 3x3 forward and data-gradient "
+                         "convolutions run on the Winograd kernel and execute 16/36 of theirs",
            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-           "kernels": "backbone conv fwd/dgrad/wgrad + train-mode BN on the library's HIP kernels (HVPR_TRAIN_CONV=hip), memory addressing on "
+           "kernels": "backbone conv fwd/dgrad (Winograd F(2x2,3x3) where 3x3 stride 1) /wgrad + train-mode BN on the library's HIP kernels (HVPR_TRAIN_CONV=hip), memory addressing on "
                       "hvpr_memory_train_*, flat fused Adam; head 1x1 convs / PointNet++ MLPs / losses through torch"}
     del model, opt, pool
     torch.cuda.empty_cache()
@@ -411,6 +436,19 @@ def main():
                                      "frac_of_bf16_peak": round(executed / (bb_ms * 1e-3) / 1e12 / 2500.0, 4),
                                      "note": "executed = products x FLOPs of the layers that run split; fp32 peak for comparison 157.3"}})
             model.backbone_2d.set_conv_precision("fp32")
+            # the same pipeline with every convolution on the direct fp32 kernel (round 1's configuration)
+            os.environ["HVPR_CONV_ALGO"] = "direct"
+            model.backbone_2d._fold.invalidate()
+            pd = detector.PipelinedForward(model, batches[0])
+            dtd = timed(pd)
+            for _ in pd.flush():
+                pass
+            del pd
+            del os.environ["HVPR_CONV_ALGO"]
+            model.backbone_2d._fold.invalidate()
+            alt.append({"mode": "conv_algo_direct", "what": "HVPR_CONV_ALGO=direct: the stride-1 3x3 layers on the direct implicit-GEMM kernel "
+                        "(hvpr_conv2d_nhwc_f32) instead of Winograd F(2x2,3x3); same fp32 arithmetic, 2.25x the multiplies",
+                        "value": round(world * args.steps / dtd, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dtd / args.steps, 4)})
 
         # ---- per-stage probe (untimed): HIP events on the launch stream ----
         stage = np.zeros(3)
@@ -454,6 +492,7 @@ def main():
     group_bytes_ = group_bytes(n_pts, nx, ny, 1)
     group_s = (group_us * 1e-6) if group_us else stage[0] * 1e-3
     flops = conv_flops(model, ny, nx)
+    executed = flops - wino_conv_flops(model, ny, nx) * (1.0 - 16.0 / 36.0)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
@@ -506,13 +545,20 @@ def main():
                      "canvas": "persistent canvases + occupancy state (hvpr_encode_fwd_f32 canvas_state): the dense result is the same, "
                                "but only stale cells are cleared — `traffic` (PMC) is therefore BELOW the algorithmic bytes, which still "
                                "count the dense canvases written once; dense-clear variant: tools/bench_group.py --dense-clear"},
-        "roofline_mfma": {"kernel": "BEV backbone + head convolutions (hvpr_conv2d_nhwc_f32, v_mfma_f32_32x32x2_f32)",
-                          "bound": "mfma", "achieved": round(flops / (stage[1] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                          "unit": "TFLOP/s", "frac": round(flops / (stage[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                          "algorithmic_flops": flops, "avg_duration_us": round(float(stage[1]) * 1e3, 1),
+        "roofline_mfma": {"kernel": "BEV backbone + head convolutions on v_mfma_f32_32x32x2_f32: hvpr_conv2d_wino_nhwc_f32 (Winograd F(2x2,3x3), "
+                                    "the stride-1 3x3 layers) + hvpr_conv2d_nhwc_f32 (stride-2 3x3, 1x1, ConvTranspose)",
+                          "bound": "mfma", "achieved": round(executed / (stage[1] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": round(executed / (stage[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                          "executed_flops": executed, "algorithmic_flops": flops,
+                          "algorithmic_TFLOPs": round(flops / (stage[1] * 1e-3) / 1e12, 2),
+                          "avg_duration_us": round(float(stage[1]) * 1e3, 1),
                           "traffic": None if traffic is None else traffic.get("conv_stack_bytes"),
-                          "note": "peak = 157.3 TFLOP/s at 2.4 GHz; under this load the shader clock measured 2.02 GHz (s_memtime vs "
-                                  "s_memrealtime inside the kernel, DESIGN.md §4.2), i.e. ~132 TFLOP/s attainable"},
+                          "note": "`achieved` / `frac` = matrix-core FLOPs actually EXECUTED (the Winograd layers issue 16/36 of their "
+                                  "direct-convolution count) / stage time; `algorithmic_TFLOPs` = the direct-convolution count of the same "
+                                  "layers (SURVEY.md §8a: 453.65 GFLOP/frame) / the same time — it may exceed the peak, which is the point of "
+                                  "the algorithm.  peak = 157.3 TFLOP/s at 2.4 GHz; under this load the shader clock measured 2.02 GHz "
+                                  "(DESIGN.md §4.2), i.e. ~132 TFLOP/s attainable.  alt_precision[mode=conv_algo_direct] is the same frame "
+                                  "with every layer on the direct kernel"},
     }
     res["alt_precision"] = alt
     if world == 1 and not args.no_extras:
