@@ -107,7 +107,10 @@ class BaseBEVBackbone_Scale(nn.Module):
         self._fold = FoldCache()
         self._shape_key = None
         self._side = None
-        self.overlap_branches = os.environ.get("HVPR_BEV_STREAMS", "2") != "1"
+        self._sides = None
+        # HIP streams of the eval forward: "1" none, "2" trunk + one branch stream, "4" trunk + one stream per level's branch
+        self.n_streams = int(os.environ.get("HVPR_BEV_STREAMS", "4"))
+        self.overlap_branches = self.n_streams != 1
         # "fp32": exact fp32 matrix-core kernel (default, the parity reference).  "bf16x3" / "bf16x6": trunk and SFM 3x3
         # convolutions on the bf16 matrix cores with operands split into 2 / 3 bf16 planes (kernels.conv2d_nhwc_bf3):
         # ~5e-6 relative error per layer / the fp32 kernel's own ~1.5e-6 (fp32 emulation)
@@ -125,6 +128,14 @@ class BaseBEVBackbone_Scale(nn.Module):
         if self._side is None or self._side.device != device:
             self._side = torch.cuda.Stream(device=device)
         return self._side
+
+    def _branch_streams(self, device, n):
+        """One stream per level's attentive branch (n_streams == 4); a single shared one otherwise."""
+        if self.n_streams < 4:
+            return [self._side_stream(device)] * n
+        if self._sides is None or len(self._sides) != n or self._sides[0].device != device:
+            self._sides = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return self._sides
 
     def train(self, mode=True):
         self._fold.invalidate()
@@ -271,16 +282,19 @@ class BaseBEVBackbone_Scale(nn.Module):
         h0 = (H + 2 - 3) // self.layer_strides[0] + 1
         w0 = (W + 2 - 3) // self.layer_strides[0] + 1
         out = torch.empty((B, h0 * us_all[0], w0 * us_all[0], self.num_bev_features), dtype=torch.float32, device=x.device)
-        # Two HIP streams: the trunk (blocks of level i+1) does not depend on the attentive branch of level i (scale conv,
-        # gate, the three weight-shared SFM steps and the deconv), so the branch runs on a side stream and fills the
-        # tail of the trunk's launches (at batch 1 the upper levels have fewer tiles than the chip has workgroup slots).
+        # HIP streams: the trunk (blocks of level i+1) does not depend on the attentive branch of level i (scale conv, gate, the
+        # three weight-shared SFM steps and the deconv), and the branches depend on each other only through the scale stream
+        # y_i = scale_i(y_{i-1}).  The trunk runs on the caller's stream, every branch on a stream of its own (waiting for its
+        # x_i and, by event, for y_{i-1}): at batch 1 the upper levels have fewer tiles than the chip has workgroup slots, and the
+        # last branch (level 2: 0.63 tiles per slot) would otherwise run alone after the trunk has finished.
         main = torch.cuda.current_stream()
-        side = self._side_stream(x.device)
         two_streams = self.overlap_branches
+        sides = self._branch_streams(x.device, len(P["levels"])) if two_streams else []
         coff = 0
         capturing = torch.cuda.is_current_stream_capturing()
-        held = []     # trunk outputs the side stream reads: referenced until the join, so that the allocator of the main
-        #               stream cannot hand their memory to the next level's convolutions while the branch still reads them
+        held = []     # tensors another stream reads: referenced until the join, so that the allocator of the producing stream
+        #               cannot hand their memory out again while the other stream still reads them
+        y_ready = None
         planes = self.PRECISIONS[self.conv_precision]
         bf3 = planes > 0
         if bf3:
@@ -293,13 +307,20 @@ class BaseBEVBackbone_Scale(nn.Module):
                 for pc in lv["convs"]:
                     x = kernels.conv2d_nhwc(x, pc)
             if two_streams:
-                side.wait_stream(main)          # x (and y of the previous level) are ready for the branch
+                side = sides[i]
+                side.wait_stream(main)          # x_i (and, at level 0, the scale stream's input) are ready for the branch
+                if y_ready is not None and sides[i - 1] is not side:
+                    side.wait_event(y_ready)    # y_{i-1} from the previous branch's stream
                 held.append(x)
                 ctx = torch.cuda.stream(side)
             else:
                 ctx = contextlib.nullcontext()
             with ctx:
                 y = kernels.conv2d_nhwc(y, lv["scale"])
+                if two_streams:
+                    y_ready = torch.cuda.Event()
+                    y_ready.record(side)
+                    held.append(y)
                 gate = kernels.spatial_gate(y, gw, gb, gs, gt)
                 x_att = x
                 nsfm = self.sfm_layer_nums[i]
@@ -309,6 +330,8 @@ class BaseBEVBackbone_Scale(nn.Module):
                                                         gate=gate, resid=x_att)
                     else:
                         x_att = kernels.conv2d_nhwc(x_att, lv["sfm"], gate=gate, resid=x_att)
+                    held.append(x_att)
+                held.append(gate)
                 if bf3 and lv["deconv3"] is not None:
                     kernels.deconv_nhwc_bf3(x_att, lv["deconv3"], out, out_coff=coff)
                 elif bf3 and nsfm == 0:
@@ -316,11 +339,14 @@ class BaseBEVBackbone_Scale(nn.Module):
                 else:
                     kernels.conv2d_nhwc(x_att, lv["deconv"], out=out, out_coff=coff)
                 if two_streams and not capturing:     # eager mode: keep the caching allocator from recycling early
-                    for t in (x, out):
+                    for t in (x, y, out):
                         t.record_stream(side)
+                    if i + 1 < len(sides):
+                        y.record_stream(sides[i + 1])
             coff += self.up_filters[i]
         if two_streams:
-            main.wait_stream(side)
+            for side in dict.fromkeys(sides):
+                main.wait_stream(side)
         held.clear()
         data_dict["spatial_features_2d"] = out.permute(0, 3, 1, 2)   # (B, 384, H, W), channels_last
         return data_dict
