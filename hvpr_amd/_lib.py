@@ -69,6 +69,8 @@ SIGNATURES = {
     "hvpr_compact_rows_f32": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "hvpr_frame_offsets_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "hvpr_gather_rows_f32": (_I, [_P, _I, _I, _P, _I, _P, _P]),
+    "hvpr_conv2d_wino_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "hvpr_conv2d_wino_wgrad_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _Z, _P]),
     "hvpr_conv2d_wino_packed_floats": (_Z, [_I, _I]),
     "hvpr_conv2d_wino_pack_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "hvpr_conv2d_wino_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),

@@ -6,7 +6,8 @@ Activations are NHWC tensors (N, H, W, C) — what torch calls channels_last —
   conv3x3 / conv1x1   forward  hvpr_conv2d_wino_nhwc_f32 (3x3 stride 1: Winograd F(2x2,3x3)) / hvpr_conv2d_nhwc_f32 (the rest);
                                fp32 matrix cores, raw output: no bias, no activation
                       dgrad    the same kernels on the flipped + transposed weights (stride 2: on the zero-upsampled gradient)
-                      wgrad    hvpr_conv2d_wgrad_nhwc_f32 (split-K over pixel tiles, deterministic)
+                      wgrad    hvpr_conv2d_wino_wgrad_nhwc_f32 (3x3 stride 1, Winograd domain) / hvpr_conv2d_wgrad_nhwc_f32;
+                               split-K over pixel tiles, deterministic
   deconv (k == s)     forward  the 1x1 GEMM with s*s*Cout columns + pixel shuffle in the epilogue (ConvTranspose2d, :177-188)
                       backward 1x1 dgrad / wgrad on the space-to-depth view of the gradient
   bn_relu             train-mode BatchNorm (batch statistics, differentiated through) + ReLU: hvpr_bn_stats_nhwc_f32,
@@ -63,6 +64,13 @@ def conv_wgrad(x, dz, taps, stride, cout, cin):
     OH, OW = dz.shape[1], dz.shape[2]
     k = 3 if taps == 9 else 1
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
+    if taps == 9 and stride == 1 and kernels.conv_algo() == "winograd" and os.environ.get("HVPR_TRAIN_WGRAD", "winograd") == "winograd":
+        nbytes = lib().hvpr_conv2d_wino_wgrad_workspace_bytes(N, H, W, cin, cout)
+        ws = _workspace(nbytes, x.device)
+        check(lib().hvpr_conv2d_wino_wgrad_nhwc_f32(kernels._ptr(x, torch.float32, "x"), N, H, W, cin, kernels._ptr(dz, torch.float32, "dz"),
+                                                    cout, dw.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()),
+              "hvpr_conv2d_wino_wgrad_nhwc_f32")
+        return dw
     nbytes = lib().hvpr_conv2d_wgrad_workspace_bytes(N, OH, OW, cin, cout, taps, stride)
     ws = _workspace(nbytes, x.device)
     check(lib().hvpr_conv2d_wgrad_nhwc_f32(kernels._ptr(x, torch.float32, "x"), N, H, W, cin, kernels._ptr(dz, torch.float32, "dz"),

@@ -65,3 +65,27 @@ def test_wino_adjoint_pack_is_the_data_gradient():
     dx = kernels.conv2d_wino_nhwc(dy, pc)
     err = float((dx.double() - x.grad.double()).abs().max() / x.grad.abs().max())
     assert err < 5e-6, err
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout", [(1, 8, 8, 64, 64), (2, 13, 21, 24, 68), (3, 31, 37, 128, 192), (2, 62, 74, 64, 128)])
+def test_wino_wgrad_matches_float64(N, H, W, cin, cout):
+    """hvpr_conv2d_wino_wgrad_nhwc_f32 against autograd in float64 and the direct weight-gradient kernel."""
+    import os
+    from hvpr_amd import conv_train
+    g = torch.Generator().manual_seed(W + cin)
+    x = torch.randn(N, H, W, cin, generator=g).to(DEV)
+    dz = torch.randn(N, H, W, cout, generator=g).to(DEV)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    (y * dz.double()).sum().backward()
+    dw = conv_train.conv_wgrad(x, dz, 9, 1, cout, cin)
+    os.environ["HVPR_TRAIN_WGRAD"] = "direct"
+    try:
+        dwd = conv_train.conv_wgrad(x, dz, 9, 1, cout, cin)
+    finally:
+        del os.environ["HVPR_TRAIN_WGRAD"]
+    s = float(w.grad.abs().max())
+    ew, ed = float((dw.double() - w.grad).abs().max()) / s, float((dwd.double() - w.grad).abs().max()) / s
+    print(f"winograd wgrad {ew:.2e}  direct {ed:.2e}")
+    assert ew < 2e-5 and ew < 4 * ed + 1e-6, (ew, ed)
+    assert torch.equal(dw, conv_train.conv_wgrad(x, dz, 9, 1, cout, cin))          # deterministic
