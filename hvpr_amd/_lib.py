@@ -69,6 +69,9 @@ SIGNATURES = {
     "hvpr_compact_rows_f32": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "hvpr_frame_offsets_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "hvpr_gather_rows_f32": (_I, [_P, _I, _I, _P, _I, _P, _P]),
+    "hvpr_pillar_vfe_train_workspace_bytes": (_Z, []),
+    "hvpr_pillar_vfe_train_fwd_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "hvpr_pillar_vfe_bwd_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "hvpr_conv2d_wino_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "hvpr_conv2d_wino_wgrad_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _Z, _P]),
     "hvpr_conv2d_wino_packed_floats": (_Z, [_I, _I]),

@@ -1,10 +1,13 @@
 """Voxel feature encoders with the reference's plugin interface (pcdet/models/backbones_3d/vfe/):
 same registry keys, constructor kwargs, state-dict names and batch_dict keys; the eval forward is ONE HIP launch
 (hvpr_pillar_vfe_fwd_f32) instead of the reference's chain of PyTorch ops."""
+import os
+
 import torch
 import torch.nn as nn
 
 from . import kernels
+from ._lib import check, lib
 from .folding import FoldCache, bn_scale_shift
 
 
@@ -93,6 +96,65 @@ class PillarVFE_Scale(VFETemplate):
         return batch_dict
 
 
+_ws_cache = {}
+
+
+def _train_ws(device):
+    if device not in _ws_cache:
+        _ws_cache[device] = torch.empty((lib().hvpr_pillar_vfe_train_workspace_bytes(),), dtype=torch.uint8, device=device)
+    return _ws_cache[device]
+
+
+class _PfnTrain(torch.autograd.Function):
+    """The two PFN layers with batch-statistics BatchNorm on hvpr_pillar_vfe_train_fwd_f32 / hvpr_pillar_vfe_bwd_f32
+    (pillar_vfe.py:184-221; nothing of size (M, 32, C) is kept or materialised)."""
+
+    @staticmethod
+    def forward(ctx, voxels, num, coords, w0, g0, b0, w1, g1, b1, eps, vs, off):
+        M, P, _ = voxels.shape
+        dev = voxels.device
+        args = [t.detach().contiguous() for t in (w0, g0, b0, w1, g1, b1)]
+        out = torch.empty((M, 64), dtype=torch.float32, device=dev)
+        m0, v0 = torch.empty(16, device=dev), torch.empty(16, device=dev)
+        m1, v1 = torch.empty(64, device=dev), torch.empty(64, device=dev)
+        ws = _train_ws(dev)
+        check(lib().hvpr_pillar_vfe_train_fwd_f32(kernels._ptr(voxels, torch.float32, "voxels"), kernels._ptr(num, torch.int32, "voxel_num_points"),
+                                                  kernels._ptr(coords, torch.int32, "voxel_coords"), M, P,
+                                                  *[kernels._ptr(a, torch.float32, "PFN parameter") for a in args], float(eps),
+                                                  vs[0], vs[1], vs[2], off[0], off[1], off[2], out.data_ptr(), m0.data_ptr(), v0.data_ptr(),
+                                                  m1.data_ptr(), v1.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()),
+              "hvpr_pillar_vfe_train_fwd_f32")
+        ctx.save_for_backward(voxels, num, coords, *args)
+        ctx.geom = (float(eps), tuple(vs), tuple(off))
+        ctx.mark_non_differentiable(m0, v0, m1, v1)
+        return out, m0, v0, m1, v1
+
+    @staticmethod
+    def backward(ctx, d_out, *_):
+        voxels, num, coords, w0, g0, b0, w1, g1, b1 = ctx.saved_tensors
+        eps, vs, off = ctx.geom
+        M, P, _ = voxels.shape
+        grads = [torch.empty_like(t) for t in (w0, g0, b0, w1, g1, b1)]
+        ws = _train_ws(voxels.device)
+        check(lib().hvpr_pillar_vfe_bwd_f32(voxels.data_ptr(), num.data_ptr(), coords.data_ptr(), M, P, w0.data_ptr(), g0.data_ptr(),
+                                            b0.data_ptr(), w1.data_ptr(), g1.data_ptr(), b1.data_ptr(), eps, vs[0], vs[1], vs[2],
+                                            off[0], off[1], off[2], kernels._ptr(d_out.contiguous(), torch.float32, "d pillar_features"),
+                                            *[g.data_ptr() for g in grads], ws.data_ptr(), ws.numel(), kernels._stream()),
+              "hvpr_pillar_vfe_bwd_f32")
+        return (None, None, None, *grads, None, None, None)
+
+
+def _update_running(bn, mean, var, n):
+    """nn.BatchNorm1d's running statistics from the batch mean / biased variance (momentum, unbiased variance)."""
+    if not bn.track_running_stats:
+        return
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+        bn.running_var.mul_(1 - mom).add_(var, alpha=mom * n / max(n - 1, 1))
+
+
 def _train_forward(self, batch_dict, voxels, num, coords):
     """Training forward with batch-statistics BatchNorm and autograd (dense math through torch): the same decoration,
     masking, two PFN layers and scale stream as the eval kernel (pillar_vfe.py:184-221; BN over all M*P slots, padded
@@ -112,12 +174,22 @@ def _train_forward(self, batch_dict, voxels, num, coords):
     off = voxels.new_tensor(self.offsets)
     centre = c[:, [3, 2, 1]] * vs + off                                  # (M,3) pillar centre in x,y,z
     mask = (torch.arange(P, device=voxels.device).view(1, -1) < num.view(-1, 1)).unsqueeze(-1).to(voxels.dtype)
-    x = torch.cat([voxels, xyz - mean, xyz - centre.unsqueeze(1)], dim=-1) * mask
-    for layer in self.pfn_layers:
-        y = layer.linear(x)
-        y = torch.relu(layer.norm(y.permute(0, 2, 1)).permute(0, 2, 1))
-        ymax = y.max(dim=1, keepdim=True)[0]
-        x = ymax if layer.last_vfe else torch.cat([y, ymax.expand(-1, P, -1)], dim=2)
+    l0, l1 = self.pfn_layers[0], self.pfn_layers[1]
+    hip = (voxels.is_cuda and voxels.dtype == torch.float32 and P == 32 and len(self.pfn_layers) == 2 and M > 0
+           and l0.norm.eps == l1.norm.eps and os.environ.get("HVPR_TRAIN_VFE", "hip") != "torch")
+    if hip:       # both PFN layers, forward and backward, on the library's kernels
+        x, m0, v0, m1, v1 = _PfnTrain.apply(voxels.contiguous(), _as_i32(num).contiguous(), _as_i32(coords).contiguous(),
+                                            l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight,
+                                            l1.norm.bias, l0.norm.eps, self.voxel_size, self.offsets)
+        _update_running(l0.norm, m0, v0, M * P)
+        _update_running(l1.norm, m1, v1, M * P)
+    else:
+        x = torch.cat([voxels, xyz - mean, xyz - centre.unsqueeze(1)], dim=-1) * mask
+        for layer in self.pfn_layers:
+            y = layer.linear(x)
+            y = torch.relu(layer.norm(y.permute(0, 2, 1)).permute(0, 2, 1))
+            ymax = y.max(dim=1, keepdim=True)[0]
+            x = ymax if layer.last_vfe else torch.cat([y, ymax.expand(-1, P, -1)], dim=2)
     s = torch.cat([n.unsqueeze(1), torch.norm(mean, 2, 2), mean.squeeze(1)], dim=-1)
     for seq in self.pfn_scale_layers:
         s = seq(s)

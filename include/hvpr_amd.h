@@ -87,6 +87,29 @@ int hvpr_pillar_vfe_fwd_f32(const float *voxels, const int32_t *num_points, cons
                             float *pillar_features, float *pillar_scale_features, float *pillar_mask,
                             hvpr_stream_t stream);
 
+/* a2 (training)  The two PFN layers of PillarVFE_Scale with BATCH-statistics BatchNorm (pillar_vfe.py:184-221, PFNLayer :29-49:
+ *     linear -> BatchNorm1d over all M * P slots, padded ones included -> ReLU -> max over the slots -> concat), forward and
+ *     backward, for the same fixed shapes as hvpr_pillar_vfe_fwd_f32 (P == 32).  No (M, P, C) tensor is materialised: every pass
+ *     recomputes from the voxels (three forward passes, two backward passes + two for the statistics).
+ *     w0 [16,10], gamma0 / beta0 [16], w1 [64,32], gamma1 / beta1 [64]: the Linear weights and BatchNorm affine parameters;
+ *     eps: BatchNorm's; vs_* / off_*: voxel size and (voxel_size / 2 + range minimum) per axis as in the eval entry point.
+ *     fwd: pillar_features [M,64]; mean0 / var0 [16], mean1 / var1 [64] = batch mean and BIASED variance of both layers (for the
+ *          caller's running statistics).
+ *     bwd: d_pillar_features [M,64] -> dw0 [16,10], dgamma0, dbeta0 [16], dw1 [64,32], dgamma1, dbeta1 [64] (overwritten; the
+ *          batch statistics are recomputed, the workspace carries no state between calls).  The voxels get no gradient.
+ *     Deterministic (fixed-order sums, finished in double).  workspace: hvpr_pillar_vfe_train_workspace_bytes(). */
+size_t hvpr_pillar_vfe_train_workspace_bytes(void);
+int hvpr_pillar_vfe_train_fwd_f32(const float *voxels, const int32_t *num_points, const int32_t *coords, int M, int P, const float *w0,
+                                  const float *gamma0, const float *beta0, const float *w1, const float *gamma1, const float *beta1,
+                                  float eps, float vs_x, float vs_y, float vs_z, float off_x, float off_y, float off_z,
+                                  float *pillar_features, float *mean0, float *var0, float *mean1, float *var1, void *workspace,
+                                  size_t workspace_bytes, hvpr_stream_t stream);
+int hvpr_pillar_vfe_bwd_f32(const float *voxels, const int32_t *num_points, const int32_t *coords, int M, int P, const float *w0,
+                            const float *gamma0, const float *beta0, const float *w1, const float *gamma1, const float *beta1, float eps,
+                            float vs_x, float vs_y, float vs_z, float off_x, float off_y, float off_z, const float *d_pillar_features,
+                            float *dw0, float *dgamma0, float *dbeta0, float *dw1, float *dgamma1, float *dbeta1, void *workspace,
+                            size_t workspace_bytes, hvpr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a3  Memory read-out, eval branch.  Replaces MemoryUnit_Agg.forward (eval),
  *     pcdet/models/backbones_2d/map_to_bev/memory_module.py:60-77: logits = f.W^T, top-k items,

@@ -180,3 +180,62 @@ def test_scatter_canvas_forward_and_gather_backward(c):
     (gf,) = torch.autograd.grad(canvas, feats, go)
     want = go.permute(0, 2, 3, 1)[coords[:, 0].long(), coords[:, 2].long(), coords[:, 3].long()]
     assert torch.equal(gf, want)
+
+
+@pytest.mark.parametrize("M", [2, 3, 7, 1001])
+def test_pillar_vfe_train_fwd_bwd_match_float64_autograd(M):
+    """hvpr_pillar_vfe_train_fwd_f32 / hvpr_pillar_vfe_bwd_f32 (the two PFN layers with batch-statistics BatchNorm,
+    pillar_vfe.py:184-221) against torch autograd of the same module in float64: features, running statistics and the
+    gradients of both Linear weights and both BatchNorm affines."""
+    import copy
+    from hvpr_amd import vfe as V
+    from hvpr_amd.config import hvpr_car_cfg
+    cfg = hvpr_car_cfg()
+    g = torch.Generator().manual_seed(M)
+    mod = V.PillarVFE_Scale(cfg.MODEL.VFE, 4, [0.16, 0.16, 3], [0, -19.84, -2.5, 47.36, 19.84, 0.5]).train()
+    with torch.no_grad():
+        for layer in mod.pfn_layers:
+            layer.norm.weight.copy_(torch.rand(layer.norm.weight.shape, generator=g) + 0.5)
+            layer.norm.bias.copy_(torch.randn(layer.norm.bias.shape, generator=g) * 0.3)
+    ref = copy.deepcopy(mod).double().to(DEV)
+    mod = mod.to(DEV)
+    P = 32
+    num = torch.randint(1, 9, (M,), generator=g)
+    num[0] = P                                                           # a full pillar: no padded slot
+    if M > 2:
+        num[2] = 1
+    coords = torch.stack([torch.zeros(M, dtype=torch.long), torch.zeros(M, dtype=torch.long),
+                          torch.randint(0, 248, (M,), generator=g), torch.randint(0, 296, (M,), generator=g)], dim=1).int()
+    vox = torch.rand(M, P, 4, generator=g) * torch.tensor([47.0, 39.0, 3.0, 1.0]) + torch.tensor([0.0, -19.5, -2.5, 0.0])
+    vox = vox * (torch.arange(P).view(1, -1, 1) < num.view(-1, 1, 1))
+    dfeat = torch.randn(M, 64, generator=g)
+
+    def run(m, dtype):
+        bd = {"voxels": vox.to(DEV, dtype), "voxel_num_points": num.to(DEV).int(), "voxel_coords": coords.to(DEV)}
+        out = m(bd)["pillar_features"]
+        (out * dfeat.to(DEV, dtype)).sum().backward()
+        return out
+
+    import os
+    o_ref = run(ref, torch.float64)
+    o_hip = run(mod, torch.float32)
+    scale = float(o_ref.abs().max())
+    assert float((o_hip.double() - o_ref).abs().max()) < 2e-5 * scale
+    for (name, p_h), (_, p_r) in zip(mod.named_parameters(), ref.named_parameters()):
+        if "pfn_layers" not in name:
+            continue
+        gr, gh = p_r.grad, p_h.grad.double()
+        err = float((gh - gr).abs().max()) / max(float(gr.abs().max()), 1e-6)
+        assert err < 2e-4, (name, err, float(gr.abs().max()))
+    for l_h, l_r in zip(mod.pfn_layers, ref.pfn_layers):
+        assert float((l_h.norm.running_mean.double() - l_r.norm.running_mean).abs().max()) < 1e-6
+        assert float((l_h.norm.running_var.double() - l_r.norm.running_var).abs().max()) < 1e-5 * float(l_r.norm.running_var.abs().max())
+        assert int(l_h.norm.num_batches_tracked) == 1
+    # the torch form of the same module (HVPR_TRAIN_VFE=torch) stays available as the parity reference of the suite
+    os.environ["HVPR_TRAIN_VFE"] = "torch"
+    try:
+        mod.zero_grad()
+        o_t = run(mod, torch.float32)
+    finally:
+        del os.environ["HVPR_TRAIN_VFE"]
+    assert float((o_t.double() - o_ref).abs().max()) < 2e-5 * scale
