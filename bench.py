@@ -392,15 +392,17 @@ def main():
             dt_single = None if (args.skip_single and not args.no_pipeline) else timed(detector.GraphedForward(model, batches[0]))
             mode, dt = "one whole-frame hipGraph replay per step (frame latency = 1 step)", dt_single
             if not args.no_pipeline:
-                # throughput mode: every step is one graph replay that encodes frame k, convolves frame k-1 and runs top-k +
-                # NMS of frame k-2 on three streams; K timed steps retire exactly K frames (the pipeline is full before and
-                # after the timed region; the warm-up fills it), nothing is skipped
+                # throughput mode: every step is one graph replay that encodes frame k, convolves frames k-1 / k-2 (two halves of
+                # the backbone) and runs top-k + NMS of frame k-3 on separate streams; K timed steps retire exactly K frames (the
+                # pipeline is full before and after the timed region; the warm-up fills it), nothing is skipped
                 pipe = detector.PipelinedForward(model, batches[0])
                 dt = timed(pipe)
                 for _ in pipe.flush():
                     pass
-                mode = "3-stage frame pipeline: one hipGraph replay per step = encode(k) | convolutions(k-1) | top-k+NMS(k-2) " \
-                       "on three HIP streams (frame latency = 3 steps)"
+                mode = ("4-stage frame pipeline: one hipGraph replay per step = encode(k) | trunk + branches 0,1 (k-1) | last branch + head + "
+                        "decode (k-2) | top-k+NMS (k-3) on separate HIP streams (frame latency = 4 steps)") if pipe.depth == 4 else \
+                       ("3-stage frame pipeline: one hipGraph replay per step = encode(k) | convolutions(k-1) | top-k+NMS(k-2) "
+                        "on three HIP streams (frame latency = 3 steps)")
 
         dt_rank = dt_local[0]      # this rank's own time of the headline run (`dt` is the max over ranks)
         if not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32" and not args.skip_single:

@@ -265,31 +265,45 @@ class BaseBEVBackbone_Scale(nn.Module):
         return data_dict
 
     def forward(self, data_dict):
+        """Eval forward.  data_dict["_bev_split"] = {"phase": "a" | "b", "x": ..., "y": ..., "out": ...} runs it in two halves on
+        caller-owned boundary buffers (the frame pipeline overlaps the halves of neighbouring frames): phase "a" = the whole trunk
+        and every branch but the last (writes x = the last trunk output, y = the last-but-one scale output, and its slices of
+        out = the concat); phase "b" = the last level's branch (reads x, y; finishes out)."""
         if self.training:
             return self._forward_train(data_dict)
-        sp, sc = data_dict["spatial_features"], data_dict["spatial_scale_features"]
-        x = sp.permute(0, 2, 3, 1).contiguous()       # no copy when the scatter produced channels_last
-        y = sc.permute(0, 2, 3, 1).contiguous()
-        B, H, W, _ = x.shape
-        if self._shape_key != (H, W):
-            self._fold.invalidate()
-            self._shape_key = (H, W)
+        split = data_dict.get("_bev_split")
+        phase = split["phase"] if split is not None else None
+        n_lv = len(self.blocks)
+        if phase == "b":
+            x, y, out = split["x"], split["y"], split["out"]
+            B = x.shape[0]
+            H, W = self._shape_key
+        else:
+            sp, sc = data_dict["spatial_features"], data_dict["spatial_scale_features"]
+            x = sp.permute(0, 2, 3, 1).contiguous()       # no copy when the scatter produced channels_last
+            y = sc.permute(0, 2, 3, 1).contiguous()
+            B, H, W, _ = x.shape
+            if self._shape_key != (H, W):
+                self._fold.invalidate()
+                self._shape_key = (H, W)
         P = self._fold.get(x.device, lambda: self._build_packed(H, W))
         gw, gb, gs, gt = P["gate"]
         gw = gw.to(x.device)
         us_all = [int(u) for u in self.upsample_strides]
-        # output size of the concat: level-0 resolution after its own stride, times its upsample stride
-        h0 = (H + 2 - 3) // self.layer_strides[0] + 1
-        w0 = (W + 2 - 3) // self.layer_strides[0] + 1
-        out = torch.empty((B, h0 * us_all[0], w0 * us_all[0], self.num_bev_features), dtype=torch.float32, device=x.device)
+        if phase is None:
+            # output size of the concat: level-0 resolution after its own stride, times its upsample stride
+            h0 = (H + 2 - 3) // self.layer_strides[0] + 1
+            w0 = (W + 2 - 3) // self.layer_strides[0] + 1
+            out = torch.empty((B, h0 * us_all[0], w0 * us_all[0], self.num_bev_features), dtype=torch.float32, device=x.device)
+        elif phase == "a":
+            out = split["out"]
         # HIP streams: the trunk (blocks of level i+1) does not depend on the attentive branch of level i (scale conv, gate, the
         # three weight-shared SFM steps and the deconv), and the branches depend on each other only through the scale stream
         # y_i = scale_i(y_{i-1}).  The trunk runs on the caller's stream, every branch on a stream of its own (waiting for its
-        # x_i and, by event, for y_{i-1}): at batch 1 the upper levels have fewer tiles than the chip has workgroup slots, and the
-        # last branch (level 2: 0.63 tiles per slot) would otherwise run alone after the trunk has finished.
+        # x_i and, by event, for y_{i-1}): at batch 1 the upper levels have fewer tiles than the chip has workgroup slots.
         main = torch.cuda.current_stream()
-        two_streams = self.overlap_branches
-        sides = self._branch_streams(x.device, len(P["levels"])) if two_streams else []
+        two_streams = self.overlap_branches and phase != "b"
+        sides = self._branch_streams(x.device, n_lv) if two_streams else []
         coff = 0
         capturing = torch.cuda.is_current_stream_capturing()
         held = []     # tensors another stream reads: referenced until the join, so that the allocator of the producing stream
@@ -297,15 +311,23 @@ class BaseBEVBackbone_Scale(nn.Module):
         y_ready = None
         planes = self.PRECISIONS[self.conv_precision]
         bf3 = planes > 0
+        assert not (bf3 and phase is not None), "the split forward runs the fp32 kernels"
         if bf3:
             x = kernels.split_bf16(x, planes)  # the trunk runs in split-bf16 form from here on
         for i, lv in enumerate(P["levels"]):
-            if bf3:
-                for pc in lv["convs3"]:
-                    x = kernels.conv2d_nhwc_bf3(x, pc)
-            else:
-                for pc in lv["convs"]:
-                    x = kernels.conv2d_nhwc(x, pc)
+            last = i == n_lv - 1
+            if phase == "b" and not last:
+                coff += self.up_filters[i]
+                continue
+            if phase != "b":
+                if bf3:
+                    for pc in lv["convs3"]:
+                        x = kernels.conv2d_nhwc_bf3(x, pc)
+                else:
+                    for j, pc in enumerate(lv["convs"]):
+                        x = kernels.conv2d_nhwc(x, pc, out=split["x"] if (phase == "a" and last and j == len(lv["convs"]) - 1) else None)
+            if phase == "a" and last:
+                break                                      # the last branch is phase "b"
             if two_streams:
                 side = sides[i]
                 side.wait_stream(main)          # x_i (and, at level 0, the scale stream's input) are ready for the branch
@@ -316,7 +338,7 @@ class BaseBEVBackbone_Scale(nn.Module):
             else:
                 ctx = contextlib.nullcontext()
             with ctx:
-                y = kernels.conv2d_nhwc(y, lv["scale"])
+                y = kernels.conv2d_nhwc(y, lv["scale"], out=split["y"] if (phase == "a" and i == n_lv - 2) else None)
                 if two_streams:
                     y_ready = torch.cuda.Event()
                     y_ready.record(side)
@@ -348,8 +370,24 @@ class BaseBEVBackbone_Scale(nn.Module):
             for side in dict.fromkeys(sides):
                 main.wait_stream(side)
         held.clear()
+        if phase == "a":
+            return data_dict
         data_dict["spatial_features_2d"] = out.permute(0, 3, 1, 2)   # (B, 384, H, W), channels_last
         return data_dict
+
+    def split_buffers(self, batch_size, H, W, device):
+        """Boundary buffers of the two-phase forward for canvases of (H, W): x (last trunk output), y (last-but-one scale output),
+        out (the concat)."""
+        h, w, hw = H, W, []
+        for s in self.layer_strides:
+            h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+            hw.append((h, w))
+        cx = self.blocks[-1][1].weight.shape[0]
+        cy = self.scale_layers[-2][1].weight.shape[0]
+        us0 = int(self.upsample_strides[0])
+        mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+        return {"x": mk(batch_size, hw[-1][0], hw[-1][1], cx), "y": mk(batch_size, hw[-2][0], hw[-2][1], cy),
+                "out": mk(batch_size, hw[0][0] * us0, hw[0][1] * us0, self.num_bev_features)}
 
 
 __all__ = {

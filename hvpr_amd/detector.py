@@ -397,6 +397,17 @@ class MixAnchor_Memory(_VoxelizingDetector):
         """a5-a7: canvases -> decoded boxes and scores of every anchor."""
         return self.dense_head(self.backbone_2d(batch_dict))
 
+    def stage_dense_a(self, batch_dict, split):
+        """First half of stage_dense on caller-owned boundary buffers (BaseBEVBackbone_Scale.split_buffers): the trunk and every
+        branch but the last."""
+        return self.backbone_2d({**batch_dict, "_bev_split": {**split, "phase": "a"}})
+
+    def stage_dense_b(self, batch_dict, split):
+        """Second half: the last level's branch, head and decode."""
+        bd = self.backbone_2d({**batch_dict, "_bev_split": {**split, "phase": "b"}})
+        bd.pop("_bev_split", None)
+        return self.dense_head(bd)
+
     def forward(self, batch_dict, sync=True):
         fused = self._can_fuse_encode(batch_dict)
         if fused:
@@ -480,26 +491,34 @@ class GraphedForward:
 
 
 class PipelinedForward:
-    """Frame pipeline of the eval forward for throughput: step k runs, concurrently on three HIP streams inside ONE graph
-    replay, stage_encode of frame k, stage_dense of frame k-1 and post_processing of frame k-2.
+    """Frame pipeline of the eval forward for throughput: step k runs, concurrently on HIP streams inside ONE graph replay,
+    stage_encode of frame k, the convolutions of earlier frames and post_processing of the oldest frame in flight.
 
-    Why: at batch 1 the encode group (8 launches, ~0.1 ms) and top-k + NMS (~0.6 ms) are latency-bound chains of small
-    kernels that leave most of the 256 CUs idle; the convolutions (4 ms) are throughput-bound.  Overlapping the chains of
-    neighbouring frames with the convolutions hides them.  Results are bit-identical to the serial forward (same kernels,
-    same inputs; tests/test_gpu_e2e.py); the latency of one frame becomes three steps.
+    depth 3: encode(k) | stage_dense(k-1) | post(k-2).
+    depth 4 (default for the fp32 kernels): encode(k) | stage_dense_a(k-1) | stage_dense_b(k-2) | post(k-3) — the last level's
+    branch (three SFM convolutions, deconvolution: 0.6 tiles per workgroup slot at batch 1), head and decode of one frame run
+    beside the trunk of the next one instead of alone at the end of the stage.
 
-    Two lanes of boundary buffers (canvases, head outputs) alternate, so there are two graphs (even / odd steps).
-    __call__(batch) enqueues frame k and returns the `sync=False` result of frame k-2 (None for the first two calls);
-    flush() drains the last two frames."""
+    Why: at batch 1 the encode group and top-k + NMS are latency-bound chains of small kernels that leave most of the 256 CUs
+    idle; the convolutions are throughput-bound but their upper levels do not fill the chip.  Results are bit-identical to the
+    serial forward (same kernels, same inputs; tests/test_gpu_e2e.py); the latency of one frame becomes `depth` steps.
+
+    Two lanes of boundary buffers (canvases, backbone boundary, head outputs) alternate, so there are two graphs (even / odd
+    steps).  __call__(batch) enqueues frame k and returns the `sync=False` result of frame k - depth + 1 (None for the first
+    depth - 1 calls); flush() drains the frames still in flight."""
 
     _HEAD_KEYS = ("batch_cls_preds", "batch_box_preds", "batch_max_scores", "batch_max_labels")
 
-    def __init__(self, model, example_batch, warmup=2):
+    def __init__(self, model, example_batch, warmup=2, depth=None):
         assert not model.training and hasattr(model, "stage_encode")
-        self.model, self.step = model, 0
+        if depth is None:
+            fp32 = getattr(model.backbone_2d, "conv_precision", "fp32") == "fp32" and hasattr(model.backbone_2d, "split_buffers")
+            depth = int(os.environ.get("HVPR_PIPE_DEPTH", "4")) if fp32 else 3
+        assert depth in (3, 4)
+        self.model, self.step, self.depth = model, 0, depth
         self.B = example_batch["batch_size"]
         self.inp = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()} for _ in range(2)]
-        self.canvas, self.head, self.aux = [None, None], [None, None], [None, None]
+        self.canvas, self.head, self.aux, self.split = [None, None], [None, None], [None, None], [None, None]
         # each lane owns its canvases for good, so the encode stage only clears what the lane's previous frame left in them
         self.own = [model.persistent_canvases(example_batch) if hasattr(model, "persistent_canvases") else {} for _ in range(2)]
         side = torch.cuda.Stream()
@@ -509,28 +528,44 @@ class PipelinedForward:
                 for _ in range(warmup):
                     bd = model.stage_encode({**self.inp[p], **self.own[p]})
                     self.canvas[p] = (bd["spatial_features"], bd["spatial_scale_features"])
-                    bd = model.stage_dense(bd)
+                    if depth == 4:
+                        if self.split[p] is None:
+                            sp = bd["spatial_features"]
+                            self.split[p] = model.backbone_2d.split_buffers(self.B, sp.shape[2], sp.shape[3], sp.device)
+                        model.stage_dense_a(bd, self.split[p])
+                        bd = model.stage_dense_b(bd, self.split[p])
+                    else:
+                        bd = model.stage_dense(bd)
                     self.head[p] = tuple(bd[k] for k in self._HEAD_KEYS)
                     model.post_processing(bd, sync=False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.s_enc, self.s_post = torch.cuda.Stream(), torch.cuda.Stream()
+        self.s_enc, self.s_post, self.s_b = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
         self.graphs, self.out = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()], [None, None]
         pool = None
         for p in range(2):
             q = 1 - p
+            # step k has parity p: frame k uses lane p, frame k-1 lane q, frame k-2 lane p, frame k-3 lane q
+            post_lane = p if depth == 3 else q
             with torch.cuda.graph(self.graphs[p], pool=pool), torch.no_grad():
                 main = torch.cuda.current_stream()
                 self.s_enc.wait_stream(main)
                 self.s_post.wait_stream(main)
-                with torch.cuda.stream(self.s_post):      # frame k-2 (lane p): top-k + NMS
-                    self.out[p] = model.post_processing(self._post_dict(p), sync=False)[0]
+                with torch.cuda.stream(self.s_post):      # oldest frame in flight: top-k + NMS
+                    self.out[p] = model.post_processing(self._post_dict(post_lane), sync=False)[0]
                 with torch.cuda.stream(self.s_enc):       # frame k (lane p): points -> canvases of lane p
                     bd = model.stage_encode({**self.inp[p], "_out_spatial": self.canvas[p], **self.own[p]})
                     self.aux[p] = bd["voxel_offsets"]
-                # frame k-1 (lane q): convolutions on the capture stream (+ the backbone's own side stream)
-                model.stage_dense({"batch_size": self.B, "spatial_features": self.canvas[q][0],
-                                   "spatial_scale_features": self.canvas[q][1], "_out_head": self.head[q]})
+                dense_in = {"batch_size": self.B, "spatial_features": self.canvas[q][0], "spatial_scale_features": self.canvas[q][1]}
+                if depth == 3:
+                    # frame k-1 (lane q): convolutions on the capture stream (+ the backbone's own branch streams)
+                    model.stage_dense({**dense_in, "_out_head": self.head[q]})
+                else:
+                    self.s_b.wait_stream(main)
+                    with torch.cuda.stream(self.s_b):     # frame k-2 (lane p): last branch + head + decode
+                        model.stage_dense_b({"batch_size": self.B, "_out_head": self.head[p]}, self.split[p])
+                    model.stage_dense_a(dense_in, self.split[q])          # frame k-1 (lane q): trunk + the other branches
+                    main.wait_stream(self.s_b)
                 main.wait_stream(self.s_enc)
                 main.wait_stream(self.s_post)
             pool = self.graphs[p].pool()
@@ -549,16 +584,16 @@ class PipelinedForward:
                 self.inp[p][k].copy_(v, non_blocking=True)
         self.graphs[p].replay()
         self.step += 1
-        return self.out[p] if self.step > 2 else None
+        return self.out[p] if self.step >= self.depth else None
 
     def flush(self):
-        """Two more steps (re-encoding the last inputs, whose results are dropped): yields the results of the last two
-        frames, oldest first.  Each result is only valid until the next step on its lane — consume it before the next."""
-        for _ in range(2):
+        """depth - 1 more steps (re-encoding the last inputs, whose results are dropped): yields the results of the frames still in
+        flight, oldest first.  Each result is only valid until the next step on its lane — consume it before the next."""
+        for _ in range(self.depth - 1):
             p = self.step & 1
             self.graphs[p].replay()
             self.step += 1
-            if self.step > 2:
+            if self.step >= self.depth:
                 yield self.out[p]
 
 
