@@ -162,10 +162,11 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
         constexpr int BUF = decltype(buf_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
         const float4 *sp = s_patch + BUF * PATCH_PAD;
         const float4 *sw = s_w + BUF * W_V4;
         float4 d0[4], d1[4], u[4][2];
+        // this chunk's first operands are requested BEFORE the next stage's DMA pieces are issued: the ~10 pieces take a few
+        // hundred cycles of issue, which covers the LDS latency of the reads (other stage: no conflict)
 #pragma unroll
         for (int jx = 0; jx < 4; ++jx) {
             d0[jx] = sp[p_off0 + (jx & 1) * 10 + (jx >> 1)];
@@ -175,6 +176,9 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) u[b][nb] = sw[u_off + b * 2 * BN + nb * 32];
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
         // input transform: t_j = d[r0][j] +- d[r1][j];  V[a][.] = (t0 - t2, t1 + t2, t2 - t1, t1 - t3)
         float4 t[4], v[4];
 #pragma unroll
