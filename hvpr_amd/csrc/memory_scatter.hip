@@ -408,15 +408,21 @@ __global__ void __launch_bounds__(256) k_bank_pack(const float *__restrict__ ban
     packed[o] = u;
 }
 
+// wmax[c] = max_j |bank[j][c]|.  Workgroup b covers items b*16 + part, stride 16 * gridDim.x; the workgroups combine through an
+// atomic max on the bit patterns (non-negative floats order like unsigned integers; max is order-independent: deterministic).
+// wmax must be zero on entry (k_wmax_zero).
+__global__ void __launch_bounds__(64) k_wmax_zero(float *__restrict__ wmax) { wmax[threadIdx.x] = 0.f; }
+
 __global__ void __launch_bounds__(1024) k_bank_wmax(const float *__restrict__ bank, int n_items, float *__restrict__ wmax) {
     __shared__ float s[16][kC];
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
     float m = 0.f;
     // eight independent loads per round (a one-load-per-iteration loop is one L2 round trip per item: 24 us for 2000 items)
-    for (int j0 = part; j0 < n_items; j0 += 16 * 8) {
+    const int step = 16 * (int)gridDim.x;
+    for (int j0 = (int)blockIdx.x * 16 + part; j0 < n_items; j0 += step * 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = j0 + 16 * u < n_items ? fabsf(bank[(size_t)(j0 + 16 * u) * kC + c]) : 0.f;
+        for (int u = 0; u < 8; ++u) v[u] = j0 + step * u < n_items ? fabsf(bank[(size_t)(j0 + step * u) * kC + c]) : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
     }
@@ -424,7 +430,8 @@ __global__ void __launch_bounds__(1024) k_bank_wmax(const float *__restrict__ ba
     __syncthreads();
     if (part == 0) {
         for (int i = 1; i < 16; ++i) m = fmaxf(m, s[i][c]);
-        wmax[c] = m;          // NaN rows propagate nothing here (fmaxf drops NaN): a NaN bank gives NaN logits either way
+        // NaN rows propagate nothing here (fmaxf drops NaN): a NaN bank gives NaN logits either way
+        atomicMax((unsigned *)wmax + c, __float_as_uint(m));
     }
 }
 
@@ -434,7 +441,10 @@ extern "C" int hvpr_memory_bank_pack_f32(const float *bank, int n_items, float *
     if (!bank || !packed || n_items < 1) return HVPR_ERR_INVALID_ARG;
     const int n_tiles = hvpr_cdiv(n_items, 16), n_out = n_tiles * 128;
     hipLaunchKernelGGL(k_bank_pack, dim3(hvpr_cdiv(n_out, 256)), dim3(256), 0, (hipStream_t)stream, bank, n_items, (uint4 *)packed, n_out);
-    hipLaunchKernelGGL(k_bank_wmax, dim3(1), dim3(1024), 0, (hipStream_t)stream, bank, n_items, packed + (size_t)n_tiles * 512);
+    float *wmax = packed + (size_t)n_tiles * 512;
+    hipLaunchKernelGGL(k_wmax_zero, dim3(1), dim3(kC), 0, (hipStream_t)stream, wmax);
+    const int wg = n_items <= 2048 ? 1 : (n_items < 128 * 128 ? hvpr_cdiv(n_items, 128) : 128);   // >= 8 items per wave slot
+    hipLaunchKernelGGL(k_bank_wmax, dim3(wg), dim3(1024), 0, (hipStream_t)stream, bank, n_items, wmax);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
