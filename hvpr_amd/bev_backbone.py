@@ -265,18 +265,20 @@ class BaseBEVBackbone_Scale(nn.Module):
         return data_dict
 
     def forward(self, data_dict):
-        """Eval forward.  data_dict["_bev_split"] = {"phase": "a" | "b", "x": ..., "y": ..., "out": ...} runs it in two halves on
-        caller-owned boundary buffers (the frame pipeline overlaps the halves of neighbouring frames): phase "a" = the whole trunk
-        and every branch but the last (writes x = the last trunk output, y = the last-but-one scale output, and its slices of
-        out = the concat); phase "b" = the last level's branch (reads x, y; finishes out)."""
+        """Eval forward.  data_dict["_bev_split"] = {"phase": "a" | "b", "level": L, "x": {i: ...}, "y": ..., "out": ...} runs it in
+        two halves on caller-owned boundary buffers (the frame pipeline overlaps the halves of neighbouring frames): phase "a" =
+        the whole trunk and the branches of the levels below L (writes x[i] = the trunk output of every level i >= L, y = the scale
+        output of level L - 1, and its slices of out = the concat); phase "b" = the branches of the levels >= L (reads x, y;
+        finishes out)."""
         if self.training:
             return self._forward_train(data_dict)
         split = data_dict.get("_bev_split")
         phase = split["phase"] if split is not None else None
         n_lv = len(self.blocks)
+        L = split["level"] if split is not None else n_lv
         if phase == "b":
-            x, y, out = split["x"], split["y"], split["out"]
-            B = x.shape[0]
+            x, y, out = None, split["y"], split["out"]
+            B = y.shape[0]
             H, W = self._shape_key
         else:
             sp, sc = data_dict["spatial_features"], data_dict["spatial_scale_features"]
@@ -286,9 +288,9 @@ class BaseBEVBackbone_Scale(nn.Module):
             if self._shape_key != (H, W):
                 self._fold.invalidate()
                 self._shape_key = (H, W)
-        P = self._fold.get(x.device, lambda: self._build_packed(H, W))
+        P = self._fold.get(y.device, lambda: self._build_packed(H, W))
         gw, gb, gs, gt = P["gate"]
-        gw = gw.to(x.device)
+        gw = gw.to(y.device)
         us_all = [int(u) for u in self.upsample_strides]
         if phase is None:
             # output size of the concat: level-0 resolution after its own stride, times its upsample stride
@@ -302,34 +304,40 @@ class BaseBEVBackbone_Scale(nn.Module):
         # y_i = scale_i(y_{i-1}).  The trunk runs on the caller's stream, every branch on a stream of its own (waiting for its
         # x_i and, by event, for y_{i-1}): at batch 1 the upper levels have fewer tiles than the chip has workgroup slots.
         main = torch.cuda.current_stream()
+        # phase "b" already runs on a forked stream of the caller's capture: forking again from it (a second level of stream
+        # forks inside one hipGraph capture) crashed hipStreamEndCapture on this ROCm build, so its branches stay in line
         two_streams = self.overlap_branches and phase != "b"
-        sides = self._branch_streams(x.device, n_lv) if two_streams else []
+        sides = self._branch_streams(y.device, n_lv) if two_streams else []
         coff = 0
         capturing = torch.cuda.is_current_stream_capturing()
         held = []     # tensors another stream reads: referenced until the join, so that the allocator of the producing stream
         #               cannot hand their memory out again while the other stream still reads them
         y_ready = None
+        used = []
         planes = self.PRECISIONS[self.conv_precision]
         bf3 = planes > 0
         assert not (bf3 and phase is not None), "the split forward runs the fp32 kernels"
         if bf3:
             x = kernels.split_bf16(x, planes)  # the trunk runs in split-bf16 form from here on
         for i, lv in enumerate(P["levels"]):
-            last = i == n_lv - 1
-            if phase == "b" and not last:
+            in_b = i >= L
+            if phase == "b":
+                if not in_b:
+                    coff += self.up_filters[i]
+                    continue
+                x = split["x"][i]
+            elif bf3:
+                for pc in lv["convs3"]:
+                    x = kernels.conv2d_nhwc_bf3(x, pc)
+            else:
+                for j, pc in enumerate(lv["convs"]):
+                    x = kernels.conv2d_nhwc(x, pc, out=split["x"][i] if (phase == "a" and in_b and j == len(lv["convs"]) - 1) else None)
+            if phase == "a" and in_b:
                 coff += self.up_filters[i]
-                continue
-            if phase != "b":
-                if bf3:
-                    for pc in lv["convs3"]:
-                        x = kernels.conv2d_nhwc_bf3(x, pc)
-                else:
-                    for j, pc in enumerate(lv["convs"]):
-                        x = kernels.conv2d_nhwc(x, pc, out=split["x"] if (phase == "a" and last and j == len(lv["convs"]) - 1) else None)
-            if phase == "a" and last:
-                break                                      # the last branch is phase "b"
+                continue                                   # this level's branch is phase "b"
             if two_streams:
                 side = sides[i]
+                used.append(side)
                 side.wait_stream(main)          # x_i (and, at level 0, the scale stream's input) are ready for the branch
                 if y_ready is not None and sides[i - 1] is not side:
                     side.wait_event(y_ready)    # y_{i-1} from the previous branch's stream
@@ -338,7 +346,7 @@ class BaseBEVBackbone_Scale(nn.Module):
             else:
                 ctx = contextlib.nullcontext()
             with ctx:
-                y = kernels.conv2d_nhwc(y, lv["scale"], out=split["y"] if (phase == "a" and i == n_lv - 2) else None)
+                y = kernels.conv2d_nhwc(y, lv["scale"], out=split["y"] if (phase == "a" and i == L - 1) else None)
                 if two_streams:
                     y_ready = torch.cuda.Event()
                     y_ready.record(side)
@@ -367,7 +375,7 @@ class BaseBEVBackbone_Scale(nn.Module):
                         y.record_stream(sides[i + 1])
             coff += self.up_filters[i]
         if two_streams:
-            for side in dict.fromkeys(sides):
+            for side in dict.fromkeys(used):          # only the streams this call forked (another phase may own the others)
                 main.wait_stream(side)
         held.clear()
         if phase == "a":
@@ -375,18 +383,23 @@ class BaseBEVBackbone_Scale(nn.Module):
         data_dict["spatial_features_2d"] = out.permute(0, 3, 1, 2)   # (B, 384, H, W), channels_last
         return data_dict
 
-    def split_buffers(self, batch_size, H, W, device):
-        """Boundary buffers of the two-phase forward for canvases of (H, W): x (last trunk output), y (last-but-one scale output),
-        out (the concat)."""
+    def split_buffers(self, batch_size, H, W, device, level=None):
+        """Boundary buffers of the two-phase forward for canvases of (H, W): x[i] (trunk output of every level i >= level), y
+        (scale output of level - 1), out (the concat).  level defaults to the last one (HVPR_PIPE_SPLIT overrides); >= 1."""
+        n_lv = len(self.blocks)
+        if level is None:
+            level = int(os.environ.get("HVPR_PIPE_SPLIT", n_lv - 1))
+        assert 1 <= level <= n_lv - 1
         h, w, hw = H, W, []
         for s in self.layer_strides:
             h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
             hw.append((h, w))
-        cx = self.blocks[-1][1].weight.shape[0]
-        cy = self.scale_layers[-2][1].weight.shape[0]
+        cy = self.scale_layers[level - 1][1].weight.shape[0]
         us0 = int(self.upsample_strides[0])
         mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
-        return {"x": mk(batch_size, hw[-1][0], hw[-1][1], cx), "y": mk(batch_size, hw[-2][0], hw[-2][1], cy),
+        return {"level": level,
+                "x": {i: mk(batch_size, hw[i][0], hw[i][1], self.blocks[i][1].weight.shape[0]) for i in range(level, n_lv)},
+                "y": mk(batch_size, hw[level - 1][0], hw[level - 1][1], cy),
                 "out": mk(batch_size, hw[0][0] * us0, hw[0][1] * us0, self.num_bev_features)}
 
 
