@@ -10,8 +10,8 @@
 // channel, the two K slots of an instruction = two neighbouring blocks (as k_wgrad in conv_train.hip).
 //
 // Workgroup = 8 waves, 64 co x 64 ci; wave (a = wid & 3, ch = wid >> 2) owns the four products xi = (a, 0..3) for co half `ch`:
-// 4 x 2 accumulator blocks of 32 x 32 (128 registers).  A pixel tile is 8 x 8 outputs (4 x 4 blocks = 8 K steps): the dz tile
-// [64 px][64 co] and the input patch [10 x 10 px][64 ci] are staged in LDS (next tile prefetched in registers).  Per K step a
+// 4 x 2 accumulator blocks of 32 x 32 (128 registers).  A pixel tile is 8 x 16 outputs (4 x 8 blocks = 16 K steps): the dz tile
+// [128 px][64 co] and the input patch [10 x 18 px][64 ci] are staged in LDS (next tile prefetched in registers).  Per K step a
 // wave reads the 2x2 of dY for its co (4 ds_read_b32) and the two patch rows x four columns row `a` of Bt needs for two ci
 // blocks (16 ds_read_b32), forms row a of (A dY At) and of (Bt d B) in registers (~20 VALU) and issues 8 MFMAs.  The two signs
 // of A's last row / column are left out of the operands and applied by the reducing kernel.  Split-K over pixel tiles into
@@ -30,15 +30,17 @@ struct WwArgs {
     int tiles_x, tiles_y, n_pt, n_chunks, n_ci_tiles;
 };
 
-constexpr int TH = 8, TW = 8, PH = TH + 2, PW = TW + 2;
+constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2;     // 8 x 16 outputs = 4 x 8 blocks = 16 K steps per tile
 constexpr int BM = 64, BNN = 64;                     // co x ci of the workgroup
 constexpr int NT = 512;
 constexpr int DZ_V4 = TH * TW * BM / 4, X_V4 = PH * PW * BNN / 4;       // 1024, 1600
-constexpr int NLD_D = DZ_V4 / NT, NLD_X = (X_V4 + NT - 1) / NT;         // 2, 4
+constexpr int NLD_D = DZ_V4 / NT, NLD_X = (X_V4 + NT - 1) / NT;         // 4, 6
+constexpr int kLds = (TH * TW * BM + PH * PW * BNN) * 4;                // 78 KB: one workgroup per CU
 
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wgrad_wino(WwArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_dz[TH * TW * BM];      // [pixel][co]
-    __shared__ __attribute__((aligned(16))) float s_x[PH * PW * BNN];      // [patch pixel][ci]
+    extern __shared__ __attribute__((aligned(16))) float smem_w[];
+    float *const s_dz = smem_w;                        // [pixel][co]
+    float *const s_x = smem_w + TH * TW * BM;          // [patch pixel][ci]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wa = wid & 3, ch = wid >> 2, half = lane >> 5, l31 = lane & 31;
     const int ot = blockIdx.x, chunk = blockIdx.y;
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int ya0 = wa == 3 ? 1 : 0, ya1 = 1;                      // dY rows combined
     const int r0 = wa == 0 ? 0 : (wa == 2 ? 2 : 1), r1 = wa == 2 ? 1 : (wa == 3 ? 3 : 2);
     const float sB = wa == 1 ? 1.f : -1.f;
-    // lane half h takes block 2m + h of the tile's 16: by = m >> 1, bx = 2 * (m & 1) + h  -> two pixels to the right for h = 1
+    // lane half h takes block 2m + h of the tile: by = m / (TW / 4), bx = 2 * (m % (TW / 4)) + h  -> two pixels to the right for h = 1
     const float *pa0 = s_dz + (ya0 * TW + 2 * half) * BM + ch * 32 + l31;       // + ((2 by) * TW + 2 bx0 + q) * BM
     const float *pa1 = s_dz + (ya1 * TW + 2 * half) * BM + ch * 32 + l31;
     const float *pb0 = s_x + (r0 * PW + 2 * half) * BNN + l31;                  // + ((2 by) * PW + 2 bx0 + j) * BNN + nb * 32
@@ -101,8 +103,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
         __syncthreads();
         if (pt + a.n_chunks < a.n_pt) fetch(pt + a.n_chunks);   // the next tile travels while this one multiplies
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int by = m >> 1, bx0 = 2 * (m & 1);
+        for (int m = 0; m < TH * TW / 8; ++m) {
+            const int by = m / (TW / 4), bx0 = 2 * (m % (TW / 4));
             const int oa = ((2 * by) * TW + 2 * bx0) * BM, ob = ((2 * by) * PW + 2 * bx0) * BNN;
             // A operand: row wa of (A dY At) for this lane's co; columns: (t0, t0 + t1, t0 - t1, t1 [true: -t1])
             const float y00 = pa0[oa], y01 = pa0[oa + BM], y10 = pa1[oa], y11 = pa1[oa + BM];
@@ -201,7 +203,9 @@ extern "C" int hvpr_conv2d_wino_wgrad_nhwc_f32(const float *x, int N, int H, int
     a.n_chunks = ww_chunks(N, H, W, Cin, Cout);
     const int n_ot = a.n_ci_tiles * ((Cout + BM - 1) / BM);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_wgrad_wino, dim3(n_ot, a.n_chunks), dim3(NT), 0, s, a);
+    static unsigned long long lds_set = 0ull;
+    if (hvpr_ensure_dyn_lds((const void *)k_wgrad_wino, kLds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_wgrad_wino, dim3(n_ot, a.n_chunks), dim3(NT), kLds, s, a);
     const long long per = (long long)Cout * Cin;
     hipLaunchKernelGGL(k_wgrad_wino_reduce, dim3(hvpr_cdiv(per, 256)), dim3(256), 0, s, a.part, a.n_chunks, Cout, Cin, dw);
     HVPR_CHECK_LAUNCH();
