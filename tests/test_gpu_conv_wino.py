@@ -89,3 +89,27 @@ def test_wino_wgrad_matches_float64(N, H, W, cin, cout):
     print(f"winograd wgrad {ew:.2e}  direct {ed:.2e}")
     assert ew < 2e-5 and ew < 4 * ed + 1e-6, (ew, ed)
     assert torch.equal(dw, conv_train.conv_wgrad(x, dz, 9, 1, cout, cin))          # deterministic
+
+
+def test_wino_full_size_properties():
+    """BASELINE.json sizes (level 0 of hvpr_car: 248 x 296 x 128, batch 2) through size-independent properties: the direct kernel
+    on the same input (1e-5 of the output scale), linearity in the input, and determinism of forward and weight gradient."""
+    from hvpr_amd import conv_train, kernels
+    g = torch.Generator().manual_seed(77)
+    N, H, W, C = 2, 248, 296, 128
+    x1 = torch.randn(N, H, W, C, generator=g).to(DEV)
+    x2 = torch.randn(N, H, W, C, generator=g).to(DEV)
+    w = (torch.randn(C, C, 3, 3, generator=g) / np.sqrt(9 * C)).to(DEV)
+    pw = kernels.pack_conv_wino(w, relu=False)
+    y1, y2, y12 = kernels.conv2d_wino_nhwc(x1, pw), kernels.conv2d_wino_nhwc(x2, pw), kernels.conv2d_wino_nhwc(x1 + x2, pw)
+    s = float(y12.abs().max())
+    assert float((y12 - (y1 + y2)).abs().max()) < 2e-5 * s                       # linearity (fp32 round-off only)
+    yd = kernels.conv2d_nhwc(x1, kernels.pack_conv(w, None, None, stride=1, relu=False, tile_cfg=1))
+    assert float((y1 - yd).abs().max()) < 1e-5 * float(yd.abs().max())
+    assert torch.equal(y1, kernels.conv2d_wino_nhwc(x1, pw))
+    dw = conv_train.conv_wgrad(x1, y2, 9, 1, C, C)
+    assert torch.equal(dw, conv_train.conv_wgrad(x1, y2, 9, 1, C, C))
+    # <dz, conv(x, w)> = <dw, w>: the weight gradient is the adjoint of the convolution in w
+    lhs = float((y2.double() * y1.double()).sum())
+    rhs = float((dw.double() * w.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * abs(lhs), (lhs, rhs)
