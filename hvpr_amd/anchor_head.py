@@ -3,6 +3,8 @@ anchor_head_template.py, target_assigner/anchor_generator.py; utils/box_coder_ut
 
 Eval forward = one fp32-MFMA 1x1 convolution for the three heads (cls | box | dir concatenated on the channel axis)
 plus one decode launch (anchors, residual decode, direction fix, class sigmoid/max) instead of ~20 PyTorch kernels."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -210,12 +212,32 @@ class AnchorHeadSingle(AnchorHeadTemplate):
         """Training forward, anchor_head_single.py:41-108: both streams through the same three 1x1 convs (torch, autograd),
         targets assigned once."""
         fr = self.forward_ret_dict
+        heads = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
+        f0 = data_dict["spatial_features_2d"]
+        hip = f0.is_cuda and f0.dtype == torch.float32 and os.environ.get("HVPR_TRAIN_CONV", "hip") != "torch" and \
+            all(h.weight.shape[0] % 2 == 0 for h in heads)
+        if hip:
+            # the three 1x1 convolutions as ONE convolution on the library's kernels (forward, data and weight gradient:
+            # hvpr_amd/conv_train.py), output channels padded to a multiple of 8 with zero rows (the data gradient is a
+            # convolution with that many input channels); the biases are added by torch
+            from . import conv_train as ct
+            w = torch.cat([h.weight for h in heads], dim=0)
+            b = torch.cat([h.bias for h in heads], dim=0)
+            n_out = w.shape[0]
+            pad = (-n_out) % 8
+            if pad:
+                w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
+            cuts = np.cumsum([0] + [h.weight.shape[0] for h in heads])
         for key, suffix in (("spatial_features_2d", ""), ("spatial_features_point_2d", "_point")):
             f = data_dict[key]
-            fr["cls_preds" + suffix] = self.conv_cls(f).permute(0, 2, 3, 1).contiguous()
-            fr["box_preds" + suffix] = self.conv_box(f).permute(0, 2, 3, 1).contiguous()
+            if hip:
+                out = ct.conv(f.permute(0, 2, 3, 1), w)[..., :n_out] + b
+                parts = [out[..., cuts[i]:cuts[i + 1]].contiguous() for i in range(len(heads))]
+            else:
+                parts = [h(f).permute(0, 2, 3, 1).contiguous() for h in heads]
+            fr["cls_preds" + suffix], fr["box_preds" + suffix] = parts[0], parts[1]
             if self.conv_dir_cls is not None:
-                fr["dir_cls_preds" + suffix] = self.conv_dir_cls(f).permute(0, 2, 3, 1).contiguous()
+                fr["dir_cls_preds" + suffix] = parts[2]
         fr["pos_point_feas"] = data_dict["point_positive_features"]
         fr["pos_memory_feas"] = data_dict["memory_positive_features"]
         fr["memory_items"] = data_dict["memory_items"]
