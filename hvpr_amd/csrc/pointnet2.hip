@@ -17,31 +17,9 @@ __device__ __forceinline__ unsigned long long fps_key(float d, int idx) {
     return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(0xffffffffu - (unsigned)idx);   // d >= 0
 }
 
-// One workgroup per sample, the points and their running minimum distances in registers.  An iteration = distance update +
-// arg-max (largest distance, lowest index on ties).  The arg-max is two DPP wave reductions (max of the distance, then min of the
-// index among the lanes that hold it) and one LDS exchange between the waves; the winner's coordinates travel with it, so the next
-// iteration does not start with a dependent global load (4096 iterations x (L2 round trip + 12 ds_bpermute) was 2 us each).
-__device__ __forceinline__ int fps_dpp_min_i32(int v) {
-    auto step = [](int x, int y) { return x < y ? x : y; };
-    v = step(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));
-    v = step(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
-    v = step(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
-    v = step(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
-    {
-        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-        v = step((int)r[0], (int)r[1]);
-    }
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-        v = step((int)r[0], (int)r[1]);
-    }
-    return v;
-}
-
 template <int PPT>
 __global__ void __launch_bounds__(FPS_THREADS) k_fps(const float *__restrict__ xyz, int N, int npoint, int *__restrict__ out) {
-    __shared__ float4 s_best[2][FPS_THREADS / 64];        // per wave: (distance, x, y, z) of its winner ...
-    __shared__ int s_idx[2][FPS_THREADS / 64];            // ... and its index
+    __shared__ unsigned long long s_best[2][FPS_THREADS / 64];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const float *p = xyz + (size_t)b * N * 3;
     float px[PPT], py[PPT], pz[PPT], md[PPT];
@@ -54,36 +32,36 @@ __global__ void __launch_bounds__(FPS_THREADS) k_fps(const float *__restrict__ x
         pz[k] = ok ? p[i * 3 + 2] : 0.f;
         md[k] = ok ? 1e10f : -1.f;          // padding can never win
     }
-    float lx = p[0], ly = p[1], lz = p[2];
+    int last = 0;
     if (t == 0) out[(size_t)b * npoint] = 0;      // first pick is index 0
     for (int j = 1; j < npoint; ++j) {
-        // this thread's best: largest distance, lowest index on ties (k ascending = index ascending: strict > keeps the first)
-        float bd = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
-        int bi = 0x7fffffff;
+        const float lx = p[last * 3 + 0], ly = p[last * 3 + 1], lz = p[last * 3 + 2];
+        unsigned long long best = 0ull;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const float dx = px[k] - lx, dy = py[k] - ly, dz = pz[k] - lz;
             const float d = (dx * dx + dy * dy) + dz * dz;
             if (md[k] >= 0.f) {
                 md[k] = fminf(md[k], d);
-                if (md[k] > bd) { bd = md[k]; bi = t + k * FPS_THREADS; bx = px[k]; by = py[k]; bz = pz[k]; }
+                const unsigned long long key = fps_key(md[k], t + k * FPS_THREADS);
+                best = key > best ? key : best;
             }
         }
-        const float wd = hvpr_reduce_max<64>(bd);
-        const int wi = fps_dpp_min_i32(bd == wd ? bi : 0x7fffffff);
-        const int buf = j & 1;
-        if (bi == wi && bd == wd) { s_best[buf][wid] = make_float4(bd, bx, by, bz); s_idx[buf][wid] = bi; }
-        __syncthreads();
-        float4 g = s_best[buf][0];
-        int gi = s_idx[buf][0];
 #pragma unroll
-        for (int w = 1; w < FPS_THREADS / 64; ++w) {
-            const float4 c = s_best[buf][w];
-            const int ci = s_idx[buf][w];
-            if (c.x > g.x || (c.x == g.x && ci < gi)) { g = c; gi = ci; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
+            const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
+            const unsigned long long ob = ((unsigned long long)hi << 32) | lo;
+            best = ob > best ? ob : best;
         }
-        lx = g.y; ly = g.z; lz = g.w;
-        if (t == 0) out[(size_t)b * npoint + j] = gi;
+        const int buf = j & 1;
+        if (lane == 0) s_best[buf][wid] = best;
+        __syncthreads();
+        unsigned long long g = s_best[buf][0];
+#pragma unroll
+        for (int w = 1; w < FPS_THREADS / 64; ++w) g = s_best[buf][w] > g ? s_best[buf][w] : g;
+        last = (int)(0xffffffffu - (unsigned)(g & 0xffffffffull));
+        if (t == 0) out[(size_t)b * npoint + j] = last;
     }
 }
 
