@@ -208,8 +208,8 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
     }
     if (n_chunks & 1) chunk_step(n_chunks - 1, std::integral_constant<int, 0>{});
 
-    // ---- output transform + epilogue, one 32-channel half of the tile at a time.  A lane holds block l31 and 16 channels per
-    // accumulator block (rows (r&3) + 8*(r>>2) + 4*half: four runs of four).  Exchange area (float4): [grp][a][q][run][lane]. ----
+    // ---- output transform + epilogue.  A lane holds block l31 and 16 channels per accumulator block (rows (r&3) + 8*(r>>2) +
+    // 4*half: four runs of four).  Exchange area (float4): [grp][a][q][channel half of the pass][run][lane]. ----
     const int p = wa >> 1, q = wa & 1;
     const int oy = oy0 + 2 * (4 * grp + by) + p, ox = ox0 + 2 * bx + q;
     const bool live_px = oy < a.H && ox < a.W;
@@ -217,34 +217,44 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
     const float gate = a.gate && live_px ? a.gate[pix] : 0.f;
     const float *rrow = a.gate ? a.resid + pix * a.resid_cstride : nullptr;
     const float sg = p ? -1.f : 1.f;
+    // one pass over both 32-channel halves when the exchange fits the two filter stages (NG = 1: 64 KB), else one half per pass
+    constexpr int NPASS = NG == 1 ? 1 : 2, NBP = 2 / NPASS;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int ps = 0; ps < NPASS; ++ps) {
         __syncthreads();               // the U stages (first pass) / the previous pass's exchange reads are done
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 m[4];
+        for (int nl = 0; nl < NBP; ++nl) {
+            const int nb = ps * NBP + nl;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) m[b] = make_float4(acc[b][nb][4 * g], acc[b][nb][4 * g + 1], acc[b][nb][4 * g + 2], acc[b][nb][4 * g + 3]);
-            s_w[(((grp * 4 + wa) * 2 + 0) * 4 + g) * 64 + lane] = f4_add(f4_add(m[0], m[1]), m[2]);
-            s_w[(((grp * 4 + wa) * 2 + 1) * 4 + g) * 64 + lane] = f4_sub(f4_sub(m[1], m[2]), m[3]);
+            for (int g = 0; g < 4; ++g) {
+                float4 m[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) m[b] = make_float4(acc[b][nb][4 * g], acc[b][nb][4 * g + 1], acc[b][nb][4 * g + 2], acc[b][nb][4 * g + 3]);
+                s_w[((((grp * 4 + wa) * 2 + 0) * NBP + nl) * 4 + g) * 64 + lane] = f4_add(f4_add(m[0], m[1]), m[2]);
+                s_w[((((grp * 4 + wa) * 2 + 1) * NBP + nl) * 4 + g) * 64 + lane] = f4_sub(f4_sub(m[1], m[2]), m[3]);
+            }
         }
         __syncthreads();
         if (live_px) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = co0 + nb * 32 + 8 * g + 4 * half;
-                if (col >= a.cout) continue;
-                const float4 x0 = s_w[(((grp * 4 + p) * 2 + q) * 4 + g) * 64 + lane];
-                const float4 x1 = s_w[(((grp * 4 + p + 1) * 2 + q) * 4 + g) * 64 + lane];
-                const float4 x2 = s_w[(((grp * 4 + p + 2) * 2 + q) * 4 + g) * 64 + lane];
-                const float4 bias = *(const float4 *)(a.bias + col);
-                float4 y = f4_add(f4_fma(sg, x2, f4_fma(sg, x1, x0)), bias);       // p = 0: x0 + x1 + x2;  p = 1: x1 - x2 - x3
-                if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-                if (a.gate) {
-                    const float4 r = *(const float4 *)(rrow + col);
-                    y.x = fmaf(gate, y.x, r.x); y.y = fmaf(gate, y.y, r.y); y.z = fmaf(gate, y.z, r.z); y.w = fmaf(gate, y.w, r.w);
+            for (int nl = 0; nl < NBP; ++nl) {
+                const int nb = ps * NBP + nl;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = co0 + nb * 32 + 8 * g + 4 * half;
+                    if (col >= a.cout) continue;
+                    const float4 x0 = s_w[((((grp * 4 + p) * 2 + q) * NBP + nl) * 4 + g) * 64 + lane];
+                    const float4 x1 = s_w[((((grp * 4 + p + 1) * 2 + q) * NBP + nl) * 4 + g) * 64 + lane];
+                    const float4 x2 = s_w[((((grp * 4 + p + 2) * 2 + q) * NBP + nl) * 4 + g) * 64 + lane];
+                    const float4 bias = *(const float4 *)(a.bias + col);
+                    float4 y = f4_add(f4_fma(sg, x2, f4_fma(sg, x1, x0)), bias);       // p = 0: x0 + x1 + x2;  p = 1: x1 - x2 - x3
+                    if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                    if (a.gate) {
+                        const float4 r = *(const float4 *)(rrow + col);
+                        y.x = fmaf(gate, y.x, r.x); y.y = fmaf(gate, y.y, r.y); y.z = fmaf(gate, y.z, r.z); y.w = fmaf(gate, y.w, r.w);
+                    }
+                    *(float4 *)(a.out + pix * a.out_cstride + a.out_coff + col) = y;
                 }
-                *(float4 *)(a.out + pix * a.out_cstride + a.out_coff + col) = y;
             }
         }
     }
