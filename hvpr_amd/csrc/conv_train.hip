@@ -194,25 +194,46 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float *__restrict__ z, 
     if (pl < lanes) {
         float4 sc = A, sh = A, mu = A, is = A;
         if (BWD) { sc = *(const float4 *)(scale + 4 * g); sh = *(const float4 *)(shift + 4 * g); mu = *(const float4 *)(mean + 4 * g); is = *(const float4 *)(invstd + 4 * g); }
-        for (long long p = p0 + pl; p < p1; p += lanes) {
-            const float4 v = *(const float4 *)(z + p * C + 4 * g);
+        // four pixels per trip, all their loads issued before the sums: a workgroup walks 1 MB with 256 threads, and one
+        // load in flight per thread (the dependent-accumulator form) kept the pass at 2.4 TB/s
+        auto one = [&](const float4 v, float4 d, const float gp, float4 &A_, float4 &B_) {
             if (!BWD) {     // sum, sum of squares
-                A.x += v.x; A.y += v.y; A.z += v.z; A.w += v.w;
-                B.x = fmaf(v.x, v.x, B.x); B.y = fmaf(v.y, v.y, B.y); B.z = fmaf(v.z, v.z, B.z); B.w = fmaf(v.w, v.w, B.w);
+                A_.x += v.x; A_.y += v.y; A_.z += v.z; A_.w += v.w;
+                B_.x = fmaf(v.x, v.x, B_.x); B_.y = fmaf(v.y, v.y, B_.y); B_.z = fmaf(v.z, v.z, B_.z); B_.w = fmaf(v.w, v.w, B_.w);
             } else {        // s1 = sum dy * mask, s2 = sum dy * mask * xhat; mask = the ReLU passed (scale * z + shift > 0)
-                float4 d = *(const float4 *)(dy + p * C + 4 * g);
-                if (gate) { const float gp = gate[p]; d.x *= gp; d.y *= gp; d.z *= gp; d.w *= gp; }
+                if (gate) { d.x *= gp; d.y *= gp; d.z *= gp; d.w *= gp; }
                 if (relu) {
                     if (!(fmaf(v.x, sc.x, sh.x) > 0.f)) d.x = 0.f;
                     if (!(fmaf(v.y, sc.y, sh.y) > 0.f)) d.y = 0.f;
                     if (!(fmaf(v.z, sc.z, sh.z) > 0.f)) d.z = 0.f;
                     if (!(fmaf(v.w, sc.w, sh.w) > 0.f)) d.w = 0.f;
                 }
-                A.x += d.x; A.y += d.y; A.z += d.z; A.w += d.w;
-                B.x = fmaf(d.x, (v.x - mu.x) * is.x, B.x); B.y = fmaf(d.y, (v.y - mu.y) * is.y, B.y);
-                B.z = fmaf(d.z, (v.z - mu.z) * is.z, B.z); B.w = fmaf(d.w, (v.w - mu.w) * is.w, B.w);
+                A_.x += d.x; A_.y += d.y; A_.z += d.z; A_.w += d.w;
+                B_.x = fmaf(d.x, (v.x - mu.x) * is.x, B_.x); B_.y = fmaf(d.y, (v.y - mu.y) * is.y, B_.y);
+                B_.z = fmaf(d.z, (v.z - mu.z) * is.z, B_.z); B_.w = fmaf(d.w, (v.w - mu.w) * is.w, B_.w);
             }
+        };
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 A1 = zero4, B1 = zero4, A2 = zero4, B2 = zero4, A3 = zero4, B3 = zero4;
+        long long p = p0 + pl;
+        for (; p + 3 * lanes < p1; p += 4 * lanes) {
+            float4 v[4], d[4];
+            float gp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = *(const float4 *)(z + (p + u * lanes) * C + 4 * g);
+                d[u] = BWD ? *(const float4 *)(dy + (p + u * lanes) * C + 4 * g) : zero4;
+                gp[u] = (BWD && gate) ? gate[p + u * lanes] : 1.f;
+            }
+            one(v[0], d[0], gp[0], A, B); one(v[1], d[1], gp[1], A1, B1); one(v[2], d[2], gp[2], A2, B2); one(v[3], d[3], gp[3], A3, B3);
         }
+        for (; p < p1; p += lanes) {
+            const float4 v = *(const float4 *)(z + p * C + 4 * g);
+            const float4 d = BWD ? *(const float4 *)(dy + p * C + 4 * g) : zero4;
+            one(v, d, (BWD && gate) ? gate[p] : 1.f, A, B);
+        }
+        A.x += (A1.x + A2.x) + A3.x; A.y += (A1.y + A2.y) + A3.y; A.z += (A1.z + A2.z) + A3.z; A.w += (A1.w + A2.w) + A3.w;
+        B.x += (B1.x + B2.x) + B3.x; B.y += (B1.y + B2.y) + B3.y; B.z += (B1.z + B2.z) + B3.z; B.w += (B1.w + B2.w) + B3.w;
     }
     s_a[threadIdx.x] = A; s_b[threadIdx.x] = B;
     __syncthreads();
