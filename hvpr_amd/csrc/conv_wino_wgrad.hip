@@ -141,29 +141,40 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
 }
 
-// dU[xi] = sum over chunks (chunk order), signs of A's last row / column, dg = Gt dU G  ->  dw [co][ci][3][3]
+// dU[xi] = sum over chunks (chunk order), signs of A's last row / column, dg = Gt dU G  ->  dw [co][ci][3][3].
+// Workgroup = 16 (co, ci) pairs x 16 products: thread (xi, pair) sums its product over the chunks (four independent partial sums:
+// the chunk loop is a chain of loads), the 16 sums of a pair meet in LDS and one thread per pair applies Gt . G.
 __global__ void __launch_bounds__(256) k_wgrad_wino_reduce(const float *__restrict__ part, int n_chunks, int Cout, int Cin,
                                                            float *__restrict__ dw) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // over [co][ci]
+    __shared__ float s_u[16][17];
+    const int pr = threadIdx.x & 15, xi = threadIdx.x >> 4;
     const long long per = (long long)Cout * Cin;
-    if (i >= per) return;
-    float u[4][4];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi) {
-        float s = 0.f;
-        for (int c = 0; c < n_chunks; ++c) s += part[((size_t)c * 16 + xi) * per + i];
-        const bool neg = ((xi >> 2) == 3) != ((xi & 3) == 3);
-        u[xi >> 2][xi & 3] = neg ? -s : s;
+    const long long i = (long long)blockIdx.x * 16 + pr;      // over [co][ci]
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < per) {
+        const float *src = part + (size_t)xi * per + i;
+        const size_t step = (size_t)16 * per;
+        int c = 0;
+        for (; c + 3 < n_chunks; c += 4) {
+            s0 += src[(size_t)c * step]; s1 += src[(size_t)(c + 1) * step]; s2 += src[(size_t)(c + 2) * step]; s3 += src[(size_t)(c + 3) * step];
+        }
+        for (; c < n_chunks; ++c) s0 += src[(size_t)c * step];
     }
+    const float s = (s0 + s1) + (s2 + s3);
+    const bool neg = ((xi >> 2) == 3) != ((xi & 3) == 3);
+    s_u[pr][xi] = neg ? -s : s;
+    __syncthreads();
+    if (threadIdx.x >= 16 || (long long)blockIdx.x * 16 + threadIdx.x >= per) return;
+    const float *u = s_u[threadIdx.x];                        // u[a * 4 + b]
     // Gt = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
     float h[3][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        h[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
-        h[1][b] = 0.5f * (u[1][b] - u[2][b]);
-        h[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+        h[0][b] = u[b] + 0.5f * (u[4 + b] + u[8 + b]);
+        h[1][b] = 0.5f * (u[4 + b] - u[8 + b]);
+        h[2][b] = 0.5f * (u[4 + b] + u[8 + b]) + u[12 + b];
     }
-    float *o = dw + (size_t)i * 9;
+    float *o = dw + ((size_t)blockIdx.x * 16 + threadIdx.x) * 9;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         o[r * 3 + 0] = h[r][0] + 0.5f * (h[r][1] + h[r][2]);
@@ -207,7 +218,7 @@ extern "C" int hvpr_conv2d_wino_wgrad_nhwc_f32(const float *x, int N, int H, int
     if (hvpr_ensure_dyn_lds((const void *)k_wgrad_wino, kLds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
     hipLaunchKernelGGL(k_wgrad_wino, dim3(n_ot, a.n_chunks), dim3(NT), kLds, s, a);
     const long long per = (long long)Cout * Cin;
-    hipLaunchKernelGGL(k_wgrad_wino_reduce, dim3(hvpr_cdiv(per, 256)), dim3(256), 0, s, a.part, a.n_chunks, Cout, Cin, dw);
+    hipLaunchKernelGGL(k_wgrad_wino_reduce, dim3(hvpr_cdiv(per, 16)), dim3(256), 0, s, a.part, a.n_chunks, Cout, Cin, dw);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
