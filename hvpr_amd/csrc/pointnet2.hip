@@ -67,27 +67,41 @@ __global__ void __launch_bounds__(FPS_THREADS) k_fps(const float *__restrict__ x
 
 // ---------------------------------------------------------------------------------------------------- ball query
 // idx[b,m,:] = the first nsample points (index order) with d2 < radius^2; the first hit pre-fills every slot; 0 if none.
+// A workgroup takes 256 queries of one sample and walks the sample's points in tiles of 512 staged in LDS (structure of arrays:
+// every thread reads the same point at the same time = a broadcast read); it stops when all of its queries are full.
+constexpr int BQ_TILE = 512;
 __global__ void __launch_bounds__(256) k_ball_query(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int B, int N,
                                                     int M, float radius, int nsample, int *__restrict__ idx) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)B * M) return;
-    const int b = (int)(t / M);
+    __shared__ float s_x[BQ_TILE], s_y[BQ_TILE], s_z[BQ_TILE];
+    const int wg_per_b = (M + 255) / 256;
+    const int b = blockIdx.x / wg_per_b, m = (blockIdx.x % wg_per_b) * 256 + threadIdx.x;
+    const bool live = m < M;
+    const long long t = (long long)b * M + (live ? m : 0);
     const float *q = new_xyz + (size_t)t * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float r2 = radius * radius;
     const float *p = xyz + (size_t)b * N * 3;
     int *o = idx + (size_t)t * nsample;
-    int cnt = 0;
-    for (int k = 0; k < N && cnt < nsample; ++k) {
-        const float dx = qx - p[k * 3 + 0], dy = qy - p[k * 3 + 1], dz = qz - p[k * 3 + 2];
-        const float d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < r2) {
-            if (cnt == 0)
-                for (int l = 0; l < nsample; ++l) o[l] = k;
-            o[cnt++] = k;
+    int cnt = live ? 0 : nsample;
+    for (int k0 = 0; k0 < N; k0 += BQ_TILE) {
+        const int nk = min(BQ_TILE, N - k0);
+        __syncthreads();                      // the previous tile has been read
+        for (int i = threadIdx.x; i < nk; i += 256) {
+            s_x[i] = p[(size_t)(k0 + i) * 3 + 0]; s_y[i] = p[(size_t)(k0 + i) * 3 + 1]; s_z[i] = p[(size_t)(k0 + i) * 3 + 2];
         }
+        __syncthreads();
+        for (int i = 0; i < nk && cnt < nsample; ++i) {
+            const float dx = qx - s_x[i], dy = qy - s_y[i], dz = qz - s_z[i];
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < r2) {
+                if (cnt == 0)
+                    for (int l = 0; l < nsample; ++l) o[l] = k0 + i;
+                o[cnt++] = k0 + i;
+            }
+        }
+        if (__syncthreads_and(cnt >= nsample)) break;
     }
-    if (cnt == 0)
+    if (live && cnt == 0)
         for (int l = 0; l < nsample; ++l) o[l] = 0;
 }
 
@@ -131,8 +145,8 @@ extern "C" int hvpr_furthest_point_sample_f32(const float *xyz, int B, int N, in
 extern "C" int hvpr_ball_query_f32(const float *xyz, const float *new_xyz, int B, int N, int M, float radius, int nsample,
                                    int32_t *idx, hvpr_stream_t stream) {
     if (!xyz || !new_xyz || !idx || B < 1 || N < 1 || M < 1 || nsample < 1 || !(radius > 0.f)) return HVPR_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_ball_query, dim3(hvpr_cdiv((long long)B * M, 256)), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, B, N,
-                       M, radius, nsample, idx);
+    hipLaunchKernelGGL(k_ball_query, dim3(B * hvpr_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, B, N, M, radius,
+                       nsample, idx);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
