@@ -289,13 +289,18 @@ def train_step_line(device, batch=16, steps=3, warmup=2):
         pool.append(b)
     torch.cuda.reset_peak_memory_stats()
     losses = []
-    for it in range(warmup):
-        optim.train_step(model, opt, sched, dict(pool[it % 2]), it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(steps):
-        loss, _ = optim.train_step(model, opt, sched, dict(pool[it % 2]), warmup + it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
-        losses.append(loss)
+    # batches one ahead (optim.prefetching): the point-stream index kernels (FPS, ball query, three-NN) of batch i + 1 run on a side
+    # stream beside step i; warmup + steps + 1 batches are fed so that every timed step also enqueues its successor's
+    t0 = 0.0
+    for it, b in enumerate(optim.prefetching(model, (dict(pool[i % 2]) for i in range(warmup + steps + 1)))):
+        if it == warmup + steps:
+            break
+        if it == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        loss, _ = optim.train_step(model, opt, sched, b, it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        if it >= warmup:
+            losses.append(loss)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     flops_frame = 2.71e12

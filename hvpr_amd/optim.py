@@ -277,6 +277,23 @@ def model_fn_decorator():
     return model_func
 
 
+def prefetching(model, batches):
+    """Iterate `batches` (dicts) one ahead: before batch i is handed out, the point stream's index tensors of batch i + 1 are
+    enqueued on a side stream (MixAnchor_Memory.prefetch_point_indices) — so they are computed beside step i.  What a
+    maintainer wraps around the data loader in train_one_epoch (tools/train_utils/train_utils.py:25-42)."""
+    m = model.module if hasattr(model, "module") else model
+    pre = getattr(m, "prefetch_point_indices", lambda b: b)
+    it = iter(batches)
+    try:
+        nxt = pre(next(it))
+    except StopIteration:
+        return
+    for b in it:
+        cur, nxt = nxt, pre(b)
+        yield cur
+    yield nxt
+
+
 def train_step(model, optimizer, scheduler, batch_dict, it, grad_norm_clip):
     """One iteration of train_one_epoch (train_utils.py:25-42): schedule, zero_grad, forward, backward, clip, step."""
     scheduler.step(it)

@@ -127,8 +127,9 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz, new_xyz, features=None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+    def forward(self, xyz, new_xyz, features=None, idx=None):
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
         if features is None:
             return grouped_xyz
@@ -158,12 +159,17 @@ class PointnetSAModuleMSG(nn.Module):
                 spec[0] += 3
             self.mlps.append(_shared_mlp(spec))
 
-    def forward(self, xyz, features=None):
+    def indices(self, xyz):
+        """The index half of forward — it depends on the coordinates only: (FPS idx, new_xyz, [ball-query idx per scale])."""
         idx = furthest_point_sample(xyz, self.npoint)
         new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+        return idx, new_xyz, [ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+
+    def forward(self, xyz, features=None, pre=None):
+        idx, new_xyz, balls = pre if pre is not None else self.indices(xyz)
         outs = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            f = mlp(grouper(xyz, new_xyz, features))            # (B, C', npoint, nsample)
+        for grouper, mlp, bidx in zip(self.groupers, self.mlps, balls):
+            f = mlp(grouper(xyz, new_xyz, features, idx=bidx))            # (B, C', npoint, nsample)
             outs.append(f.max(dim=-1)[0])
         return new_xyz, torch.cat(outs, dim=1)
 
@@ -175,14 +181,25 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = _shared_mlp(list(mlp))
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
-        dist, idx = three_nn(unknown, known)
+    def forward(self, unknown, known, unknow_feats, known_feats, pre=None):
+        dist, idx = pre if pre is not None else three_nn(unknown, known)
         w = 1.0 / (dist + 1e-8)
         w = w / w.sum(dim=2, keepdim=True)
         f = three_interpolate(known_feats, idx, w)
         if unknow_feats is not None:
             f = torch.cat([f, unknow_feats], dim=1)
         return self.mlp(f.unsqueeze(-1)).squeeze(-1)
+
+
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
 
 
 class PointNet2MSG(nn.Module):
@@ -208,6 +225,21 @@ class PointNet2MSG(nn.Module):
             self.FP_modules.append(PointnetFPModule(mlp=[pre + skips[k]] + fp[k]))
         self.num_point_features = fp[0][-1]
 
+    @torch.no_grad()
+    def index_plan(self, points, batch_size):
+        """Every index tensor of the forward — furthest-point samples, ball-query groups, three nearest neighbours — from the
+        point coordinates alone (none of them depends on a weight): {"sa": [(fps idx, new_xyz, [ball idx])], "fp": {i: (dist,
+        idx)}}.  A training loop can compute the plan of the NEXT batch on a side stream while the current step runs
+        (detector.prefetch_point_indices); forward() takes it from batch_dict["_pn2_plan"]."""
+        xyz = points[:, 1:4].contiguous().view(batch_size, -1, 3)
+        l_xyz, sa_plan = [xyz], []
+        for sa in self.SA_modules:
+            pre = sa.indices(l_xyz[-1])
+            sa_plan.append(pre)
+            l_xyz.append(pre[1])
+        fp_plan = {i: three_nn(l_xyz[i - 1], l_xyz[i]) for i in range(-1, -(len(self.FP_modules) + 1), -1)}
+        return {"sa": sa_plan, "fp": fp_plan}
+
     def forward(self, batch_dict):
         B = batch_dict["batch_size"]
         pts = batch_dict["points"]
@@ -215,13 +247,21 @@ class PointNet2MSG(nn.Module):
         assert pts.shape[0] % B == 0, "PointNet2MSG needs the same number of points in every sample (pointnet2_backbone.py:76)"
         xyz = xyz.view(B, -1, 3)
         feats = feats.view(B, -1, feats.shape[-1]).permute(0, 2, 1).contiguous() if feats is not None else None
+        plan = batch_dict.pop("_pn2_plan", None)
+        if plan is not None:                     # computed ahead on another stream: wait for it, keep its memory alive for us
+            plan, ready = plan
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ready)
+            for t in _tensors_of(plan):
+                t.record_stream(cur)
         l_xyz, l_feat = [xyz], [feats]
-        for sa in self.SA_modules:
-            nx, nf = sa(l_xyz[-1], l_feat[-1])
+        for k, sa in enumerate(self.SA_modules):
+            nx, nf = sa(l_xyz[-1], l_feat[-1], pre=plan["sa"][k] if plan is not None else None)
             l_xyz.append(nx)
             l_feat.append(nf)
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
-            l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], l_feat[i])
+            l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], l_feat[i],
+                                               pre=plan["fp"][i] if plan is not None else None)
         pf = l_feat[0].permute(0, 2, 1).contiguous()
         batch_dict["point_features"] = pf.view(-1, pf.shape[-1])
         batch_dict["point_coords"] = torch.cat((bidx[:, None].float(), l_xyz[0].reshape(-1, 3)), dim=1)

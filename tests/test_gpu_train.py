@@ -264,3 +264,37 @@ def test_point_pillar_topk_ties_duplicates_and_order():
                 assert got[m][a] < got[m][a + 1], (m, a)
     # features outside the fp16 range of the pre-filter: every item is a candidate
     check(pillars[:20] * 1e5, points)
+
+
+def test_point_index_prefetch_gives_the_same_step():
+    """detector.prefetch_point_indices (the point stream's FPS / ball-query / three-NN indices computed ahead on a side stream)
+    changes nothing: the loss of a training step is bit-identical with and without it, the point stream's gradients equal up to the
+    order of its atomic scatter-adds."""
+    import copy
+    from hvpr_amd import detector, optim
+    cfg = hvpr_car_cfg()
+    torch.manual_seed(0)
+    model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg, training=True))
+    synthetic_weights.load_synthetic(model, seed=3, cls_bias=-4.595)
+    model = model.to(DEV).train()
+    batch = _train_batch([20, 21], np.random.default_rng(4))
+    ref = copy.deepcopy(model)
+
+    def step(m, b):
+        m.zero_grad()
+        ret, _, _ = m(b)
+        ret["loss"].mean().backward()
+        return ret["loss"].detach().clone()
+
+    l0 = step(ref, dict(batch))
+    l1 = step(model, model.prefetch_point_indices(dict(batch)))
+    torch.cuda.synchronize()
+    assert torch.equal(l0, l1)
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None
+            continue
+        if "backbone_3d" in n:                    # the point stream itself: same indices -> same gradients
+            torch.testing.assert_close(p.grad, q.grad, rtol=1e-4, atol=1e-6 * float(q.grad.abs().max()) + 1e-12)
+    got = [b for b in optim.prefetching(model, [dict(batch), dict(batch), dict(batch)])]
+    assert len(got) == 3 and all("_pn2_plan" in b for b in got)

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--cfg", choices=["car", "3class"], default="car", help="car = config 3, 3class = config 4 of SURVEY.md §8d")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: MIOpen searches its convolution solvers once per shape")
     ap.add_argument("--channels-last", action="store_true", help="backbone + head weights in channels_last memory format")
+    ap.add_argument("--no-prefetch", action="store_true", help="do not compute the next batch's point-stream indices beside the current step")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # launcher: one fresh child per GPU (tools/train.py:61-70)
         if torch.cuda.device_count() < args.gpus:
@@ -75,14 +76,23 @@ def main():
     rng = np.random.default_rng(rank)
     pool = [make_batch(rank * 1000 + 100 * i, args.batch, device, rng, len(cfg.CLASS_NAMES)) for i in range(2)]
     losses = []
-    for it in range(args.warmup):
-        optim.train_step(model, opt, sched, dict(pool[it % 2]), it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
-    distributed.barrier(device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        loss, _ = optim.train_step(model, opt, sched, dict(pool[it % 2]), args.warmup + it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
-        losses.append(loss)
+    # batches come one ahead (optim.prefetching): the point-stream index kernels of batch i + 1 run beside step i; one batch more
+    # than steps is fed so that every timed step also enqueues the index work of its successor (nothing is moved out of the
+    # timed region).  --no-prefetch: the plain loop.
+    n_all = args.warmup + args.steps
+    feed = (dict(pool[i % 2]) for i in range(n_all + 1))
+    batches = feed if args.no_prefetch else optim.prefetching(model, feed)
+    t0 = 0.0
+    for it, b in enumerate(batches):
+        if it == n_all:
+            break
+        if it == args.warmup:
+            distributed.barrier(device)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        loss, _ = optim.train_step(model, opt, sched, b, it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        if it >= args.warmup:
+            losses.append(loss)
     distributed.barrier(device)
     torch.cuda.synchronize()
     dt = distributed.max_over_ranks(time.perf_counter() - t0, device)
