@@ -234,7 +234,11 @@ class BaseBEVBackbone_Scale(nn.Module):
                     k += 1
                 conv, bn = mods[k], mods[k + 1]
                 last = k + 3 >= len(mods)
-                t = ct.bn_relu(ct.conv(t, conv.weight, conv.stride[0]), bn, gate=gate if last else None, resid=resid if last else None)
+                if last and gate is not None and resid is t and conv.stride[0] == 1 and conv.kernel_size[0] == 3 \
+                        and os.environ.get("HVPR_TRAIN_SFM", "fused") == "fused":
+                    t = ct.sfm_step(t, conv.weight, bn, gate)            # the SFM step as one autograd node
+                else:
+                    t = ct.bn_relu(ct.conv(t, conv.weight, conv.stride[0]), bn, gate=gate if last else None, resid=resid if last else None)
                 k += 3
             return t
 

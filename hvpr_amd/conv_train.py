@@ -183,6 +183,86 @@ class _BNReLU(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, dgate, (dy if gate is not None else None)
 
 
+_ones_cache = {}
+
+
+def _ones(shape, device):
+    key = (tuple(shape), device)
+    if key not in _ones_cache:
+        _ones_cache[key] = torch.ones(shape, dtype=torch.float32, device=device)
+    return _ones_cache[key]
+
+
+class _SfmStep(torch.autograd.Function):
+    """x_att' = gate * relu(BN_train(conv3x3(x_att))) + x_att (base_bev_backbone.py:250-255) as ONE autograd node: the backward adds
+    the residual path's gradient in the epilogue of the data-gradient convolution (y = 1 * conv_adjoint(dz) + dy) instead of
+    leaving a 3-tensor element-wise add of full activations to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, eps, gate):
+        x = x.contiguous()
+        z = conv_fwd_raw(x, weight, 1)
+        C = z.shape[-1]
+        P = z.numel() // C
+        dev = z.device
+        mean, var, invstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
+        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), dev)
+        check(lib().hvpr_bn_stats_nhwc_f32(z.data_ptr(), P, C, float(eps), mean.data_ptr(), var.data_ptr(), invstd.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_stats_nhwc_f32")
+        scale = (gamma.detach() * invstd).contiguous()
+        shift = (beta.detach() - mean * scale).contiguous()
+        gate = gate.detach().contiguous()
+        assert gate.numel() == P
+        y = torch.empty_like(z)
+        check(lib().hvpr_bn_relu_fwd_nhwc_f32(z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(), 1, gate.data_ptr(), x.data_ptr(),
+                                              y.data_ptr(), kernels._stream()), "hvpr_bn_relu_fwd_nhwc_f32")
+        ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gate)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, weight, z, scale, shift, mean, invstd, gate = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = z.shape[-1]
+        P = z.numel() // C
+        dz = torch.empty_like(z)
+        dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
+        dgate = torch.empty_like(gate)
+        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), z.device)
+        check(lib().hvpr_bn_relu_bwd_nhwc_f32(kernels._ptr(dy, torch.float32, "dy"), z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(),
+                                              mean.data_ptr(), invstd.data_ptr(), 1, gate.data_ptr(), dgate.data_ptr(), dz.data_ptr(),
+                                              dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()),
+              "hvpr_bn_relu_bwd_nhwc_f32")
+        cout, cin = weight.shape[0], weight.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if kernels.conv_algo() == "winograd" and cin % 4 == 0:
+                pc = kernels.pack_conv_wino(weight, relu=False, px_groups=_wino_groups(), adjoint=True)
+                dx = kernels.conv2d_wino_nhwc(dz, pc, gate=_ones(tuple(dz.shape[:3]), dz.device), resid=dy)    # + the residual path
+            else:
+                dx = conv_fwd_raw(dz, weight, 1, adjoint=True) + dy
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, dz, 9, 1, cout, cin)
+        return dx, dw, dgamma, dbeta, None, dgate
+
+
+def sfm_step(x, weight, bn, gate):
+    """gate * relu(bn(conv3x3(x))) + x with train-mode `bn` (running statistics updated like nn.BatchNorm2d), one autograd node."""
+    y, mean, var = _SfmStep.apply(x, weight, bn.weight, bn.bias, bn.eps, gate)
+    _update_running(bn, mean, var, x.numel() // x.shape[-1])
+    return y
+
+
+def _update_running(bn, mean, var, n):
+    if bn.track_running_stats:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
+
+
 def conv(x, weight, stride=1):
     """3x3 (pad 1) or 1x1 convolution without bias on NHWC activations, differentiable in x and weight."""
     return _Conv.apply(x, weight, int(stride))
