@@ -76,7 +76,9 @@ SIGNATURES = {
     "hvpr_conv2d_wino_wgrad_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _Z, _P]),
     "hvpr_conv2d_wino_packed_floats": (_Z, [_I, _I]),
     "hvpr_conv2d_wino_pack_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
-    "hvpr_conv2d_wino_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "hvpr_conv2d_wino_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
+    "hvpr_conv2d_wino_stats_rows": (_I, [_I, _I, _I]),
+    "hvpr_bn_finalize_partials_f32": (_I, [_P, _I, _I, _c.c_longlong, _F, _P, _P, _P, _P]),
     "hvpr_conv2d_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
 }
 

@@ -238,7 +238,8 @@ class BaseBEVBackbone_Scale(nn.Module):
                         and os.environ.get("HVPR_TRAIN_SFM", "fused") == "fused":
                     t = ct.sfm_step(t, conv.weight, bn, gate)            # the SFM step as one autograd node
                 else:
-                    t = ct.bn_relu(ct.conv(t, conv.weight, conv.stride[0]), bn, gate=gate if last else None, resid=resid if last else None)
+                    z, partials = ct.conv(t, conv.weight, conv.stride[0], stats=True)
+                    t = ct.bn_relu(z, bn, gate=gate if last else None, resid=resid if last else None, partials=partials)
                 k += 3
             return t
 

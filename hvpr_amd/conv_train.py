@@ -47,16 +47,43 @@ def _wino_groups():
     return int(os.environ.get("HVPR_TRAIN_WINO_GROUPS", "1"))
 
 
-def conv_fwd_raw(x, weight, stride=1, adjoint=False):
+def bn_statistics(z, eps, partials=None):
+    """mean, biased variance, 1/sqrt(var + eps) per channel of z (N,H,W,C): from the per-tile sums the producing Winograd
+    convolution left behind (conv(..., stats=True)) when it did, else by a pass over z."""
+    C = z.shape[-1]
+    P = z.numel() // C
+    dev = z.device
+    mean, var, invstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
+    if partials is not None and partials.numel() > 0:
+        assert partials.shape[-1] == C and partials.shape[1] == 2
+        check(lib().hvpr_bn_finalize_partials_f32(partials.data_ptr(), partials.shape[0], C, P, float(eps), mean.data_ptr(), var.data_ptr(),
+                                                  invstd.data_ptr(), kernels._stream()), "hvpr_bn_finalize_partials_f32")
+    else:
+        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), dev)
+        check(lib().hvpr_bn_stats_nhwc_f32(kernels._ptr(z, torch.float32, "z"), P, C, float(eps), mean.data_ptr(), var.data_ptr(),
+                                           invstd.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_stats_nhwc_f32")
+    return mean, var, invstd
+
+
+def conv_fwd_raw(x, weight, stride=1, adjoint=False, stats=False):
     """x (N,H,W,Cin) -> conv(x, weight) (N,OH,OW,Cout), no bias / activation.  weight (Cout,Cin,k,k), k in {1,3}, pad (k-1)/2.
+    stats: return (z, partials) — partials = the batch statistics' per-tile sums when the Winograd kernel produced them, else None.
     adjoint: weight is the (Cin', Cout', 3, 3) filter of the layer whose data gradient is wanted and x its output gradient.
     Stride-1 3x3: the Winograd kernel (packed on the device per call) unless HVPR_CONV_ALGO=direct."""
     if weight.shape[2] == 3 and stride == 1 and kernels.conv_algo() == "winograd" and weight.shape[1 if adjoint else 0] % 4 == 0:
-        return kernels.conv2d_wino_nhwc(x, kernels.pack_conv_wino(weight, relu=False, px_groups=_wino_groups(), adjoint=adjoint))
+        g = _wino_groups()
+        partials = None
+        if stats and g == 1 and os.environ.get("HVPR_TRAIN_BN_STATS", "fused") == "fused":
+            N, H, W, _ = x.shape
+            cout = weight.shape[1 if adjoint else 0]
+            partials = torch.empty((lib().hvpr_conv2d_wino_stats_rows(N, H, W), 2, cout), dtype=torch.float32, device=x.device)
+        z = kernels.conv2d_wino_nhwc(x, kernels.pack_conv_wino(weight, relu=False, px_groups=g, adjoint=adjoint), bn_partials=partials)
+        return (z, partials) if stats else z
     if adjoint:
         weight = weight.detach().permute(1, 0, 2, 3).flip(2, 3)                 # (Cin, Cout, k, k): the adjoint kernel
     pc = kernels.pack_conv(weight, None, None, stride=stride, relu=False, tile_cfg=_tile_cfg(weight.shape[0]))
-    return kernels.conv2d_nhwc(x, pc)
+    z = kernels.conv2d_nhwc(x, pc)
+    return (z, None) if stats else z
 
 
 def conv_wgrad(x, dz, taps, stride, cout, cin):
@@ -81,14 +108,20 @@ def conv_wgrad(x, dz, taps, stride, cout, cin):
 
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride):
+    def forward(ctx, x, weight, stride, stats=False):
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.stride = stride
-        return conv_fwd_raw(x, weight, stride)
+        if not stats:
+            return conv_fwd_raw(x, weight, stride)
+        z, partials = conv_fwd_raw(x, weight, stride, stats=True)
+        if partials is None:
+            partials = z.new_empty((0, 2, z.shape[-1]))
+        ctx.mark_non_differentiable(partials)
+        return z, partials
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, _dp=None):
         x, weight = ctx.saved_tensors
         dz = dz.contiguous()
         cout, cin, k, _ = weight.shape
@@ -105,7 +138,7 @@ class _Conv(torch.autograd.Function):
                 dx = conv_fwd_raw(up, weight, 1, adjoint=True)
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(x, dz, k * k, s, cout, cin)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class _Deconv(torch.autograd.Function):
@@ -143,15 +176,12 @@ class _BNReLU(torch.autograd.Function):
     x_att = attention(sfm(x_att), y) + x_att (base_bev_backbone.py:250-255) in the same two kernels."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, eps, relu, gate, resid):
+    def forward(ctx, z, gamma, beta, eps, relu, gate, resid, partials=None):
         z = z.contiguous()
         C = z.shape[-1]
         P = z.numel() // C
         dev = z.device
-        mean, var, invstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
-        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), dev)
-        check(lib().hvpr_bn_stats_nhwc_f32(kernels._ptr(z, torch.float32, "z"), P, C, float(eps), mean.data_ptr(), var.data_ptr(),
-                                           invstd.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_stats_nhwc_f32")
+        mean, var, invstd = bn_statistics(z, eps, partials)
         scale = (gamma.detach() * invstd).contiguous()
         shift = (beta.detach() - mean * scale).contiguous()
         y = torch.empty_like(z)
@@ -180,7 +210,7 @@ class _BNReLU(torch.autograd.Function):
                                               mean.data_ptr(), invstd.data_ptr(), 1 if ctx.relu else 0, kernels._ptr(gate), kernels._ptr(dgate),
                                               dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
                                               kernels._stream()), "hvpr_bn_relu_bwd_nhwc_f32")
-        return dz, dgamma, dbeta, None, None, dgate, (dy if gate is not None else None)
+        return dz, dgamma, dbeta, None, None, dgate, (dy if gate is not None else None), None
 
 
 _ones_cache = {}
@@ -201,14 +231,11 @@ class _SfmStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, eps, gate):
         x = x.contiguous()
-        z = conv_fwd_raw(x, weight, 1)
+        z, partials = conv_fwd_raw(x, weight, 1, stats=True)
         C = z.shape[-1]
         P = z.numel() // C
         dev = z.device
-        mean, var, invstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
-        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), dev)
-        check(lib().hvpr_bn_stats_nhwc_f32(z.data_ptr(), P, C, float(eps), mean.data_ptr(), var.data_ptr(), invstd.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_stats_nhwc_f32")
+        mean, var, invstd = bn_statistics(z, eps, partials)
         scale = (gamma.detach() * invstd).contiguous()
         shift = (beta.detach() - mean * scale).contiguous()
         gate = gate.detach().contiguous()
@@ -263,19 +290,21 @@ def _update_running(bn, mean, var, n):
             bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
 
 
-def conv(x, weight, stride=1):
-    """3x3 (pad 1) or 1x1 convolution without bias on NHWC activations, differentiable in x and weight."""
-    return _Conv.apply(x, weight, int(stride))
+def conv(x, weight, stride=1, stats=False):
+    """3x3 (pad 1) or 1x1 convolution without bias on NHWC activations, differentiable in x and weight.  stats: the output goes
+    straight into bn_relu — returns (z, partials): the per-tile sums of the batch statistics the Winograd kernel left for it (an
+    empty tensor when it did not), to be handed to bn_relu(..., partials=)."""
+    return _Conv.apply(x, weight, int(stride), bool(stats))
 
 
 def deconv(x, weight):
     return _Deconv.apply(x, weight)
 
 
-def bn_relu(z, bn, relu=True, gate=None, resid=None):
+def bn_relu(z, bn, relu=True, gate=None, resid=None, partials=None):
     """Train-mode nn.BatchNorm2d `bn` (its weight / bias / eps / momentum / running buffers) + optional ReLU on NHWC `z`; with
     gate (N,H,W,1) and resid (N,H,W,C): gate * relu(bn(z)) + resid, differentiable in all of them."""
-    y, mean, var = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu, gate, resid)
+    y, mean, var = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu, gate, resid, partials)
     if bn.track_running_stats:
         with torch.no_grad():
             n = z.numel() // z.shape[-1]

@@ -399,6 +399,16 @@ extern "C" int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float 
     return HVPR_OK;
 }
 
+extern "C" int hvpr_bn_finalize_partials_f32(const float *partials, int rows, int C, long long count, float eps, float *mean, float *var,
+                                             float *invstd, hvpr_stream_t stream) {
+    if (!partials || !mean || !var || !invstd || rows < 1 || count < 1) return HVPR_ERR_INVALID_ARG;
+    if (C < 4 || C > 1024) return HVPR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, rows, C, (double)count, eps, 0,
+                       mean, var, invstd);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
 extern "C" int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu,
                                          const float *gate, const float *resid, float *y, hvpr_stream_t stream) {
     if (!z || !scale || !shift || !y || P < 1 || ((gate == nullptr) != (resid == nullptr))) return HVPR_ERR_INVALID_ARG;

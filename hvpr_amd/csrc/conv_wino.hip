@@ -57,6 +57,7 @@ struct WinoArgs {
     int out_cstride, out_coff, resid_cstride;
     int relu;
     int tiles_x, tiles_y, n_ct;
+    float *stats;         // optional [pixel tiles][2][cout]: per-tile sum / sum of squares of the raw output (train-mode BatchNorm)
 };
 
 __device__ __forceinline__ float4 f4_fma(float s, float4 a, float4 b) {      // s * a + b, s = +-1: an exact add / subtract
@@ -219,6 +220,9 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
     const float sg = p ? -1.f : 1.f;
     // one pass over both 32-channel halves when the exchange fits the two filter stages (NG = 1: 64 KB), else one half per pass
     constexpr int NPASS = NG == 1 ? 1 : 2, NBP = 2 / NPASS;
+    float4 ykeep[2][4];                 // this lane's outputs (statistics pass below); zero where the pixel / channel is not live
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ykeep[i >> 2][i & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         __syncthreads();               // the U stages (first pass) / the previous pass's exchange reads are done
@@ -254,8 +258,42 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
                         y.x = fmaf(gate, y.x, r.x); y.y = fmaf(gate, y.y, r.y); y.z = fmaf(gate, y.z, r.z); y.w = fmaf(gate, y.w, r.w);
                     }
                     *(float4 *)(a.out + pix * a.out_cstride + a.out_coff + col) = y;
+                    if (NG == 1) ykeep[nl][g] = y;
                 }
             }
+        }
+    }
+    if (NG == 1 && a.stats) {
+        // Batch statistics of the layer's BatchNorm, fused: per-channel sum and sum of squares over this tile's live pixels go
+        // to row (pixel tile) of a.stats (finished in double by hvpr_bn_finalize_partials_f32) — the separate pass over the
+        // written tensor (601 MB per level-0 layer at batch 16) disappears.  Through LDS: lanes park their 8 float4, thread
+        // (channel, wave) adds the 32 blocks of that wave's pixel position, then the four positions.
+        __syncthreads();               // the exchange reads are done
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s_w[((wid * 2 + nl) * 4 + g) * 64 + lane] = ykeep[nl][g];
+        __syncthreads();
+        {
+            const int c = tid & 63, part = tid >> 6;
+            const float *base = (const float *)(s_w + ((part * 2 + (c >> 5)) * 4 + ((c >> 3) & 3)) * 64 + ((c >> 2) & 1) * 32) + (c & 3);
+            float sm = 0.f, sq = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) {
+                const float v = base[((i + c) & 31) * 4];       // rotated start: spreads the lanes over the banks
+                sm += v; sq = fmaf(v, v, sq);
+            }
+            float *s_part = (float *)(s_w + 2048);               // [4 waves][2][64]
+            s_part[(part * 2 + 0) * 64 + c] = sm;
+            s_part[(part * 2 + 1) * 64 + c] = sq;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float *s_part = (const float *)(s_w + 2048);
+            const int c = tid & 63, k = tid >> 6;
+            const float v = (s_part[(0 * 2 + k) * 64 + c] + s_part[(1 * 2 + k) * 64 + c]) + (s_part[(2 * 2 + k) * 64 + c] + s_part[(3 * 2 + k) * 64 + c]);
+            const int pt_lin = (n * a.tiles_y + ty) * a.tiles_x + tx;
+            if (co0 + c < a.cout) a.stats[((size_t)pt_lin * 2 + k) * a.cout + co0 + c] = v;
         }
     }
     __syncthreads();   // the next tile refills the LDS stages
@@ -324,6 +362,11 @@ int launch(WinoArgs a, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int hvpr_conv2d_wino_stats_rows(int N, int H, int W) {     // rows of bn_partials: the 8 x 16 pixel tiles
+    if (N < 1 || H < 1 || W < 1) return 0;
+    return N * ((H + 7) / 8) * ((W + TW - 1) / TW);
+}
+
 extern "C" size_t hvpr_conv2d_wino_packed_floats(int cin, int cout) {
     if (cin < 1 || cout < 1) return 0;
     return (size_t)((cout + BN - 1) / BN * BN) * (size_t)cin * 16;
@@ -343,7 +386,7 @@ extern "C" int hvpr_conv2d_wino_pack_f32(const float *weight, const float *scale
 
 extern "C" int hvpr_conv2d_wino_nhwc_f32(const float *in, int N, int H, int W, int Cin, const float *w_packed, const float *bias,
                                          int cout, int relu, const float *gate, const float *resid, int resid_cstride, float *out,
-                                         int out_cstride, int out_coff, int px_groups, hvpr_stream_t stream) {
+                                         int out_cstride, int out_coff, int px_groups, float *bn_partials, hvpr_stream_t stream) {
     if (!in || !w_packed || !bias || !out || N < 1 || H < 1 || W < 1 || Cin < 8 || cout < 1) return HVPR_ERR_INVALID_ARG;
     if ((gate == nullptr) != (resid == nullptr)) return HVPR_ERR_INVALID_ARG;
     if (Cin % KC != 0) return HVPR_ERR_UNSUPPORTED;
@@ -355,6 +398,8 @@ extern "C" int hvpr_conv2d_wino_nhwc_f32(const float *in, int N, int H, int W, i
     a.cout = cout; a.cout_pad = (cout + BN - 1) / BN * BN;
     a.out_cstride = out_cstride; a.out_coff = out_coff; a.resid_cstride = resid_cstride;
     a.relu = relu;
+    a.stats = bn_partials;
+    if (bn_partials && (px_groups != 1 || relu || gate)) return HVPR_ERR_UNSUPPORTED;      // statistics of the RAW output, 8 x 16 tiles
     int rc;
     if (px_groups == 1) rc = launch<1>(a, (hipStream_t)stream);
     else if (px_groups == 2) rc = launch<2>(a, (hipStream_t)stream);

@@ -385,6 +385,9 @@ def pack_conv(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=0):
     return PackedConv(wp.contiguous(), b, taps, stride, cout, cout_pad, 1, cin, relu, tile_cfg)
 
 
+_zero_bias = {}
+
+
 class PackedConvWino:
     """Stride-1 3x3 conv weights in the Winograd kernel's stage image (hvpr_conv2d_wino_pack_f32) with BatchNorm folded."""
 
@@ -408,14 +411,20 @@ def pack_conv_wino(weight, scale=None, shift=None, relu=True, px_groups=1, adjoi
     sc = None if scale is None else scale.detach().float().contiguous()
     check(lib().hvpr_conv2d_wino_pack_f32(_ptr(w, torch.float32, "conv weight"), _ptr(sc, torch.float32, "scale"), cout, cin,
                                           1 if adjoint else 0, wp.data_ptr(), _stream()), "hvpr_conv2d_wino_pack_f32")
-    b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
-    if shift is not None:
+    if shift is None:                     # raw convolutions (training: packed every call) share one zero bias per size
+        key = (cout_pad, w.device)
+        if key not in _zero_bias:
+            _zero_bias[key] = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
+        b = _zero_bias[key]
+    else:
+        b = torch.zeros((cout_pad,), dtype=torch.float32, device=w.device)
         b[:cout] = shift.detach().float()
     return PackedConvWino(wp, b, cout, cout_pad, cin, relu, px_groups)
 
 
-def conv2d_wino_nhwc(x, pc, out=None, out_coff=0, gate=None, resid=None):
-    """x (N,H,W,Cin) contiguous f32 -> (N,H,W,C): 3x3 / stride 1 / pad 1 by Winograd F(2x2,3x3); arguments as conv2d_nhwc."""
+def conv2d_wino_nhwc(x, pc, out=None, out_coff=0, gate=None, resid=None, bn_partials=None):
+    """x (N,H,W,Cin) contiguous f32 -> (N,H,W,C): 3x3 / stride 1 / pad 1 by Winograd F(2x2,3x3); arguments as conv2d_nhwc.
+    bn_partials: (hvpr_conv2d_wino_stats_rows(N,H,W), 2, C) f32 to receive the per-tile sums of the raw output (training)."""
     N, H, W, cin = x.shape
     assert cin == pc.cin
     if out is None:
@@ -424,8 +433,8 @@ def conv2d_wino_nhwc(x, pc, out=None, out_coff=0, gate=None, resid=None):
     check(lib().hvpr_conv2d_wino_nhwc_f32(_ptr(x, torch.float32, "conv input"), N, H, W, cin, pc.w.data_ptr(), pc.bias.data_ptr(),
                                           pc.cout, 1 if pc.relu else 0, _ptr(gate, torch.float32, "gate"),
                                           _ptr(resid, torch.float32, "resid"), 0 if resid is None else resid.shape[-1],
-                                          out.data_ptr(), out.shape[-1], int(out_coff), pc.px_groups, _stream()),
-          "hvpr_conv2d_wino_nhwc_f32")
+                                          out.data_ptr(), out.shape[-1], int(out_coff), pc.px_groups,
+                                          _ptr(bn_partials, torch.float32, "bn_partials"), _stream()), "hvpr_conv2d_wino_nhwc_f32")
     return out
 
 

@@ -391,7 +391,14 @@ int hvpr_conv2d_wino_pack_f32(const float *weight, const float *scale, int cout,
                               hvpr_stream_t stream);
 int hvpr_conv2d_wino_nhwc_f32(const float *in, int N, int H, int W, int Cin, const float *w_packed, const float *bias, int cout,
                               int relu, const float *gate, const float *resid, int resid_cstride, float *out, int out_cstride,
-                              int out_coff, int px_groups, hvpr_stream_t stream);
+                              int out_coff, int px_groups, float *bn_partials, hvpr_stream_t stream);
+/* bn_partials (optional, training): [hvpr_conv2d_wino_stats_rows(N, H, W)][2][cout] f32, overwritten with the per-pixel-tile sum
+ * and sum of squares of the raw output (px_groups == 1, relu == 0, no gate) — the batch statistics of the layer's BatchNorm without
+ * a pass over the written tensor; hvpr_bn_finalize_partials_f32 turns them into mean / biased variance / 1/sqrt(var + eps)
+ * (count = N * H * W; sums finished in double, fixed order: deterministic). */
+int hvpr_conv2d_wino_stats_rows(int N, int H, int W);
+int hvpr_bn_finalize_partials_f32(const float *partials, int rows, int C, long long count, float eps, float *mean, float *var,
+                                  float *invstd, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a5 optional precision modes: 3x3 convolutions on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation)

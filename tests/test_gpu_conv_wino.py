@@ -113,3 +113,22 @@ def test_wino_full_size_properties():
     lhs = float((y2.double() * y1.double()).sum())
     rhs = float((dw.double() * w.double()).sum())
     assert abs(lhs - rhs) < 1e-4 * abs(lhs), (lhs, rhs)
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout", [(2, 13, 21, 24, 68), (1, 62, 74, 64, 128), (3, 31, 37, 128, 192)])
+def test_wino_fused_bn_statistics(N, H, W, cin, cout):
+    """The per-tile sums the Winograd kernel leaves behind (bn_partials) give the same batch statistics as a pass over the
+    written output (hvpr_bn_stats_nhwc_f32) and as float64 — ragged images, channel counts that are not a multiple of 64."""
+    from hvpr_amd import conv_train
+    g = torch.Generator().manual_seed(H + cout)
+    x = torch.randn(N, H, W, cin, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(DEV)
+    z, partials = conv_train.conv_fwd_raw(x, w, 1, stats=True)
+    assert partials is not None and partials.shape[1:] == (2, cout)
+    mean, var, invstd = conv_train.bn_statistics(z, 1e-3, partials)
+    mean2, var2, invstd2 = conv_train.bn_statistics(z, 1e-3)                 # the separate pass over z
+    zd = z.double().reshape(-1, cout)
+    np.testing.assert_allclose(mean.cpu().numpy(), zd.mean(0).cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), zd.var(0, unbiased=False).cpu().numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(mean.cpu().numpy(), mean2.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(invstd.cpu().numpy(), invstd2.cpu().numpy(), rtol=2e-5)
