@@ -66,7 +66,7 @@ __device__ __forceinline__ float4 f4_fma(float s, float4 a, float4 b) {      // 
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-template <int NG>
+template <int NG, bool STATS>
 __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wino(WinoArgs a) {
     constexpr int NT = 256 * NG;
     constexpr int TH = 8 * NG, PH = TH + 2;
@@ -258,12 +258,12 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
                         y.x = fmaf(gate, y.x, r.x); y.y = fmaf(gate, y.y, r.y); y.z = fmaf(gate, y.z, r.z); y.w = fmaf(gate, y.w, r.w);
                     }
                     *(float4 *)(a.out + pix * a.out_cstride + a.out_coff + col) = y;
-                    if (NG == 1) ykeep[nl][g] = y;
+                    if (STATS) ykeep[nl][g] = y;
                 }
             }
         }
     }
-    if (NG == 1 && a.stats) {
+    if (STATS) {
         // Batch statistics of the layer's BatchNorm, fused: per-channel sum and sum of squares over this tile's live pixels go
         // to row (pixel tile) of a.stats (finished in double by hvpr_bn_finalize_partials_f32) — the separate pass over the
         // written tensor (601 MB per level-0 layer at batch 16) disappears.  Through LDS: lanes park their 8 float4, thread
@@ -334,7 +334,7 @@ __global__ void k_wino_pack(const float *__restrict__ w, const float *__restrict
     }
 }
 
-template <int NG>
+template <int NG, bool STATS>
 int launch(WinoArgs a, hipStream_t s) {
     constexpr int NT = 256 * NG, TH = 8 * NG, PH = TH + 2;
     constexpr int PPAD = (PH * ROWP + 63) / 64 * 64;
@@ -344,19 +344,19 @@ int launch(WinoArgs a, hipStream_t s) {
     a.tiles_y = (a.H + TH - 1) / TH;
     a.n_ct = a.cout_pad / BN;
     static unsigned long long lds_set = 0ull;
-    if (hvpr_ensure_dyn_lds((const void *)k_wino<NG>, lds, &lds_set) != 0) return -1;
+    if (hvpr_ensure_dyn_lds((const void *)k_wino<NG, STATS>, lds, &lds_set) != 0) return -1;
     const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wino<NG>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wino<NG, STATS>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         resident = per_cu * cus;
     }
     long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
     if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
-    hipLaunchKernelGGL((k_wino<NG>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((k_wino<NG, STATS>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
     return 0;
 }
 
@@ -401,8 +401,8 @@ extern "C" int hvpr_conv2d_wino_nhwc_f32(const float *in, int N, int H, int W, i
     a.stats = bn_partials;
     if (bn_partials && (px_groups != 1 || relu || gate)) return HVPR_ERR_UNSUPPORTED;      // statistics of the RAW output, 8 x 16 tiles
     int rc;
-    if (px_groups == 1) rc = launch<1>(a, (hipStream_t)stream);
-    else if (px_groups == 2) rc = launch<2>(a, (hipStream_t)stream);
+    if (px_groups == 1) rc = bn_partials ? launch<1, true>(a, (hipStream_t)stream) : launch<1, false>(a, (hipStream_t)stream);
+    else if (px_groups == 2) rc = launch<2, false>(a, (hipStream_t)stream);
     else return HVPR_ERR_INVALID_ARG;
     if (rc != 0) return HVPR_ERR_LAUNCH;
     HVPR_CHECK_LAUNCH();
