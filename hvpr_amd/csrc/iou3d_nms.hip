@@ -290,6 +290,158 @@ __global__ void __launch_bounds__(64) k_nms_mask(const Box *__restrict__ prepare
     if (row < n) mask[(size_t)row * nb + cb] = s_bits[t];
 }
 
+// ---- NMS mask in two launches (n <= 4096): the rejects per tile, then the polygon clips over ONE balanced list --------------
+// k_nms_mask above clips a tile's surviving pairs inside the tile's wave: tiles in dense regions of the scene hold thousands of
+// pairs, tiles elsewhere none, and the launch lasts as long as its heaviest tiles (97 us for 4096 candidates of which the rejects
+// leave a few 10^4 pairs).  Here the tile waves only run the two exact rejects and write their survivors to a per-tile segment of
+// a global list (no atomics); k_nms_clip then walks the concatenation of all segments with every lane of the chip holding the
+// same number of pairs, and sets the mask bits with atomicOr (order-independent: the mask, and with it the survivors, are
+// identical to the one-launch form).
+constexpr int kTileCap = 64 * 64;                     // pairs a tile can hold
+__host__ __device__ inline int tri_index(int rb, int cb, int nb) { return rb * nb - rb * (rb - 1) / 2 + (cb - rb); }
+
+__global__ void __launch_bounds__(64) k_nms_pairs(const Box *__restrict__ prepared, const int *__restrict__ n_device, int n_max,
+                                                  unsigned long long *__restrict__ mask, int nb, unsigned short *__restrict__ plist,
+                                                  int *__restrict__ pcount) {
+    const int n = n_device ? min(*n_device, n_max) : n_max;
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    const int t = threadIdx.x;
+    const int row = rb * 64 + t;
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    if (row < n) mask[(size_t)row * nb + cb] = 0ull;      // k_nms_clip ORs the suppression bits in
+    if (cb < rb) return;
+    __shared__ __attribute__((aligned(16))) BoxLite s_lrow[64], s_lcol[64];
+    __shared__ __attribute__((aligned(16))) float4 s_circ[64];   // column boxes: centre and circum-radius
+    __shared__ unsigned short s_pairs[64 * 32];
+    const int col = cb * 64 + t;
+    if (row < n) s_lrow[t] = lite_of(prepared[row]);
+    if (col < n) {
+        s_lcol[t] = lite_of(prepared[col]);
+        s_circ[t] = make_float4(s_lcol[t].x, s_lcol[t].y, s_lcol[t].rad, 0.f);
+    }
+    __syncthreads();
+    const int ncol = min(64, n - cb * 64);
+    const int tile = tri_index(rb, cb, nb);
+    unsigned short *out = plist + (size_t)tile * kTileCap;
+    int n_out = 0;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int c_lo = 32 * half;
+        unsigned near = 0u;
+        if (row < n) {   // reject no. 1 (the circum-circle test of far_apart())
+            const float mx = s_lrow[t].x, my = s_lrow[t].y, mr = s_lrow[t].rad + 0.05f;
+            const int i0 = (rb == cb) ? t + 1 : 0;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) {
+                const float4 c = s_circ[c_lo + i];
+                const float ddx = mx - c.x, ddy = my - c.y, lim = mr + c.z;
+                const bool close = !(ddx * ddx + ddy * ddy > lim * lim * 1.0001f);
+                if (close && c_lo + i >= i0 && c_lo + i < ncol) near |= 1u << i;
+            }
+        }
+        const int cnt = __popc(near);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (t >= o) incl += u;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int pos = incl - cnt;
+        while (near) {
+            const int i = __ffs((int)near) - 1;
+            near &= near - 1;
+            s_pairs[pos++] = (unsigned short)((t << 6) | (c_lo + i));
+        }
+        __syncthreads();
+        // reject no. 2 (separating axes) on the packed pair list; survivors go to the tile's global segment
+        for (int k0 = 0; k0 < total; k0 += 64) {
+            const int k = k0 + t;
+            const int pr = k < total ? s_pairs[k] : 0;
+            const bool keep = k < total && !axes_separate(s_lrow[pr >> 6], s_lcol[pr & 63]);
+            const unsigned long long m = __ballot(keep);
+            if (keep) out[n_out + __popcll(m & ((1ull << t) - 1ull))] = (unsigned short)pr;
+            n_out += __popcll(m);
+        }
+        __syncthreads();
+    }
+    if (t == 0) pcount[tile] = n_out;
+}
+
+// exclusive prefix of the live tiles' pair counts, in (rb, cb >= rb) order, + the tile of every position: one workgroup
+constexpr int kMaxTiles = 2080;                       // nb <= 64
+struct ClipIndex { int pre[kMaxTiles + 1]; unsigned char rb[kMaxTiles], cb[kMaxTiles]; };
+
+__global__ void __launch_bounds__(1024) k_nms_scan(const int *__restrict__ n_device, int n_max, int nb, const int *__restrict__ pcount,
+                                                   ClipIndex *__restrict__ ci) {
+    __shared__ int s_wave[16];
+    const int n = n_device ? min(*n_device, n_max) : n_max;
+    const int nba = (n + 63) / 64, n_tiles = nba * (nba + 1) / 2;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    // thread t owns live tiles 3t .. 3t + 2  (3 * 1024 >= 2080)
+    int rb = 0, rem = 3 * t;
+    while (rb < nba && rem >= nba - rb) { rem -= nba - rb; ++rb; }
+    int cb = rb + rem;
+    int c[3], trb[3], tcb[3], run = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const bool live = 3 * t + i < n_tiles;
+        trb[i] = rb; tcb[i] = cb;
+        c[i] = live ? pcount[tri_index(rb, cb, nb)] : 0;
+        run += c[i];
+        if (live && ++cb == nba) { ++rb; cb = rb; }
+    }
+    int incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wid] = incl;
+    __syncthreads();
+    int base = incl - run;
+    for (int w = 0; w < wid; ++w) base += s_wave[w];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (3 * t + i < n_tiles) {
+            ci->pre[3 * t + i] = base;
+            ci->rb[3 * t + i] = (unsigned char)trb[i]; ci->cb[3 * t + i] = (unsigned char)tcb[i];
+        }
+        base += c[i];
+    }
+    if (t == 1023) ci->pre[n_tiles] = base;
+}
+
+constexpr int kClipThreads = 128, kClipBlocks = 768;  // three workgroups per CU (a PolyStore per wave, 49 KB of LDS each)
+__global__ void __launch_bounds__(kClipThreads) k_nms_clip(const Box *__restrict__ prepared, const int *__restrict__ n_device, int n_max,
+                                                           float thresh, unsigned long long *__restrict__ mask, int nb,
+                                                           const unsigned short *__restrict__ plist, const ClipIndex *__restrict__ ci) {
+    __shared__ int s_pre[kMaxTiles + 1];
+    __shared__ unsigned char s_rb[kMaxTiles], s_cb[kMaxTiles];
+    __shared__ PolyStore ps[kClipThreads / 64];
+    const int n = n_device ? min(*n_device, n_max) : n_max;
+    const int nba = (n + 63) / 64, n_tiles = nba * (nba + 1) / 2;
+    const int t = threadIdx.x;
+    for (int i = t; i <= n_tiles; i += kClipThreads) s_pre[i] = ci->pre[i];
+    for (int i = t; i < n_tiles; i += kClipThreads) { s_rb[i] = ci->rb[i]; s_cb[i] = ci->cb[i]; }
+    __syncthreads();
+    const int total = s_pre[n_tiles];
+    PolyStore &my = ps[t >> 6];
+    for (long long gidx = (long long)blockIdx.x * kClipThreads + t; gidx < total; gidx += (long long)gridDim.x * kClipThreads) {
+        // the tile holding pair gidx: largest i with s_pre[i] <= gidx
+        int lo = 0, hi = n_tiles;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= (int)gidx) lo = mid; else hi = mid;
+        }
+        const int rb = s_rb[lo], cb = s_cb[lo];
+        const int pr = plist[(size_t)tri_index(rb, cb, nb) * kTileCap + ((int)gidx - s_pre[lo])];
+        const int row = rb * 64 + (pr >> 6), c = pr & 63;
+        const Box A = prepared[row], B = prepared[cb * 64 + c];
+        if (iou_bev(A, B, my, t & 63) > thresh) atomicOr(&mask[(size_t)row * nb + cb], 1ull << c);
+    }
+}
+
 // ---- NMS: sequential sweep, one wave ----------------------------------------------------------------------
 // keep[] receives positions in the sorted order (or order[pos] when `order` is given and map_through_order != 0).
 __global__ void __launch_bounds__(64) k_nms_sweep(const unsigned long long *__restrict__ mask, int nb_stride,
@@ -495,7 +647,12 @@ extern "C" int hvpr_boxes_pairwise_f32(const float *boxes_a, int n, const float 
 extern "C" size_t hvpr_nms_workspace_bytes(int n_max) {
     if (n_max < 1) return 0;
     const size_t nb = (n_max + 63) / 64;
-    return (size_t)n_max * nb * sizeof(unsigned long long) + (size_t)n_max * sizeof(Box) + 256;
+    size_t bytes = (size_t)n_max * nb * sizeof(unsigned long long) + 256 + (size_t)n_max * sizeof(Box) + 256;
+    if (nb <= 64) {     // the two-launch mask: per-tile pair segments + counts
+        const size_t tiles = nb * (nb + 1) / 2;
+        bytes += tiles * kTileCap * sizeof(unsigned short) + 256 + tiles * sizeof(int) + 256 + sizeof(ClipIndex) + 256;
+    }
+    return bytes;
 }
 
 extern "C" int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_t *order, const int32_t *n_device,
@@ -514,7 +671,18 @@ extern "C" int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_
     unsigned long long *mask = (unsigned long long *)workspace;
     Box *prepared = (Box *)((char *)workspace + (((size_t)n_max * nb * sizeof(unsigned long long) + 255) / 256) * 256);
     hipLaunchKernelGGL(k_nms_prep, dim3(hvpr_cdiv(n_max, 256)), dim3(256), 0, s, boxes, box_stride, order, n_device, n_max, prepared);
-    hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, s, prepared, n_device, n_max, thresh, mask, nb);
+    if (nb <= 64) {
+        const size_t tiles = (size_t)nb * (nb + 1) / 2;
+        char *p = (char *)prepared + (((size_t)n_max * sizeof(Box) + 255) / 256) * 256;
+        unsigned short *plist = (unsigned short *)p;
+        int *pcount = (int *)(p + ((tiles * kTileCap * sizeof(unsigned short) + 255) / 256) * 256);
+        ClipIndex *ci = (ClipIndex *)((char *)pcount + ((tiles * sizeof(int) + 255) / 256) * 256);
+        hipLaunchKernelGGL(k_nms_pairs, dim3(nb, nb), dim3(64), 0, s, prepared, n_device, n_max, mask, nb, plist, pcount);
+        hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(1024), 0, s, n_device, n_max, nb, pcount, ci);
+        hipLaunchKernelGGL(k_nms_clip, dim3(kClipBlocks), dim3(kClipThreads), 0, s, prepared, n_device, n_max, thresh, mask, nb, plist, ci);
+    } else {
+        hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, s, prepared, n_device, n_max, thresh, mask, nb);
+    }
     if (nb <= kRingWords) {
         const size_t lds = (size_t)2 * kRingBlocks * 64 * kRingWords * sizeof(unsigned long long);
         static unsigned long long lds_set = 0ull;   // per device

@@ -147,48 +147,70 @@ __global__ void __launch_bounds__(256) k_score_hist(const float *__restrict__ sc
 }
 
 __global__ void __launch_bounds__(1024) k_hist_find(unsigned *__restrict__ hist, int pre_max, unsigned *__restrict__ tbin) {
-    // thread t owns bins [64t, 64t+64); suffix sums over threads (wave shuffles + 16 wave totals) find the owner of the
-    // pre_max-th largest score, which then walks its own 64 bins
+    // The bin that holds the pre_max-th largest score.  The 64 K bins are read as 16 segments of 4096 with COALESCED 16-byte
+    // loads (thread t: bins 4t .. 4t+3 of every segment; the former layout — 64 consecutive bins per thread — made every load
+    // instruction touch 64 cache lines: 19 us for 256 KB).  Segment totals pick the segment, a suffix sum over the threads of that
+    // segment picks the thread, which walks its four bins.
+    static_assert(HBINS == 65536, "16 segments of 4096 bins");
+    __shared__ float s_seg[16][16];
+    __shared__ unsigned s_tot[16];
     __shared__ unsigned s_wave[16];
     const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    unsigned *h = hist + (size_t)n * HBINS;
-    unsigned hv[64];
-    unsigned loc = 0;
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist + (size_t)n * HBINS);
+    uint4 hv[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {      // 16-byte loads: a quarter of the requests of 64 scalar ones (the bins of a thread are 256 B apart)
-        const uint4 u = reinterpret_cast<const uint4 *>(h)[t * 16 + q];
-        hv[4 * q] = u.x; hv[4 * q + 1] = u.y; hv[4 * q + 2] = u.z; hv[4 * q + 3] = u.w;
-        loc += (u.x + u.y) + (u.z + u.w);
-    }
-    // inclusive suffix sum inside the wave (towards higher lanes)
-    unsigned suf = loc;
+    for (int q = 0; q < 16; ++q) hv[q] = h4[q * 1024 + t];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned u = __shfl_down(suf, o, 64);
-        if (lane + o < 64) suf += u;
+    for (int q = 0; q < 16; ++q) {          // counts < 2^24: exact in fp32
+        const float s = hvpr_reduce_sum<64>((float)((hv[q].x + hv[q].y) + (hv[q].z + hv[q].w)));
+        if (lane == q) s_seg[wid][q] = s;
     }
-    if (lane == 0) s_wave[wid] = suf;
     __syncthreads();
-    unsigned above_waves = 0;
-    for (int w = wid + 1; w < 16; ++w) above_waves += s_wave[w];
-    const unsigned incl = suf + above_waves;          // scores in bins >= 64t
-    const unsigned excl = incl - loc;                 // scores in bins >= 64(t+1)
-    unsigned total = 0;
-    for (int w = 0; w < 16; ++w) total += s_wave[w];
-    if (total < (unsigned)pre_max) {
-        if (t == 0) tbin[n] = 0u;                     // fewer than pre_max pass: everything is a candidate
-    } else if (excl < (unsigned)pre_max && incl >= (unsigned)pre_max) {
-        unsigned acc = excl;
-        int b = 63;
-        for (; b > 0; --b) {
-            if (acc + hv[b] >= (unsigned)pre_max) break;
-            acc += hv[b];
+    if (t < 16) {
+        float a = 0.f;
+        for (int w = 0; w < 16; ++w) a += s_seg[w][t];
+        s_tot[t] = (unsigned)a;
+    }
+    __syncthreads();
+    int Q = -1;
+    unsigned above = 0;                      // scores in the segments above Q
+    for (int q = 15; q >= 0; --q) {
+        if (above + s_tot[q] >= (unsigned)pre_max) { Q = q; break; }
+        above += s_tot[q];
+    }
+    if (Q < 0) {
+        if (t == 0) tbin[n] = 0u;            // fewer than pre_max pass: everything is a candidate
+    } else {
+        uint4 cur = hv[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) if (q == Q) cur = hv[q];
+        const unsigned loc = (cur.x + cur.y) + (cur.z + cur.w);
+        unsigned suf = loc;                  // inclusive suffix sum inside the wave (towards higher lanes)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_down(suf, o, 64);
+            if (lane + o < 64) suf += u;
         }
-        tbin[n] = (unsigned)(t * 64 + b);
+        if (lane == 0) s_wave[wid] = suf;
+        __syncthreads();
+        unsigned above_waves = above;
+        for (int w = wid + 1; w < 16; ++w) above_waves += s_wave[w];
+        const unsigned incl = suf + above_waves;          // scores in bins >= this thread's first bin
+        const unsigned excl = incl - loc;
+        if (excl < (unsigned)pre_max && incl >= (unsigned)pre_max) {
+            const unsigned b4[4] = {cur.x, cur.y, cur.z, cur.w};
+            unsigned acc = excl;
+            int b = 3;
+            for (; b > 0; --b) {
+                if (acc + b4[b] >= (unsigned)pre_max) break;
+                acc += b4[b];
+            }
+            tbin[n] = (unsigned)(Q * 4096 + t * 4 + b);
+        }
     }
     // idle state: the histogram is all-zero between calls (no memset node per frame)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) reinterpret_cast<uint4 *>(h)[t * 16 + q] = make_uint4(0u, 0u, 0u, 0u);
+    for (int q = 0; q < 16; ++q) h4[q * 1024 + t] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 __global__ void __launch_bounds__(256) k_score_compact_bin(const float *__restrict__ scores, int A, float thresh, int use_thresh,
