@@ -66,18 +66,21 @@ __device__ __forceinline__ float4 f4_fma(float s, float4 a, float4 b) {      // 
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-template <int NG, bool STATS>
-__global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wino(WinoArgs a) {
+template <int NG, bool STATS, int NB>
+__global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2, NB == 2 ? 2 : 3))) k_wino(WinoArgs a) {
     constexpr int NT = 256 * NG;
     constexpr int TH = 8 * NG, PH = TH + 2;
     constexpr int PPAD = (PH * ROWP + 63) / 64 * 64;          // float4 per channel-half plane
     constexpr int PATCH_V4 = 2 * PPAD;
-    constexpr int NLD_P = (PATCH_V4 + NT - 1) / NT, NLD_W = W_V4 / NT;
+    // NB = 32-channel blocks per workgroup: 2 (64 output channels) or 1 (32: twice the tiles with half the work each, for levels
+    // whose tile count does not fill the chip — the filter stage is then the half of the packed 64-channel image it needs)
+    constexpr int BNT = 32 * NB, W_V4T = 16 * 2 * BNT;
+    constexpr int NLD_P = (PATCH_V4 + NT - 1) / NT, NLD_W = W_V4T / NT;
     constexpr int PATCH_PAD = NLD_P * NT;
-    static_assert(W_V4 % NT == 0, "whole DMA pieces");
+    static_assert(W_V4T % NT == 0 && (NB == 2 || NG == 1), "whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    float4 *const s_w = smem;                                  // [2][W_V4]; the output transform's exchange area afterwards
-    float4 *const s_patch = smem + 2 * W_V4;                   // [2][PATCH_PAD]
+    float4 *const s_w = smem;                                  // [2][W_V4T]; the output transform's exchange area afterwards
+    float4 *const s_patch = smem + 2 * W_V4T;                  // [2][PATCH_PAD]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned wave_s = __builtin_amdgcn_readfirstlane((unsigned)(threadIdx.x >> 6));
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
     const float sgn = wa == 1 ? 1.f : -1.f;
     const int pbase = half * PPAD + (2 * (4 * grp + by)) * ROWP + bx;
     const int p_off0 = pbase + r0 * ROWP, p_off1 = pbase + r1 * ROWP;
-    const int u_off = (wa * 4 * 2 + half) * BN + l31;
+    const int u_off = (wa * 4 * 2 + half) * BNT + l31;
     const unsigned lds_w0 = lds_addr_of(s_w) + wave_s * 1024u;
     const unsigned lds_patch0 = lds_addr_of(s_patch) + wave_s * 1024u;
 
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
     const int n = pt / a.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-    const int co0 = ct * BN;
+    const int co0 = ct * BNT;
 
     unsigned poff[NLD_P];
     bool pok[NLD_P];
@@ -131,7 +134,9 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
         poff[i] = pok[i] ? (unsigned)(((iy * a.W + ix) * a.Cin + p_part[i]) * (int)sizeof(float)) : 0u;
     }
     const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * a.Cin);                 // uniform
-    const char *w_ct = (const char *)(a.wpk + (size_t)ct * n_chunks * (W_V4 * 4));           // uniform
+    // packed image: [64-channel tile][chunk][xi 16][half 2][co 64] float4; an NB = 1 workgroup reads the 32-column half it owns
+    const char *w_ct = (const char *)(a.wpk + (size_t)(NB == 2 ? ct : ct >> 1) * n_chunks * (W_V4 * 4));           // uniform
+    const unsigned w_half = NB == 2 ? 0u : (unsigned)(ct & 1) * 32u * 16u;
 
     auto stage = [&](int chunk, int buf) {
         const char *pbase_g = in_n + (size_t)chunk * (KC * sizeof(float));
@@ -141,7 +146,8 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
             if (pok[i]) lds_dma16(pbase_g, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * NT) * 16u);
 #pragma unroll
         for (int i = 0; i < NLD_W; ++i)
-            lds_dma16(wbase, (unsigned)((tid + i * NT) * 16), lds_w0 + (unsigned)(buf * W_V4 + i * NT) * 16u);
+            lds_dma16(wbase, NB == 2 ? (unsigned)((tid + i * NT) * 16) : (unsigned)((((tid + i * NT) >> 5) * 64 + ((tid + i * NT) & 31)) * 16) + w_half,
+                      lds_w0 + (unsigned)(buf * W_V4T + i * NT) * 16u);
     };
     const bool border = iy0 < 0 || ix0 < 0 || iy0 + PH > a.H || ix0 + PW > a.W;
     if (border) {
@@ -151,11 +157,11 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
             for (int i = 0; i < NLD_P; ++i) s_patch[b * PATCH_PAD + tid + i * NT] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
-    f32x16 acc[4][2];
+    f32x16 acc[4][NB];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][nb][r] = 0.f;
 
@@ -164,8 +170,8 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const float4 *sp = s_patch + BUF * PATCH_PAD;
-        const float4 *sw = s_w + BUF * W_V4;
-        float4 d0[4], d1[4], u[4][2];
+        const float4 *sw = s_w + BUF * W_V4T;
+        float4 d0[4], d1[4], u[4][NB];
         // this chunk's first operands are requested BEFORE the next stage's DMA pieces are issued: the ~10 pieces take a few
         // hundred cycles of issue, which covers the LDS latency of the reads (other stage: no conflict)
 #pragma unroll
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) u[b][nb] = sw[u_off + b * 2 * BN + nb * 32];
+            for (int nb = 0; nb < NB; ++nb) u[b][nb] = sw[u_off + b * 2 * BNT + nb * 32];
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -189,11 +195,11 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
         for (int b = 0; b < 4; ++b) {
             if (b + 2 < 4) {
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) u[b + 2][nb] = sw[u_off + (b + 2) * 2 * BN + nb * 32];
+                for (int nb = 0; nb < NB; ++nb) u[b + 2][nb] = sw[u_off + (b + 2) * 2 * BNT + nb * 32];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].x, v[b].x, acc[b][nb], 0, 0, 0);
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].y, v[b].y, acc[b][nb], 0, 0, 0);
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].z, v[b].z, acc[b][nb], 0, 0, 0);
@@ -219,7 +225,7 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
     const float *rrow = a.gate ? a.resid + pix * a.resid_cstride : nullptr;
     const float sg = p ? -1.f : 1.f;
     // one pass over both 32-channel halves when the exchange fits the two filter stages (NG = 1: 64 KB), else one half per pass
-    constexpr int NPASS = NG == 1 ? 1 : 2, NBP = 2 / NPASS;
+    constexpr int NPASS = NG == 1 ? 1 : 2, NBP = NB / NPASS;
     float4 ykeep[2][4];                 // this lane's outputs (statistics pass below); zero where the pixel / channel is not live
 #pragma unroll
     for (int i = 0; i < 8; ++i) ykeep[i >> 2][i & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -263,6 +269,7 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
             }
         }
     }
+    static_assert(!STATS || (NG == 1 && NB == 2), "the statistics pass is written for the 8 x 16 px x 64 channel tile");
     if (STATS) {
         // Batch statistics of the layer's BatchNorm, fused: per-channel sum and sum of squares over this tile's live pixels go
         // to row (pixel tile) of a.stats (finished in double by hvpr_bn_finalize_partials_f32) — the separate pass over the
@@ -334,29 +341,29 @@ __global__ void k_wino_pack(const float *__restrict__ w, const float *__restrict
     }
 }
 
-template <int NG, bool STATS>
+template <int NG, bool STATS, int NB>
 int launch(WinoArgs a, hipStream_t s) {
     constexpr int NT = 256 * NG, TH = 8 * NG, PH = TH + 2;
     constexpr int PPAD = (PH * ROWP + 63) / 64 * 64;
     constexpr int NLD_P = (2 * PPAD + NT - 1) / NT;
-    constexpr int lds = (2 * W_V4 + 2 * NLD_P * NT) * 16;
+    constexpr int lds = (2 * (16 * 2 * 32 * NB) + 2 * NLD_P * NT) * 16;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    a.n_ct = a.cout_pad / BN;
+    a.n_ct = a.cout_pad / (32 * NB);
     static unsigned long long lds_set = 0ull;
-    if (hvpr_ensure_dyn_lds((const void *)k_wino<NG, STATS>, lds, &lds_set) != 0) return -1;
+    if (hvpr_ensure_dyn_lds((const void *)k_wino<NG, STATS, NB>, lds, &lds_set) != 0) return -1;
     const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y * a.n_ct;
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wino<NG, STATS>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wino<NG, STATS, NB>, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         resident = per_cu * cus;
     }
     long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;
     if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
-    hipLaunchKernelGGL((k_wino<NG, STATS>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((k_wino<NG, STATS, NB>), dim3((unsigned)blocks), dim3(NT), lds, s, a);
     return 0;
 }
 
@@ -401,8 +408,9 @@ extern "C" int hvpr_conv2d_wino_nhwc_f32(const float *in, int N, int H, int W, i
     a.stats = bn_partials;
     if (bn_partials && (px_groups != 1 || relu || gate)) return HVPR_ERR_UNSUPPORTED;      // statistics of the RAW output, 8 x 16 tiles
     int rc;
-    if (px_groups == 1) rc = bn_partials ? launch<1, true>(a, (hipStream_t)stream) : launch<1, false>(a, (hipStream_t)stream);
-    else if (px_groups == 2) rc = launch<2, false>(a, (hipStream_t)stream);
+    if (px_groups == 1) rc = bn_partials ? launch<1, true, 2>(a, (hipStream_t)stream) : launch<1, false, 2>(a, (hipStream_t)stream);
+    else if (px_groups == 2) rc = launch<2, false, 2>(a, (hipStream_t)stream);
+    else if (px_groups == 4) rc = launch<1, false, 1>(a, (hipStream_t)stream);      // 8 x 16 px x 32 channels: twice the tiles
     else return HVPR_ERR_INVALID_ARG;
     if (rc != 0) return HVPR_ERR_LAUNCH;
     HVPR_CHECK_LAUNCH();

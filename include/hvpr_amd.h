@@ -384,7 +384,8 @@ int hvpr_fused_adam_truewd_f32(float *params, const float *grads, float *exp_avg
  *         w'[o][i][u][v] = weight[i][o][2-u][2-v].
  *     hvpr_conv2d_wino_nhwc_f32: in [N,H,W,Cin] (Cin % 8 == 0), bias [cout_pad], gate / resid / out / out_cstride / out_coff as
  *         in hvpr_conv2d_nhwc_f32 (cout % 4 == 0).  px_groups: 1 = 8 x 16 output pixels x 64 channels per workgroup (4 waves),
- *         2 = 16 x 16 pixels x 64 channels (8 waves sharing the filter stage).
+ *         2 = 16 x 16 pixels x 64 channels (8 waves sharing the filter stage), 4 = 8 x 16 pixels x 32 channels (4 waves; twice
+ *         the tiles for launches that do not fill the chip).
  * ------------------------------------------------------------------------------------------- */
 size_t hvpr_conv2d_wino_packed_floats(int cin, int cout);
 int hvpr_conv2d_wino_pack_f32(const float *weight, const float *scale, int cout, int cin, int adjoint, float *packed,

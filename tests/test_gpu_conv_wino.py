@@ -26,6 +26,10 @@ def _ref(x, w, scale, shift, relu, gate=None, resid=None):
     (2, 13, 21, 24, 68, 2, True, True),
     (1, 62, 74, 64, 128, 1, True, True),         # level-2 geometry, SFM epilogue
     (3, 31, 37, 128, 128, 2, True, False),
+    (1, 8, 16, 8, 64, 4, False, False),          # px_groups 4 = 32 output channels per workgroup
+    (2, 13, 21, 24, 68, 4, True, True),
+    (1, 62, 74, 64, 128, 4, True, True),
+    (3, 31, 37, 128, 160, 4, True, False),
 ])
 def test_wino_conv_matches_float64(N, H, W, cin, cout, groups, relu, gated):
     from hvpr_amd import kernels

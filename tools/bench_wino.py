@@ -15,13 +15,14 @@ for (H, W, C) in [(248, 296, 128), (124, 148, 256), (62, 74, 512)]:
     flops = 2 * 9 * C * C * H * W * batch
     cands = [("direct64", lambda: kernels.conv2d_nhwc(x, kernels_pd[1]))]
     kernels_pd = {t: kernels.pack_conv(w, sc, sh, stride=1, relu=True, tile_cfg=t) for t in (0, 1, 2)}
-    pw = {g: kernels.pack_conv_wino(w, sc, sh, relu=True, px_groups=g) for g in (1, 2)}
+    pw = {g: kernels.pack_conv_wino(w, sc, sh, relu=True, px_groups=g) for g in (1, 2, 4)}
     outs = {}
     for name, fn in [("direct_64x64", lambda: kernels.conv2d_nhwc(x, kernels_pd[1])),
                      ("direct_128x64", lambda: kernels.conv2d_nhwc(x, kernels_pd[2])),
                      ("direct_128x128", lambda: kernels.conv2d_nhwc(x, kernels_pd[0])),
                      ("wino_g1", lambda: kernels.conv2d_wino_nhwc(x, pw[1])),
-                     ("wino_g2", lambda: kernels.conv2d_wino_nhwc(x, pw[2]))]:
+                     ("wino_g2", lambda: kernels.conv2d_wino_nhwc(x, pw[2])),
+                     ("wino_c32", lambda: kernels.conv2d_wino_nhwc(x, pw[4]))]:
         for _ in range(3):
             outs[name] = fn()
         torch.cuda.synchronize()
