@@ -335,11 +335,15 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4 *__restrict__
         dz[i] = r;
         }
         if (gate) {          // wave-uniform branch
-            // sum over the lanes of one pixel: `groups` consecutive lanes (a power of two <= 64 inside the wave; wider pixels span
+            // sum over the lanes of one pixel: `groups` consecutive lanes (a power of two: <= 64 inside the wave; wider pixels span
             // several waves and meet in the atomic)
-            const int w = groups < 64 ? groups : 64;
-            for (int o = w >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
-            if (live && ((threadIdx.x & 63) & (w - 1)) == 0) atomicAdd(dgate + i / groups, ga);
+            if ((groups & (groups - 1)) == 0) {
+                const int w = groups < 64 ? groups : 64;
+                for (int o = w >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
+                if (live && ((threadIdx.x & 63) & (w - 1)) == 0) atomicAdd(dgate + i / groups, ga);
+            } else if (live) {       // C / 4 not a power of two (48, 96, ... channels): a pixel's lanes straddle waves unevenly
+                atomicAdd(dgate + i / groups, ga);
+            }
         }
     }
 }
@@ -428,8 +432,6 @@ extern "C" int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long l
     if (!dy || !z || !scale || !shift || !mean || !invstd || !dz || !dgamma || !dbeta || !workspace || P < 1) return HVPR_ERR_INVALID_ARG;
     if ((gate == nullptr) != (dgate == nullptr)) return HVPR_ERR_INVALID_ARG;
     if (C < 4 || C % 4 != 0 || C > 1024) return HVPR_ERR_UNSUPPORTED;
-    const int groups_ = C / 4;
-    if (gate && (groups_ & (groups_ - 1)) != 0) return HVPR_ERR_UNSUPPORTED;       // the gated form needs C / 4 to be a power of two
     if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
     const int blocks = bn_blocks(P);
     hipStream_t s = (hipStream_t)stream;

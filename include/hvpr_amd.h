@@ -336,7 +336,7 @@ int hvpr_memory_train_bwd_f32(const float *x, const float *dy, long long R, cons
  *         (the mean / variance terms are differentiated through).
  *     gate [P] + resid [P,C] (both or neither; may be NULL): the SFM step fused in, y = gate[p] * relu(...) + resid
  *         (x_att = attention(sfm(x_att), y) + x_att, base_bev_backbone.py:250-255); the backward then also returns dgate [P]
- *         (= sum_c relu(...) * dy, overwritten) and propagates gate * dy; d resid = dy.  Needs C / 4 to be a power of two.
+ *         (= sum_c relu(...) * dy, overwritten) and propagates gate * dy; d resid = dy.
  *     C % 4 == 0, C <= 1024 for the reductions.
  * ------------------------------------------------------------------------------------------- */
 /* hvpr_conv2d_wino_wgrad_nhwc_f32: the same weight gradient for 3x3 / stride 1 / pad 1 in the Winograd F(2x2,3x3) domain

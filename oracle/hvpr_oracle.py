@@ -289,6 +289,82 @@ def bev_backbone_eval(spatial_features, spatial_scale_features, params, layer_nu
 
 
 # ----------------------------------------------------------------------------------------
+# a11  BEV backbone, TRAINING forward (two streams through shared weights) — backbones_2d/base_bev_backbone.py:228-279,
+#      spatial_attention.py:47-63; train-mode BatchNorm2d(eps 1e-3, momentum 0.01) as torch defines it
+# ----------------------------------------------------------------------------------------
+def _bn2d_train(x, params, prefix, running, eps=1e-3, momentum=0.01):
+    """Batch statistics over (N,H,W), biased variance in the normalisation, UNBIASED variance into the running estimate; one
+    running-statistics update per CALL (the shared SFM / gate BatchNorms are called 6 / 18 times per forward at hvpr.yaml)."""
+    mean = x.mean(dim=(0, 2, 3))
+    var = x.var(dim=(0, 2, 3), unbiased=False)
+    n = x.numel() // x.shape[1]
+    with torch.no_grad():
+        rm, rv = running[prefix + ".running_mean"], running[prefix + ".running_var"]
+        running[prefix + ".running_mean"] = (1 - momentum) * rm + momentum * mean.detach().to(rm.dtype)
+        running[prefix + ".running_var"] = (1 - momentum) * rv + momentum * (var.detach() * (n / max(n - 1, 1))).to(rv.dtype)
+    xh = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps)
+    return xh * params[prefix + ".weight"].view(1, -1, 1, 1) + params[prefix + ".bias"].view(1, -1, 1, 1)
+
+
+def bev_backbone_train(spatial_features, spatial_features_point, spatial_scale_features, params, layer_nums, layer_strides,
+                       sfm_layer_nums, upsample_strides, trace=None, relu_masks=None):
+    """Training forward of BaseBEVBackbone_Scale (:228-279).  params: torch tensors keyed like the reference's state_dict
+    (leaves may require grad: the function is differentiable through torch autograd, dtype follows the inputs).
+    Returns (spatial_features_2d, spatial_features_point_2d, running) with running = the running statistics after the call.
+    trace: optional list that receives (name, activation) for every block / scale / SFM step / deblock output, and
+    (name + ".pre", pre-activation) for the ReLU inside it.  relu_masks: optional {name: bool tensor} — the ReLU of that op is
+    replaced by a multiplication with the given mask: lets a test differentiate the function on the branch (the set of ReLU
+    decisions) another fp32 implementation took, where a pre-activation within round-off of zero went the other way."""
+    x, xp, y = spatial_features, spatial_features_point, spatial_scale_features
+    running = {k: v.detach().clone() for k, v in params.items() if "running_" in k}
+
+    def tr(name, t):
+        if trace is not None:
+            if t.requires_grad:
+                t.retain_grad()
+            trace.append((name, t))
+        return t
+
+    def relu(v, name):
+        if trace is not None:
+            trace.append((name + ".pre", v))
+        if relu_masks is not None and name in relu_masks:
+            return v * relu_masks[name].to(v.dtype)
+        return torch.relu(v)
+
+    def cbr(t, conv, bn, name, stride=1):
+        return relu(_bn2d_train(F.conv2d(t, params[conv + ".weight"], stride=stride, padding=1), params, bn, running), name)
+
+    def block(t, i, who):                                                # :154-169; ZeroPad2d(1) + pad-0 conv = pad-1 conv
+        t = tr(f"L{i}.{who}.block0", cbr(t, f"blocks.{i}.1", f"blocks.{i}.2", f"L{i}.{who}.block0", layer_strides[i]))
+        for k in range(layer_nums[i]):
+            t = tr(f"L{i}.{who}.block{k + 1}", cbr(t, f"blocks.{i}.{4 + 3 * k}", f"blocks.{i}.{5 + 3 * k}", f"L{i}.{who}.block{k + 1}"))
+        return t
+
+    def attention(t, w):                                                 # spatial_attention.py:57-63
+        pooled = torch.cat([w.max(dim=1, keepdim=True)[0], w.mean(dim=1, keepdim=True)], dim=1)
+        a = F.conv2d(pooled, params["attention.spatial.conv.weight"], params["attention.spatial.conv.bias"], padding=1)
+        return torch.sigmoid(_bn2d_train(a, params, "attention.spatial.norm", running)) * t
+
+    def deblock(t, i, name):                                             # :177-188
+        u = F.conv_transpose2d(t, params[f"deblocks.{i}.0.weight"], stride=upsample_strides[i])
+        return relu(_bn2d_train(u, params, f"deblocks.{i}.1", running), name)
+
+    ups, ups_p = [], []
+    for i in range(len(layer_nums)):
+        x = block(x, i, "x")                                             # :244-246 — the call ORDER fixes the running statistics
+        xp = block(xp, i, "xp")
+        y = tr(f"L{i}.y", cbr(y, f"scale_layers.{i}.1", f"scale_layers.{i}.2", f"L{i}.y", layer_strides[i]))
+        xa, xpa = x, xp
+        for j in range(sfm_layer_nums[i]):                               # :251-257
+            xa = tr(f"L{i}.x.sfm{j}", attention(cbr(xa, f"sfmblocks_down.{i}.0", f"sfmblocks_down.{i}.1", f"L{i}.x.sfm{j}"), y) + xa)
+            xpa = tr(f"L{i}.xp.sfm{j}", attention(cbr(xpa, f"sfmblocks_down.{i}.0", f"sfmblocks_down.{i}.1", f"L{i}.xp.sfm{j}"), y) + xpa)
+        ups.append(tr(f"L{i}.x.up", deblock(xa, i, f"L{i}.x.up")))       # :260-262
+        ups_p.append(tr(f"L{i}.xp.up", deblock(xpa, i, f"L{i}.xp.up")))
+    return torch.cat(ups, dim=1), torch.cat(ups_p, dim=1), running
+
+
+# ----------------------------------------------------------------------------------------
 # a6/a7  head + anchors + decode — dense_heads/anchor_head_single.py:109-145,
 #        anchor_head_template.py:293-340, target_assigner/anchor_generator.py:17-60,
 #        utils/box_coder_utils.py:45-77, utils/common_utils.py:20-23

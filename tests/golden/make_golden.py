@@ -263,6 +263,78 @@ def g4_backbone(R):
                             param_names=np.array(list(shapes.keys())), param_shapes=np.array([str(list(v)) for v in shapes.values()]))
 
 
+GRAD_SAMPLE_STRIDE = 101        # "full" G4-train case: parameter gradients are kept as (norm, every 101st element)
+
+
+def g4_backbone_train(R):
+    """G4-train: base_bev_backbone.py:228-279 in TRAINING mode — both streams through the shared weights, batch
+    statistics, every BatchNorm call updating its running statistics — on the reference's own module, CPU.  Stored: the fp32
+    forward outputs and running statistics, and the gradients of the fixed scalar
+        L = sum(spatial_features_2d * cot_f) + sum(spatial_features_point_2d * cot_fp)
+    w.r.t. the three inputs and every parameter.  The gradients come from the SAME module in float64 (`.double()`, the
+    yardstick: backward through 25 ReLU + train-BatchNorm layers is ill-conditioned in fp32) together with the norm-wise
+    distance of the reference's own fp32 gradients from them (`ref32_err.*`), which documents the regime a fp32 implementation
+    can be held to."""
+    import copy
+    for tag, (C, filt, sfilt, H, W, seed) in {
+        "small": (32, [32, 48, 64], [8, 16, 24], 16, 24, 414),     # channel counts the kernels take: Cin % 8 == 0
+        "full": (128, [128, 256, 512], [32, 64, 128], 8, 12, 415),
+    }.items():
+        gen = torch.Generator().manual_seed(seed)
+        cfg = EasyDict(LAYER_NUMS=[3, 3, 3], SFM_LAYER_NUMS=[3, 3, 3], LAYER_STRIDES=[1, 2, 2], NUM_FILTERS=filt,
+                       NUM_SCALE_FILTERS=sfilt, UPSAMPLE_STRIDES=[1, 2, 4], NUM_UPSAMPLE_FILTERS=[filt[0]] * 3)
+        torch.manual_seed(seed)
+        m = R.bev.BaseBEVBackbone_Scale(model_cfg=cfg, input_channels=C)
+        shapes = load_det(m, seed)
+        m.train()
+        B = 2
+        occ = (torch.rand(B, 1, H, W, generator=gen) < 0.35).float()
+        occ_p = (torch.rand(B, 1, H, W, generator=gen) < 0.5).float()
+        x = torch.relu(torch.randn(B, C, H, W, generator=gen)) * occ
+        xp = torch.relu(torch.randn(B, C, H, W, generator=gen)) * occ_p
+        y = torch.relu(torch.randn(B, C // 4, H, W, generator=gen)) * occ
+        nf = 3 * filt[0]
+        cot_f = torch.from_numpy(det_state({"cotangent.f": (B, nf, H, W)}, seed)["cotangent.f"])
+        cot_fp = torch.from_numpy(det_state({"cotangent.fp": (B, nf, H, W)}, seed)["cotangent.fp"])
+        res = {}
+        for dt in (torch.float32, torch.float64):
+            mm = copy.deepcopy(m).to(dt)
+            ins = [t.clone().to(dt).requires_grad_(True) for t in (x, xp, y)]
+            d = mm({"spatial_features": ins[0], "spatial_features_point": ins[1], "spatial_scale_features": ins[2]})
+            f, fp = d["spatial_features_2d"], d["spatial_features_point_2d"]
+            ((f * cot_f.to(dt)).sum() + (fp * cot_fp.to(dt)).sum()).backward()
+            res[dt] = dict(f=f.detach(), fp=fp.detach(), gin=[t.grad for t in ins],
+                           gpar={k: p.grad for k, p in mm.named_parameters()},
+                           buf={k: v.detach().clone() for k, v in mm.named_buffers() if "num_batches" not in k},
+                           nbt={k: int(v) for k, v in mm.named_buffers() if "num_batches" in k})
+        r32, r64 = res[torch.float32], res[torch.float64]
+        out = dict(spatial_features=x.numpy(), spatial_features_point=xp.numpy(), spatial_scale_features=y.numpy(),
+                   layer_nums=[3, 3, 3], sfm_layer_nums=[3, 3, 3], layer_strides=[1, 2, 2], upsample_strides=[1, 2, 4],
+                   param_seed=seed, param_names=np.array(list(shapes.keys())),
+                   param_shapes=np.array([str(list(v)) for v in shapes.values()]),
+                   spatial_features_2d=r32["f"].numpy(), spatial_features_point_2d=r32["fp"].numpy(),
+                   spatial_features_2d_f64=r64["f"].float().numpy(), spatial_features_point_2d_f64=r64["fp"].float().numpy(),
+                   grad_sample_stride=GRAD_SAMPLE_STRIDE if tag == "full" else 1)
+        for k, v in r32["buf"].items():
+            out["after_train." + k] = v.numpy()
+        for k, v in r32["nbt"].items():
+            out["num_batches_tracked." + k] = v
+
+        def nerr(a, b):
+            return float((a.double() - b).norm() / b.norm().clamp_min(1e-300))
+        for name, g32, g64 in zip(("spatial_features", "spatial_features_point", "spatial_scale_features"), r32["gin"], r64["gin"]):
+            out["grad_in." + name] = g64.float().numpy()
+            out["ref32_err.grad_in." + name] = nerr(g32, g64)
+        for k, g64 in r64["gpar"].items():
+            g32 = r32["gpar"][k]
+            out["grad_norm." + k] = float(g64.norm())
+            # a conv bias in front of a train-mode BatchNorm has an exactly-zero gradient: only round-off on both sides
+            out["ref32_err.grad." + k] = nerr(g32, g64) if float(g64.norm()) > 1e-9 * g64.numel() ** 0.5 else 0.0
+            flat = g64.float().reshape(-1).numpy()
+            out["grad." + k] = flat[::GRAD_SAMPLE_STRIDE].copy() if tag == "full" else g64.float().numpy()
+        np.savez_compressed(os.path.join(OUT, f"g4_backbone_train_{tag}.npz"), **out)
+
+
 def g5_head(R):
     gen = torch.Generator().manual_seed(505)
     for stride in (1, 2):
@@ -618,12 +690,48 @@ def g13_voxel_index(R):
     np.savez_compressed(os.path.join(OUT, "g13_voxel_index.npz"), **out)
 
 
+def g14_axis_aligned_iou(R):
+    """Partial pin of row a8 (the rotated-IoU sources are absent): for boxes whose heading is a multiple of pi/2 the rotated BEV
+    IoU IS the axis-aligned IoU, which the reference does ship — box_utils.boxes3d_nearest_bev_iou (box_utils.py:297-323, the
+    matcher of axis_aligned_target_assigner.py:146) on top of boxes_iou_normal (:252-272).  Stored: the boxes and the reference's
+    IoU matrices; the test derives greedy-NMS survivors from the reference matrix and compares the oracle's / kernel's NMS."""
+    gen = torch.Generator().manual_seed(1414)
+
+    def boxes(n):
+        b = torch.zeros(n, 7)
+        b[:, 0] = torch.rand(n, generator=gen) * 12
+        b[:, 1] = torch.rand(n, generator=gen) * 8 - 4
+        b[:, 2] = torch.rand(n, generator=gen) - 1.5
+        b[:, 3] = 3.0 + torch.rand(n, generator=gen) * 1.5
+        b[:, 4] = 1.4 + torch.rand(n, generator=gen) * 0.5
+        b[:, 5] = 1.4 + torch.rand(n, generator=gen) * 0.3
+        b[:, 6] = torch.randint(-2, 3, (n,), generator=gen).float() * (np.pi / 2)
+        return b
+    a, b = boxes(48), boxes(40)
+    b[0] = a[0]                                    # identical pair -> IoU 1
+    b[1] = a[1]; b[1, 6] = a[1, 6] + np.pi         # same rectangle, opposite heading
+    b[2] = a[2]; b[2, 0] += 50                     # far apart -> 0
+    b[3] = a[3]; b[3, 3:5] = a[3, 3:5] * 0.5       # contained
+    b[4] = a[4]; b[4, 6] = 0.0; a[4, 6] = np.pi / 2   # the same centre, crossed
+    iou_ab = R.box_utils.boxes3d_nearest_bev_iou(a, b)
+    # a dense cluster for NMS: 256 boxes around a few centres, scores distinct
+    n = 256
+    c = boxes(n)
+    centres = torch.rand(12, 2, generator=gen) * torch.tensor([12.0, 8.0]) - torch.tensor([0.0, 4.0])
+    c[:, 0:2] = centres[torch.randint(0, 12, (n,), generator=gen)] + torch.randn(n, 2, generator=gen) * 0.6
+    scores = torch.rand(n, generator=gen)
+    iou_cc = R.box_utils.boxes3d_nearest_bev_iou(c, c)
+    np.savez_compressed(os.path.join(OUT, "g14_axis_aligned_iou.npz"), boxes_a=a.numpy(), boxes_b=b.numpy(), iou_ab=iou_ab.numpy(),
+                        nms_boxes=c.numpy(), nms_scores=scores.numpy(), iou_nms=iou_cc.numpy())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     R = load_reference()
     g1_vfe(R)
     g2_g3_memory_scatter(R)
     g4_backbone(R)
+    g4_backbone_train(R)
     g5_head(R)
     g6_g7_coder(R)
     g8_assigner_losses(R)
@@ -632,6 +740,7 @@ if __name__ == "__main__":
     g11_preprocess(R)
     g12_kitti_eval(R)
     g13_voxel_index(R)
+    g14_axis_aligned_iou(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")

@@ -23,3 +23,157 @@ def test_g9_onecycle_three_steps_on_gpu(golden_dir):
 
 def test_g10_get_score_and_memory_train_branch_on_gpu(golden_dir):
     C.run_g10(golden_dir, DEV, rtol=1e-4)
+
+
+def _g4_train_setup(golden_dir, tag):
+    import numpy as np
+    import torch
+
+    from detparams import det_state
+    from hvpr_amd import bev_backbone
+    from hvpr_amd.config import AttrDict
+
+    z = np.load(f"{golden_dir}/g4_backbone_train_{tag}.npz", allow_pickle=False)
+    seed = int(z["param_seed"])
+    shapes = {str(n): tuple(eval(str(s))) for n, s in zip(z["param_names"], z["param_shapes"])}
+    filt = [shapes[f"blocks.{i}.1.weight"][0] for i in range(3)]
+    sfilt = [shapes[f"scale_layers.{i}.1.weight"][0] for i in range(3)]
+    cfg = AttrDict(LAYER_NUMS=[int(v) for v in z["layer_nums"]], SFM_LAYER_NUMS=[int(v) for v in z["sfm_layer_nums"]],
+                   LAYER_STRIDES=[int(v) for v in z["layer_strides"]], NUM_FILTERS=filt, NUM_SCALE_FILTERS=sfilt,
+                   UPSAMPLE_STRIDES=[int(v) for v in z["upsample_strides"]], NUM_UPSAMPLE_FILTERS=[filt[0]] * 3)
+    m = bev_backbone.BaseBEVBackbone_Scale(model_cfg=cfg, input_channels=z["spatial_features"].shape[1])
+    before = det_state(shapes, seed)
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in before.items()}, strict=False)
+    assert not missing.unexpected_keys and all("num_batches_tracked" in k for k in missing.missing_keys), missing
+    return z, seed, before, cfg, m.to(DEV).train()
+
+
+def _op_names(cfg):
+    """Call order of the activations the training forward produces (bev_backbone._forward_train_hip = base_bev_backbone.py:242-262)."""
+    names = []
+    for i, (n, ns) in enumerate(zip(cfg.LAYER_NUMS, cfg.SFM_LAYER_NUMS)):
+        names += [f"L{i}.x.block{k}" for k in range(n + 1)] + [f"L{i}.xp.block{k}" for k in range(n + 1)] + [f"L{i}.y"]
+        for j in range(ns):
+            names += [f"L{i}.x.sfm{j}", f"L{i}.xp.sfm{j}"]
+        names += [f"L{i}.x.up", f"L{i}.xp.up"]
+    return names
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_g4_train_two_stream_backbone_on_gpu(golden_dir, tag, monkeypatch):
+    """Row a11 against the REFERENCE: BaseBEVBackbone_Scale's training forward (base_bev_backbone.py:228-279) on the library's
+    own kernels vs fixture G4-train (the reference's own module, CPU).
+
+    Forward: both streams' outputs element-wise 1e-3 (observed 3e-6 norm-wise), every BatchNorm's running statistics after its
+    1 / 2 / 6 / 18 calls, num_batches_tracked.
+
+    Backward — gradients of the fixture's scalar w.r.t. the three canvases and every parameter, yardstick = the reference module in
+    float64.  A fp32 ReLU network has a discontinuity the tolerance has to respect: of the ~0.7 M ReLU decisions of this forward a
+    few have a pre-activation within fp32 round-off of zero, any two fp32 implementations may take them differently, and ONE such
+    decision at level 2 moves every gradient upstream of it by ~1e-3 (measured: one flipped element of 6144 in the last SFM step).
+    So the check is split into three exact statements:
+      (1) the ReLU decisions of the kernels differ from the reference's (float64 oracle, pinned to the fixture by
+          tests/test_oracle_golden.py::test_g4_backbone_train) only where the pre-activation is within 1e-4 of zero relative to
+          the layer's rms, and in at most 1e-5 of all decisions;
+      (2) ON the branch the kernels took (oracle in float64 with those decisions imposed) every gradient agrees norm-wise to 1e-4 —
+          the parity statement for the backward operators;
+      (3) against the fixture's gradients themselves (reference decisions) nothing is further than the documented flip regime:
+          3e-2 per tensor."""
+    import numpy as np
+    import torch
+
+    from detparams import det_tensor
+    from hvpr_amd import conv_train as ct
+    from oracle import hvpr_oracle as O
+
+    z, seed, before, cfg, m = _g4_train_setup(golden_dir, tag)
+    stride = int(z["grad_sample_stride"])
+    acts, names = [], iter(_op_names(cfg))
+
+    def tap(fn):
+        def inner(*a, **k):
+            y = fn(*a, **k)
+            acts.append((next(names), y, k.get("resid") if "resid" in k else (a[0] if fn is orig_sfm else None)))
+            return y
+        return inner
+    orig_sfm = ct.sfm_step
+    monkeypatch.setattr(ct, "bn_relu", tap(ct.bn_relu))
+    monkeypatch.setattr(ct, "sfm_step", tap(ct.sfm_step))
+    in_keys = ("spatial_features", "spatial_features_point", "spatial_scale_features")
+    ins = [torch.from_numpy(z[k]).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) for k in in_keys]
+    d = m({"spatial_features": ins[0], "spatial_features_point": ins[1], "spatial_scale_features": ins[2]})
+    f, fp = d["spatial_features_2d"], d["spatial_features_point_2d"]
+    assert next(names, None) is None and len(acts) == len(_op_names(cfg))
+
+    def close(got, ref, what, rtol=1e-3):
+        got = got.detach().float().cpu().numpy()
+        rms = float(np.sqrt(np.mean(np.square(ref, dtype=np.float64))))
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=rtol * max(rms, 1e-30), err_msg=what)
+    close(f, z["spatial_features_2d"], "spatial_features_2d")
+    close(fp, z["spatial_features_point_2d"], "spatial_features_point_2d")
+    for k, v in m.state_dict().items():
+        if "num_batches_tracked" in k:
+            assert int(v) == int(z["num_batches_tracked." + k]), k
+        elif "running_" in k:
+            ref_delta = z["after_train." + k] - before[k]
+            got_delta = v.cpu().numpy() - before[k]
+            np.testing.assert_allclose(got_delta, ref_delta, rtol=2e-3, atol=2e-3 * np.abs(ref_delta).max() + 1e-7, err_msg=k)
+    cot_f = torch.from_numpy(det_tensor("cotangent.f", f.shape, seed))
+    cot_fp = torch.from_numpy(det_tensor("cotangent.fp", fp.shape, seed))
+    ((f * cot_f.to(DEV)).sum() + (fp * cot_fp.to(DEV)).sum()).backward()
+
+    # (1) the kernels' ReLU decisions: an op's output is relu(.) [plain], gate * relu(.) + resid [SFM step; gate = sigmoid > 0]
+    masks = {}
+    for name, y, resid in acts:
+        r = y.detach() if resid is None else (y.detach() - resid.detach())
+        masks[name] = (r != 0).permute(0, 3, 1, 2).cpu()
+    par = {k: torch.from_numpy(v).double() for k, v in before.items()}
+
+    def oracle(relu_masks):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in par.items() if "running_" not in k}
+        oi = [torch.from_numpy(z[k]).double().requires_grad_(True) for k in in_keys]
+        tr = []
+        of, ofp, _ = O.bev_backbone_train(oi[0], oi[1], oi[2], {**par, **leaves}, cfg.LAYER_NUMS, cfg.LAYER_STRIDES, cfg.SFM_LAYER_NUMS,
+                                          cfg.UPSAMPLE_STRIDES, trace=tr, relu_masks=relu_masks)
+        ((of * cot_f.double()).sum() + (ofp * cot_fp.double()).sum()).backward()
+        return oi, leaves, dict(tr)
+    _, _, tr = oracle(None)
+    flips = total = 0
+    for name, mask in masks.items():
+        pre = tr[name + ".pre"].detach()
+        diff = mask != (pre > 0)
+        total += mask.numel()
+        if bool(diff.any()):
+            flips += int(diff.sum())
+            worst = float(pre[diff].abs().max() / pre.pow(2).mean().sqrt())
+            assert worst < 1e-4, (name, int(diff.sum()), worst)
+    print(f"G4-train[{tag}]: {flips} of {total} ReLU decisions differ from the reference's (pre-activations within round-off of zero)")
+    assert flips <= max(1, int(1e-5 * total)), (flips, total)
+
+    # (2) gradients on the kernels' branch, (3) against the fixture (reference branch)
+    oi, leaves, _ = oracle(masks)
+
+    def nerr(got, ref):
+        got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+        return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300))
+    rows = []
+    for t, o, name in zip(ins, oi, in_keys):
+        rows.append(("grad_in." + name, nerr(t.grad.cpu().numpy(), o.grad.numpy()), nerr(t.grad.cpu().numpy(), z["grad_in." + name])))
+    for k, p in m.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        gn = float(z["grad_norm." + k])
+        if gn < 1e-9 * p.numel() ** 0.5:       # conv bias in front of a train-mode BatchNorm: exact gradient zero
+            assert float(p.grad.abs().max()) < 1e-4, k
+            continue
+        got = p.grad.detach().cpu().numpy()
+        sample = got.reshape(-1)[::stride] if stride > 1 else got
+        rows.append(("grad." + k, nerr(got, leaves[k].grad.numpy()), nerr(sample, z["grad." + k])))
+    e_branch, e_fix = np.array([r[1] for r in rows]), np.array([r[2] for r in rows])
+    print(f"G4-train[{tag}] gradients, norm-wise: on the kernels' branch median {np.median(e_branch):.2e} max {e_branch.max():.2e} | "
+          f"vs the fixture median {np.median(e_fix):.2e} max {e_fix.max():.2e}")
+    for name, a_, b_ in sorted(rows, key=lambda r: -r[1])[:4]:
+        print(f"   {name:50s} branch {a_:.2e} fixture {b_:.2e}")
+    assert e_branch.max() < 1e-4, sorted(rows, key=lambda r: -r[1])[:3]
+    assert e_fix.max() < 3e-2, sorted(rows, key=lambda r: -r[2])[:3]
+    if flips == 0:
+        assert e_fix.max() < 1e-4, sorted(rows, key=lambda r: -r[2])[:3]

@@ -134,3 +134,44 @@ def test_g13_voxel_index_pins_the_voxelizer_oracle(golden_dir):
             v2, c2, n2 = O.voxelize(pts, z["voxel_size"], z["range"], 32, cap, mode="v2")
             np.testing.assert_array_equal(c2, cells)
             np.testing.assert_array_equal(n2, np.minimum(counts, 32))
+
+
+def _g4_train_case(z, dtype):
+    params = {k: v.to(dtype) for k, v in _det_params(z).items()}
+    leaves = {k: v.requires_grad_(True) for k, v in params.items() if "running_" not in k}
+    params.update(leaves)
+    ins = [torch.from_numpy(z[k]).to(dtype).requires_grad_(True)
+           for k in ("spatial_features", "spatial_features_point", "spatial_scale_features")]
+    f, fp, running = O.bev_backbone_train(ins[0], ins[1], ins[2], params, list(z["layer_nums"]), list(z["layer_strides"]),
+                                          list(z["sfm_layer_nums"]), list(z["upsample_strides"]))
+    return ins, leaves, f, fp, running
+
+
+def test_g4_backbone_train(golden_dir):
+    """The oracle's training forward of the two-stream backbone against the reference's own module in train mode
+    (base_bev_backbone.py:228-279; fixture G4-train): both outputs, every running statistic after the multi-call updates, and —
+    in float64, where the chain is well conditioned — the gradients of the fixture's scalar w.r.t. inputs and parameters."""
+    for tag in ("small", "full"):
+        z = _load(golden_dir, f"g4_backbone_train_{tag}.npz")
+        seed, stride = int(z["param_seed"]), int(z["grad_sample_stride"])
+        ins, leaves, f, fp, running = _g4_train_case(z, torch.float32)
+        for got, key in ((f, "spatial_features_2d"), (fp, "spatial_features_point_2d")):
+            ref = z[key]
+            np.testing.assert_allclose(got.detach().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max(), err_msg=key)
+        before = _det_params(z)
+        for k, v in running.items():
+            ref_delta = z["after_train." + k] - before[k].numpy()
+            np.testing.assert_allclose(v.numpy() - before[k].numpy(), ref_delta, rtol=1e-3, atol=1e-3 * np.abs(ref_delta).max() + 1e-7,
+                                       err_msg=k)
+        ins, leaves, f, fp, _ = _g4_train_case(z, torch.float64)
+        cot_f = torch.from_numpy(det_tensor("cotangent.f", f.shape, seed)).double()
+        cot_fp = torch.from_numpy(det_tensor("cotangent.fp", fp.shape, seed)).double()
+        ((f * cot_f).sum() + (fp * cot_fp).sum()).backward()
+        for t, name in zip(ins, ("spatial_features", "spatial_features_point", "spatial_scale_features")):
+            ref = z["grad_in." + name]
+            np.testing.assert_allclose(t.grad.numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max(), err_msg=name)
+        for k, p in leaves.items():
+            ref = z["grad." + k]
+            got = p.grad.reshape(-1)[::stride].numpy() if stride > 1 else p.grad.numpy()
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * max(float(z["grad_norm." + k]), 1e-12) + 1e-12, err_msg=k)
+            assert abs(float(p.grad.norm()) - float(z["grad_norm." + k])) <= 1e-6 * float(z["grad_norm." + k]) + 1e-9, k
