@@ -165,3 +165,26 @@ def test_multi_classes_nms_and_nms_normal_gpu():
         np.testing.assert_array_equal(keep.cpu().numpy(), np.array(kept))
     else:
         assert len(set(keep.cpu().numpy().tolist()) ^ set(kept)) <= 2 * near
+
+
+def test_g14_rotated_iou_and_nms_on_axis_aligned_boxes_vs_reference(golden_dir):
+    """Partial pin of row a8 on the GPU (fixture G14 = the reference's box_utils.boxes3d_nearest_bev_iou, box_utils.py:297-323, on
+    boxes whose heading is a multiple of pi/2, where the rotated BEV IoU IS the axis-aligned one): hvpr_boxes_pairwise_f32 within
+    the published routine's in-box margin of the reference IoU, exact zeros stay zero, and the NMS kernel's survivors = greedy NMS
+    on the REFERENCE's IoU matrix at nine thresholds (see tests/test_oracle_golden.py for what is statement and what observation)."""
+    from test_oracle_golden import G14_IOU_ATOL, _greedy_nms_from_iou
+    z = np.load(f"{golden_dir}/g14_axis_aligned_iou.npz")
+    a, b = torch.from_numpy(z["boxes_a"]).to(DEV), torch.from_numpy(z["boxes_b"]).to(DEV)
+    got = kernels.boxes_pairwise(a, b, 1).cpu().numpy()
+    np.testing.assert_allclose(got, z["iou_ab"], rtol=0, atol=G14_IOU_ATOL)
+    assert (got[z["iou_ab"] == 0] == 0).all()
+    assert abs(got[0, 0] - 1) < 2e-3 and abs(got[1, 1] - 1) < 2e-3
+    boxes, scores = z["nms_boxes"], z["nms_scores"]
+    n = len(scores)
+    tb = torch.from_numpy(boxes).to(DEV)
+    np.testing.assert_allclose(kernels.boxes_pairwise(tb, tb, 1).cpu().numpy(), z["iou_nms"], rtol=0, atol=G14_IOU_ATOL)
+    ws = kernels.PostWorkspace(1, n, n, DEV)
+    order, _, cnt = kernels.score_topk(torch.from_numpy(scores[None]).to(DEV), None, n, ws)
+    for thr in (0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8):
+        keep, kc = kernels.nms_bev(tb, order[0].contiguous(), cnt, n, thr, n, ws.nms)
+        np.testing.assert_array_equal(keep.cpu().numpy()[: int(kc.item())], _greedy_nms_from_iou(z["iou_nms"], scores, thr)[0])
