@@ -209,35 +209,34 @@ class AnchorHeadSingle(AnchorHeadTemplate):
         return {"pc": kernels.pack_conv(w, None, b, relu=False, tile_cfg=1), "xs": x, "ys": y, "table": table}
 
     def _forward_train(self, data_dict):
-        """Training forward, anchor_head_single.py:41-108: both streams through the same three 1x1 convs (torch, autograd),
-        targets assigned once."""
+        """Training forward, anchor_head_single.py:41-108: both streams through the same three 1x1 convolutions, targets assigned
+        once.  The three convolutions run as ONE convolution on the library's kernels (forward, data and weight gradient:
+        hvpr_amd/conv_train.py), output channels padded to a multiple of 8 with zero rows (the data gradient is a convolution
+        with that many input channels); the biases are added by torch.  CPU tensors raise (torch form: tests/torch_forms.py)."""
+        from . import conv_train as ct
         fr = self.forward_ret_dict
         heads = [self.conv_cls, self.conv_box] + ([self.conv_dir_cls] if self.conv_dir_cls is not None else [])
         f0 = data_dict["spatial_features_2d"]
-        hip = f0.is_cuda and f0.dtype == torch.float32 and os.environ.get("HVPR_TRAIN_CONV", "hip") != "torch" and \
-            all(h.weight.shape[0] % 2 == 0 for h in heads)
-        if hip:
-            # the three 1x1 convolutions as ONE convolution on the library's kernels (forward, data and weight gradient:
-            # hvpr_amd/conv_train.py), output channels padded to a multiple of 8 with zero rows (the data gradient is a
-            # convolution with that many input channels); the biases are added by torch
-            from . import conv_train as ct
-            w = torch.cat([h.weight for h in heads], dim=0)
-            b = torch.cat([h.bias for h in heads], dim=0)
-            n_out = w.shape[0]
-            pad = (-n_out) % 8
-            if pad:
-                w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
-            cuts = np.cumsum([0] + [h.weight.shape[0] for h in heads])
+        if not f0.is_cuda or f0.dtype != torch.float32:
+            raise RuntimeError("hvpr_amd: AnchorHeadSingle's training forward needs fp32 GPU tensors (the HIP path has no CPU fallback)")
+        w = torch.cat([h.weight for h in heads], dim=0)
+        b = torch.cat([h.bias for h in heads], dim=0)
+        n_out = w.shape[0]
+        pad = (-n_out) % 8
+        if pad:
+            w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
+        cuts = np.cumsum([0] + [h.weight.shape[0] for h in heads])
         for key, suffix in (("spatial_features_2d", ""), ("spatial_features_point_2d", "_point")):
-            f = data_dict[key]
-            if hip:
-                out = ct.conv(f.permute(0, 2, 3, 1), w)[..., :n_out] + b
-                parts = [out[..., cuts[i]:cuts[i + 1]].contiguous() for i in range(len(heads))]
-            else:
-                parts = [h(f).permute(0, 2, 3, 1).contiguous() for h in heads]
+            out = ct.conv(data_dict[key].permute(0, 2, 3, 1), w)[..., :n_out] + b
+            parts = [out[..., cuts[i]:cuts[i + 1]].contiguous() for i in range(len(heads))]
             fr["cls_preds" + suffix], fr["box_preds" + suffix] = parts[0], parts[1]
             if self.conv_dir_cls is not None:
                 fr["dir_cls_preds" + suffix] = parts[2]
+        return self._finish_train(data_dict)
+
+    def _finish_train(self, data_dict):
+        """The device-agnostic rest of the training forward (anchor_head_single.py:86-108): loss inputs, target assignment, boxes."""
+        fr = self.forward_ret_dict
         fr["pos_point_feas"] = data_dict["point_positive_features"]
         fr["pos_memory_feas"] = data_dict["memory_positive_features"]
         fr["memory_items"] = data_dict["memory_items"]

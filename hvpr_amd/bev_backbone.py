@@ -30,11 +30,6 @@ class SpatialAttention(nn.Module):
         super().__init__()
         self.spatial = ConvLayer(2, 1, 3, stride=1, padding=1, use_norm=True, activation=False)
 
-    def forward(self, x, w):
-        """Torch form used by the training forward: gate from the scale stream w, applied to x (spatial_attention.py:57-63)."""
-        pooled = torch.cat((w.max(dim=1, keepdim=True)[0], w.mean(dim=1, keepdim=True)), dim=1)
-        return torch.sigmoid(self.spatial.norm(self.spatial.conv(pooled))) * x
-
     def gate_params(self):
         s, t = bn_scale_shift(self.spatial.norm)
         return (self.spatial.conv.weight.detach().float().reshape(18).contiguous(), float(self.spatial.conv.bias.detach()),
@@ -198,27 +193,13 @@ class BaseBEVBackbone_Scale(nn.Module):
         weights (two streams, shared scale stream); BatchNorm uses batch statistics and every call of a shared BN layer
         updates its running statistics.
 
-        Default (GPU): the library's own kernels through hvpr_amd.conv_train — forward / data-gradient convolutions on
-        hvpr_conv2d_nhwc_f32, weight gradients on hvpr_conv2d_wgrad_nhwc_f32, train-mode BatchNorm + ReLU on the hvpr_bn_*
-        kernels, NHWC activations end to end.  HVPR_TRAIN_CONV=torch keeps the torch (MIOpen) autograd form, the parity
-        reference of tests/test_gpu_conv_train.py."""
-        if data_dict["spatial_features"].is_cuda and os.environ.get("HVPR_TRAIN_CONV", "hip") != "torch":
-            return self._forward_train_hip(data_dict)
-        x, xp, y = data_dict["spatial_features"], data_dict["spatial_features_point"], data_dict["spatial_scale_features"]
-        ups, ups_p = [], []
-        for i in range(len(self.blocks)):
-            x, xp, y = self.blocks[i](x), self.blocks[i](xp), self.scale_layers[i](y)
-            xa, xpa = x, xp
-            for _ in range(self.sfm_layer_nums[i]):
-                xa = self.attention(self.sfmblocks_down[i](xa), y) + xa
-                xpa = self.attention(self.sfmblocks_down[i](xpa), y) + xpa
-            ups.append(self.deblocks[i](xa))
-            ups_p.append(self.deblocks[i](xpa))
-        data_dict["spatial_features_2d"] = torch.cat(ups, dim=1)
-        data_dict["spatial_features_point_2d"] = torch.cat(ups_p, dim=1)
-        return data_dict
-
-    def _forward_train_hip(self, data_dict):
+        One code path: the library's own kernels through hvpr_amd.conv_train — forward / data-gradient convolutions on
+        hvpr_conv2d_wino_nhwc_f32 / hvpr_conv2d_nhwc_f32, weight gradients on hvpr_conv2d_wino_wgrad_nhwc_f32 /
+        hvpr_conv2d_wgrad_nhwc_f32, train-mode BatchNorm + ReLU on the hvpr_bn_* kernels, NHWC activations end to end.  CPU
+        tensors and unsupported channel counts raise (the torch form of this forward is test infrastructure:
+        tests/torch_forms.py)."""
+        if not data_dict["spatial_features"].is_cuda:
+            raise RuntimeError("hvpr_amd: BaseBEVBackbone_Scale's training forward needs GPU tensors (the HIP path has no CPU fallback)")
         from . import conv_train as ct
 
         def nhwc(t):

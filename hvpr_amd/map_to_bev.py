@@ -4,11 +4,9 @@ Eval forward = memory read-out (hvpr_memory_readout_fwd_f32) + gather-form scatt
 whole batch: no python loop over frames, no `.item()` host sync (the reference has both: pointpillar_scatter.py:176-178).
 The canvases come back as (B, C, ny, nx) tensors in channels_last memory format."""
 import math
-import os
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import kernels
 
@@ -23,8 +21,6 @@ class MemoryUnit_Agg(nn.Module):
         stdv = 1.0 / math.sqrt(fea_dim)
         self.weight.data.uniform_(-stdv, stdv)
         self._packed = None
-
-    allow_torch_reference = False      # see PointPillarScatter_Agg_Memory_1_scale.allow_torch_reference
 
     def train(self, mode=True):
         self._packed = None
@@ -53,25 +49,16 @@ class MemoryUnit_Agg(nn.Module):
         return {"output": kernels.memory_readout_fwd(input1.contiguous(), self.packed_bank(), k)}
 
     def _forward_train(self, pillars, k, positives):
+        """Hard-shrink addressing through hvpr_memory_train_fwd/bwd_f32: the (nv*k, items) attention is never materialised ('att'
+        is not returned: nothing on the path consumes it, pointpillar_scatter.py:133-138).  Torch form: tests/torch_forms.py."""
         nv, _, d = positives.shape
-        if positives.is_cuda and d == 64 and self.mem_dim <= 2048 and self.shrink_thres > 0 and os.environ.get("HVPR_TRAIN_MEMORY", "hip") != "torch":
-            # hard-shrink addressing through hvpr_memory_train_fwd/bwd_f32: the (nv*k, items) attention is never materialised
-            # ('att' is not returned in this form: nothing on the path consumes it, pointpillar_scatter.py:133-138)
-            mem = _MemoryTrain.apply(positives.reshape(-1, d), self.weight, float(self.shrink_thres)).reshape(nv, k, d)
-            agg = torch.softmax((mem * pillars.unsqueeze(1)).sum(dim=2), dim=1)
-            return {"output": (agg.detach().unsqueeze(2) * mem).sum(dim=1)}
-        if positives.is_cuda and os.environ.get("HVPR_TRAIN_MEMORY", "hip") != "torch":
-            raise ValueError("hvpr_amd: the memory training branch is built for 64 channels, <= 2048 items and SHRINK_TH > 0 (hvpr.yaml:83-85)")
-        if not positives.is_cuda and not self.allow_torch_reference:
+        if not positives.is_cuda:
             raise RuntimeError("hvpr_amd: the memory training branch needs GPU tensors (the HIP path has no CPU fallback)")
-        # torch form: the parity reference of the tests (materialises the (nv*k, items) attention)
-        att = torch.softmax(F.linear(positives.reshape(-1, d), self.weight), dim=1)          # (nv*k, items)
-        if self.shrink_thres > 0:
-            att = hard_shrink_relu(att, self.shrink_thres)
-            att = F.normalize(att, p=1, dim=1)
-        mem = F.linear(att, self.weight.t()).reshape(nv, k, d)                             # read-out per positive
+        if d != 64 or self.mem_dim > 2048 or not self.shrink_thres > 0:
+            raise ValueError("hvpr_amd: the memory training branch is built for 64 channels, <= 2048 items and SHRINK_TH > 0 (hvpr.yaml:83-85)")
+        mem = _MemoryTrain.apply(positives.reshape(-1, d), self.weight, float(self.shrink_thres)).reshape(nv, k, d)
         agg = torch.softmax((mem * pillars.unsqueeze(1)).sum(dim=2), dim=1)
-        return {"output": (agg.detach().unsqueeze(2) * mem).sum(dim=1), "att": att}
+        return {"output": (agg.detach().unsqueeze(2) * mem).sum(dim=1)}
 
     def extra_repr(self):
         return f"mem_dim={self.mem_dim}, fea_dim={self.fea_dim}"
@@ -110,11 +97,6 @@ class _MemoryTrain(torch.autograd.Function):
                                                               stats.data_ptr(), dx.data_ptr(), dw.data_ptr(), scratch.data_ptr(), ws.data_ptr(),
                                                               ws.numel(), kernels._stream()), "hvpr_memory_train_bwd_f32")
         return dx, dw, None
-
-
-def hard_shrink_relu(x, lambd=0.0, epsilon=1e-12):
-    """relu(x - l) * x / (|x - l| + eps) — memory_module.py:85-87."""
-    return (F.relu(x - lambd) * x) / (torch.abs(x - lambd) + epsilon)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -238,13 +220,9 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         # formed transposed so that the top-k runs along the contiguous dimension.
         with torch.no_grad():
             idx = self._topk_points(pillars.detach(), points.detach())            # (M, k), descending
-        positives = _GatherRows.apply(points, idx) if points.is_cuda else points[idx]      # (M, k, C)
+        positives = _GatherRows.apply(points, idx)                                          # (M, k, C)
         w = torch.softmax(torch.bmm(pillars.unsqueeze(1), positives.transpose(1, 2)).squeeze(1), dim=1)
         return (w.detach().unsqueeze(2) * positives).sum(dim=1), positives
-
-    # CPU tensors have no kernel to run on: the torch form below is a REFERENCE for the host-logic unit tests only and has to be
-    # switched on explicitly (tests/train_fixture_cases.py); the product path raises instead of silently computing on the CPU.
-    allow_torch_reference = False
 
     def _topk_points(self, pillars, points):
         """Indices (M, k) of the k points with the largest pillar . point logits, descending — hvpr_point_pillar_topk_f32: the
@@ -253,9 +231,7 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         k, N = self.k, points.shape[0]
         nb = 1
         if not pillars.is_cuda:
-            if not self.allow_torch_reference:
-                raise RuntimeError("hvpr_amd: get_score needs GPU tensors (the HIP path has no CPU fallback)")
-            return torch.topk(pillars @ points.t(), k, dim=1)[1]
+            raise RuntimeError("hvpr_amd: get_score needs GPU tensors (the HIP path has no CPU fallback)")
         if pillars.shape[1] != 64:
             raise ValueError("hvpr_amd: get_score is built for 64-channel point / pillar features (hvpr.yaml:81)")
         if pillars.shape[0] == 0:

@@ -1,8 +1,6 @@
 """Voxel feature encoders with the reference's plugin interface (pcdet/models/backbones_3d/vfe/):
 same registry keys, constructor kwargs, state-dict names and batch_dict keys; the eval forward is ONE HIP launch
 (hvpr_pillar_vfe_fwd_f32) instead of the reference's chain of PyTorch ops."""
-import os
-
 import torch
 import torch.nn as nn
 
@@ -156,9 +154,9 @@ def _update_running(bn, mean, var, n):
 
 
 def _train_forward(self, batch_dict, voxels, num, coords):
-    """Training forward with batch-statistics BatchNorm and autograd (dense math through torch): the same decoration,
-    masking, two PFN layers and scale stream as the eval kernel (pillar_vfe.py:184-221; BN over all M*P slots, padded
-    slots included — SURVEY.md B.5)."""
+    """Training forward with batch-statistics BatchNorm (pillar_vfe.py:184-221; BN over all M*P slots, padded slots included —
+    SURVEY.md B.5): the two PFN layers, forward and backward, on hvpr_pillar_vfe_train_fwd_f32 / hvpr_pillar_vfe_bwd_f32.
+    Unsupported widths / CPU tensors raise (torch form: tests/torch_forms.py)."""
     md = batch_dict.get("voxel_count_device")
     if md is not None:                      # rows past the live count are unspecified: drop them (one host read per step)
         m = int(md.item())
@@ -166,30 +164,24 @@ def _train_forward(self, batch_dict, voxels, num, coords):
         batch_dict["voxels"], batch_dict["voxel_num_points"], batch_dict["voxel_coords"] = voxels, num, coords
         batch_dict["voxel_count_device"] = None
     n = num.to(voxels.dtype)
-    c = coords.to(voxels.dtype)
     M, P, _ = voxels.shape
     xyz = voxels[:, :, :3]
     mean = xyz.sum(dim=1, keepdim=True) / n.view(-1, 1, 1)
-    vs = voxels.new_tensor(self.voxel_size)
-    off = voxels.new_tensor(self.offsets)
-    centre = c[:, [3, 2, 1]] * vs + off                                  # (M,3) pillar centre in x,y,z
     mask = (torch.arange(P, device=voxels.device).view(1, -1) < num.view(-1, 1)).unsqueeze(-1).to(voxels.dtype)
+    if not (voxels.is_cuda and voxels.dtype == torch.float32):
+        raise RuntimeError("hvpr_amd: PillarVFE_Scale's training forward needs fp32 GPU tensors (the HIP path has no CPU fallback)")
+    if len(self.pfn_layers) != 2:
+        raise ValueError("hvpr_amd: the VFE training kernels are built for two PFN layers (hvpr.yaml NUM_FILTERS: [32, 64])")
     l0, l1 = self.pfn_layers[0], self.pfn_layers[1]
-    hip = (voxels.is_cuda and voxels.dtype == torch.float32 and P == 32 and len(self.pfn_layers) == 2 and M > 0
-           and l0.norm.eps == l1.norm.eps and os.environ.get("HVPR_TRAIN_VFE", "hip") != "torch")
-    if hip:       # both PFN layers, forward and backward, on the library's kernels
-        x, m0, v0, m1, v1 = _PfnTrain.apply(voxels.contiguous(), _as_i32(num).contiguous(), _as_i32(coords).contiguous(),
-                                            l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight,
-                                            l1.norm.bias, l0.norm.eps, self.voxel_size, self.offsets)
+    if tuple(l0.linear.weight.shape) != (16, 10) or tuple(l1.linear.weight.shape) != (64, 32) or l0.norm.eps != l1.norm.eps or P > 32:
+        raise ValueError("hvpr_amd: the VFE training kernels are built for 4 point features, NUM_FILTERS [32, 64], one eps and <= 32 points per pillar")
+    # both PFN layers, forward and backward, on the library's kernels
+    x, m0, v0, m1, v1 = _PfnTrain.apply(voxels.contiguous(), _as_i32(num).contiguous(), _as_i32(coords).contiguous(),
+                                        l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight,
+                                        l1.norm.bias, l0.norm.eps, self.voxel_size, self.offsets)
+    if M > 0:
         _update_running(l0.norm, m0, v0, M * P)
         _update_running(l1.norm, m1, v1, M * P)
-    else:
-        x = torch.cat([voxels, xyz - mean, xyz - centre.unsqueeze(1)], dim=-1) * mask
-        for layer in self.pfn_layers:
-            y = layer.linear(x)
-            y = torch.relu(layer.norm(y.permute(0, 2, 1)).permute(0, 2, 1))
-            ymax = y.max(dim=1, keepdim=True)[0]
-            x = ymax if layer.last_vfe else torch.cat([y, ymax.expand(-1, P, -1)], dim=2)
     s = torch.cat([n.unsqueeze(1), torch.norm(mean, 2, 2), mean.squeeze(1)], dim=-1)
     for seq in self.pfn_scale_layers:
         s = seq(s)

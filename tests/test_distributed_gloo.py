@@ -68,6 +68,8 @@ class _DenseTrainStack:
         cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [0, -2.56, -3, 5.12, 2.56, 1]
         model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg, training=True))
         synthetic_weights.load_synthetic(model, seed=4, cls_bias=-4.595)
+        import torch_forms
+        torch_forms.patch(model)          # CPU: the torch forms of the dense modules (the product's forwards are HIP-only)
 
         class Stack(torch.nn.Module):
             def __init__(self):

@@ -2,6 +2,7 @@
 kernels, train-mode BatchNorm + ReLU and the whole two-stream backbone training forward + backward against torch fp32 autograd
 of the same modules (the form the reference runs: base_bev_backbone.py:228-279).  Tolerance: north_star's 1e-3 relative,
 element-wise with the absolute term tied to the tensor's own rms."""
+import contextlib
 import copy
 import os
 
@@ -112,9 +113,9 @@ def test_backbone_training_forward_backward_hip_equals_torch_autograd():
     sp, spp, sc = canvas(128), canvas(128), canvas(32)
     outs = {}
     ref64 = copy.deepcopy(a).double()                      # the yardstick: the same module in float64 through torch autograd
+    import torch_forms
     for name, m, mode, dt in (("hip", a, "hip", torch.float32), ("torch", b, "torch", torch.float32), ("f64", ref64, "torch", torch.float64)):
-        os.environ["HVPR_TRAIN_CONV"] = mode
-        try:
+        with (torch_forms.patched(m) if mode == "torch" else contextlib.nullcontext()):
             ins = [t.detach().clone().to(dt).requires_grad_(True) for t in (sp, spp, sc)]
             d = m({"spatial_features": ins[0], "spatial_features_point": ins[1], "spatial_scale_features": ins[2]})
             f, fp = d["spatial_features_2d"], d["spatial_features_point_2d"]
@@ -122,8 +123,6 @@ def test_backbone_training_forward_backward_hip_equals_torch_autograd():
             loss.backward()
             outs[name] = (f.detach(), fp.detach(), [t.grad for t in ins], {k: p.grad for k, p in m.named_parameters()},
                           {k: v.detach().clone() for k, v in m.named_buffers()})
-        finally:
-            os.environ.pop("HVPR_TRAIN_CONV", None)
     h, t, r = outs["hip"], outs["torch"], outs["f64"]
     assert h[0].shape == (2, 384, 64, 80)
     _close(h[0], r[0], what="spatial_features_2d")                  # forward: element-wise 1e-3 against float64

@@ -49,7 +49,7 @@ def _g4_train_setup(golden_dir, tag):
 
 
 def _op_names(cfg):
-    """Call order of the activations the training forward produces (bev_backbone._forward_train_hip = base_bev_backbone.py:242-262)."""
+    """Call order of the activations the training forward produces (bev_backbone._forward_train = base_bev_backbone.py:242-262)."""
     names = []
     for i, (n, ns) in enumerate(zip(cfg.LAYER_NUMS, cfg.SFM_LAYER_NUMS)):
         names += [f"L{i}.x.block{k}" for k in range(n + 1)] + [f"L{i}.xp.block{k}" for k in range(n + 1)] + [f"L{i}.y"]

@@ -130,7 +130,8 @@ def test_memory_train_forward_backward_match_the_reference_formula(R, n_items, s
     """hvpr_memory_train_fwd/bwd vs torch autograd (float64) of memory_module.py:36-48 + hard_shrink_relu :85-87.  `scale` sets
     the feature norm: small -> every softmax value is below the shrink threshold (empty support: zero output, zero gradients),
     large -> a few items per row survive."""
-    from hvpr_amd.map_to_bev import _MemoryTrain, hard_shrink_relu
+    from hvpr_amd.map_to_bev import _MemoryTrain
+    from torch_forms import hard_shrink_relu
     g = torch.Generator().manual_seed(R + n_items)
     x = (torch.relu(torch.randn(R, 64, generator=g)) * scale / 4).to(DEV).requires_grad_(True)
     w = ((torch.rand(n_items, 64, generator=g) * 2 - 1) / 8).to(DEV).requires_grad_(True)
@@ -197,7 +198,9 @@ def test_pillar_vfe_train_fwd_bwd_match_float64_autograd(M):
         for layer in mod.pfn_layers:
             layer.norm.weight.copy_(torch.rand(layer.norm.weight.shape, generator=g) + 0.5)
             layer.norm.bias.copy_(torch.randn(layer.norm.bias.shape, generator=g) * 0.3)
+    import torch_forms
     ref = copy.deepcopy(mod).double().to(DEV)
+    torch_forms.patch(ref)                                               # the torch form of the same module (tests/torch_forms.py)
     mod = mod.to(DEV)
     P = 32
     num = torch.randint(1, 9, (M,), generator=g)
@@ -216,7 +219,6 @@ def test_pillar_vfe_train_fwd_bwd_match_float64_autograd(M):
         (out * dfeat.to(DEV, dtype)).sum().backward()
         return out
 
-    import os
     o_ref = run(ref, torch.float64)
     o_hip = run(mod, torch.float32)
     scale = float(o_ref.abs().max())
@@ -231,11 +233,8 @@ def test_pillar_vfe_train_fwd_bwd_match_float64_autograd(M):
         assert float((l_h.norm.running_mean.double() - l_r.norm.running_mean).abs().max()) < 1e-6
         assert float((l_h.norm.running_var.double() - l_r.norm.running_var).abs().max()) < 1e-5 * float(l_r.norm.running_var.abs().max())
         assert int(l_h.norm.num_batches_tracked) == 1
-    # the torch form of the same module (HVPR_TRAIN_VFE=torch) stays available as the parity reference of the suite
-    os.environ["HVPR_TRAIN_VFE"] = "torch"
-    try:
+    # the torch form in fp32 on the same module sits in the same band
+    with torch_forms.patched(mod):
         mod.zero_grad()
         o_t = run(mod, torch.float32)
-    finally:
-        del os.environ["HVPR_TRAIN_VFE"]
     assert float((o_t.double() - o_ref).abs().max()) < 2e-5 * scale

@@ -20,9 +20,9 @@ def test_g10_point_pillar_attention_and_memory_train_branch(golden_dir):
     C.run_g10(golden_dir)
 
 
-def test_training_ops_refuse_cpu_tensors_unless_the_reference_form_is_switched_on():
-    """The product path has no CPU fallback: get_score / the memory training branch raise on CPU tensors; the torch reference
-    forms the fixtures above run through are opt-in."""
+def test_training_modules_refuse_cpu_tensors():
+    """The product path has no CPU fallback: get_score / the memory training branch / the backbone, head and VFE training forwards
+    raise on CPU tensors; the torch forms the fixtures above run through live in tests/torch_forms.py."""
     import numpy as np
     import pytest
     import torch
@@ -34,3 +34,18 @@ def test_training_ops_refuse_cpu_tensors_unless_the_reference_form_is_switched_o
         m.get_score(torch.randn(100, 64), torch.randn(5, 64))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.memory(torch.randn(5, 64), 20, torch.randn(5, 20, 64))
+    # the dense training modules as well: no silent torch path on CPU tensors
+    from hvpr_amd import detector
+    from hvpr_amd.config import hvpr_car_cfg
+    import copy
+    cfg = copy.deepcopy(hvpr_car_cfg())
+    cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [0, -2.56, -3, 5.12, 2.56, 1]
+    model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg, training=True)).train()
+    canv = {"spatial_features": torch.randn(1, 128, 32, 32), "spatial_features_point": torch.randn(1, 128, 32, 32),
+            "spatial_scale_features": torch.randn(1, 32, 32, 32)}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.backbone_2d(dict(canv))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.dense_head({"spatial_features_2d": torch.randn(1, 384, 32, 32), "spatial_features_point_2d": torch.randn(1, 384, 32, 32)})
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.vfe({"voxels": torch.rand(3, 32, 4), "voxel_num_points": torch.tensor([1, 2, 3]), "voxel_coords": torch.zeros(3, 4)})
