@@ -263,23 +263,69 @@ def extra_group_lines(device):
     return out
 
 
-def train_step_line(device, batch=16, steps=3, warmup=2):
-    """BASELINE.json configs[2]: hvpr_car full train step (a1..a15: fwd + bwd + Adam-onecycle), 16 frames per step, a bounded
-    number of steps; MFMA fraction against 2.71 TFLOP/frame of convolution work."""
+def train_conv_flops(model, H, W):
+    """Direct-convolution FLOPs (2 * MACs) of ONE frame's training step through the backbone and head — forward, data gradient and
+    weight gradient of BOTH streams (the scale stream once) — and the part of them that is EXECUTED: the stride-1 3x3 layers run
+    forward, data gradient and weight gradient in the Winograd F(2x2,3x3) domain (16 of 36 multiplies); the stride-2 data gradient
+    runs Winograd on the zero-upsampled gradient (4 x 16/36 of its direct count)."""
+    bb = model.backbone_2d
+    direct = executed = 0.0
+    h, w = H, W
+    for i, blk in enumerate(bb.blocks):
+        s = bb.layer_strides[i]
+        h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        px = h * w
+
+        def add(cin, cout, stride, streams):
+            nonlocal direct, executed
+            f = 2.0 * cin * cout * 9 * px * streams
+            direct += 3 * f                                   # fwd + dgrad + wgrad
+            if stride == 1:
+                executed += 3 * f * 16.0 / 36.0
+            else:
+                executed += f + f + 4 * f * 16.0 / 36.0 * stride * stride / 4    # fwd, wgrad direct; dgrad on the upsampled gradient
+        convs = [m for m in blk if isinstance(m, torch.nn.Conv2d)]
+        for c in convs:
+            add(c.in_channels, c.out_channels, c.stride[0], 2)
+        sf = bb.sfmblocks_down[i][0]
+        for _ in range(bb.sfm_layer_nums[i]):
+            add(sf.in_channels, sf.out_channels, 1, 2)
+        sc = bb.scale_layers[i][1]
+        add(sc.in_channels, sc.out_channels, sc.stride[0], 1)
+        de = bb.deblocks[i][0]
+        f = 2.0 * de.in_channels * de.out_channels * px * int(bb.upsample_strides[i]) ** 2 * 2
+        direct += 3 * f
+        executed += 3 * f
+    head = model.dense_head
+    for c in (head.conv_cls, head.conv_box, head.conv_dir_cls):
+        f = 2.0 * c.in_channels * c.out_channels * H * W * 2
+        direct += 3 * f
+        executed += 3 * f
+    return direct, executed
+
+
+def train_step_line(device, which="car", batch=16, steps=3, warmup=2):
+    """BASELINE.json configs[2] (which="car", batch 16) / configs[3] per GPU (which="3class", batch 8): the full train step
+    (a1..a15: fwd + bwd + Adam-onecycle), a bounded number of steps; matrix-core fraction from the executed convolution FLOPs."""
     from hvpr_amd import optim
-    cfg = hvpr_car_cfg()
-    model = detector.build_network(cfg.MODEL, len(cfg.CLASS_NAMES), detector.SyntheticDataset(cfg, training=True))
+    from hvpr_amd.config import hvpr_3class_cfg
+    cfg = hvpr_car_cfg() if which == "car" else hvpr_3class_cfg()
+    n_class = len(cfg.CLASS_NAMES)
+    ds = detector.SyntheticDataset(cfg, training=True)
+    model = detector.build_network(cfg.MODEL, n_class, ds)
     synthetic_weights.load_synthetic(model, seed=0, cls_bias=-4.59511985013459)
     model = model.to(device)
     opt = optim.build_optimizer(model, cfg.OPTIMIZATION)
     sched, _ = optim.build_scheduler(opt, total_iters_each_epoch=steps + warmup, total_epochs=1, last_epoch=-1, optim_cfg=cfg.OPTIMIZATION)
     rng = np.random.default_rng(0)
+    sizes = np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]], np.float32)
 
     def gt(B, per=8):
         g = np.zeros((B, per, 8), np.float32)
+        cls = rng.integers(0, n_class, (B, per))
         g[..., 0] = rng.uniform(3, 44, (B, per)); g[..., 1] = rng.uniform(-17, 17, (B, per)); g[..., 2] = rng.uniform(-1.2, -0.8, (B, per))
-        g[..., 3:6] = np.array([3.9, 1.6, 1.56], np.float32) * rng.uniform(0.9, 1.1, (B, per, 3))
-        g[..., 6] = rng.uniform(-np.pi, np.pi, (B, per)); g[..., 7] = 1
+        g[..., 3:6] = sizes[cls] * rng.uniform(0.9, 1.1, (B, per, 3))
+        g[..., 6] = rng.uniform(-np.pi, np.pi, (B, per)); g[..., 7] = cls + 1
         return g
     pool = []
     for k in range(2):
@@ -290,29 +336,37 @@ def train_step_line(device, batch=16, steps=3, warmup=2):
     torch.cuda.reset_peak_memory_stats()
     losses = []
     # batches one ahead (optim.prefetching): the point-stream index kernels (FPS, ball query, three-NN) of batch i + 1 run on a side
-    # stream beside step i; warmup + steps + 1 batches are fed so that every timed step also enqueues its successor's
+    # stream beside step i.  The generator enqueues the index work of batch i + 1 BEFORE it yields batch i, so the clock starts
+    # when batch `warmup - 1` has been stepped (its successor's index work is then enqueued inside the timed region) and stops
+    # after step warmup + steps - 1, whose own successor's index work was enqueued inside as well: `steps` index plans, `steps`
+    # steps.
     t0 = 0.0
     for it, b in enumerate(optim.prefetching(model, (dict(pool[i % 2]) for i in range(warmup + steps + 1)))):
         if it == warmup + steps:
             break
-        if it == warmup:
+        loss, _ = optim.train_step(model, opt, sched, b, it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        if it == warmup - 1:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        loss, _ = optim.train_step(model, opt, sched, b, it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
         if it >= warmup:
             losses.append(loss)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    flops_frame = 2.71e12
-    res = {"workload": f"hvpr_car.yaml full train step a1..a15, batch={batch}, 8 GT boxes/frame, {warmup} warm-up + {steps} timed steps",
+    direct, executed = train_conv_flops(model, int(ds.grid_size[1]), int(ds.grid_size[0]))
+    res = {"workload": f"hvpr_{which}.yaml full train step a1..a15, batch={batch}, 8 GT boxes/frame, {warmup} warm-up + {steps} timed steps",
            "steps_per_s": round(1.0 / dt, 3), "frames_per_s": round(batch / dt, 2), "ms_per_step": round(1e3 * dt, 1),
-           "conv_TFLOPs": round(flops_frame * batch / dt / 1e12, 1), "mfma_frac_of_f32_peak": round(flops_frame * batch / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-           "flops_note": "direct-convolution count, 2.71 TFLOP per frame (fwd + dgrad + wgrad); the stride-1 3x3 forward and data-gradient "
-                         "convolutions run on the Winograd kernel and execute 16/36 of theirs",
+           "conv_direct_TFLOP_per_step": round(direct * batch / 1e12, 2), "conv_executed_TFLOP_per_step": round(executed * batch / 1e12, 2),
+           "mfma_executed_TFLOPs": round(executed * batch / dt / 1e12, 1),
+           "mfma_frac_of_f32_peak": round(executed * batch / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+           "mfma_frac_direct_count": round(direct * batch / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+           "flops_note": "mfma_frac_of_f32_peak = convolution FLOPs actually EXECUTED on the fp32 matrix cores (Winograd layers: 16/36 of "
+                         "their direct count, forward, data gradient and weight gradient) / step time / 157.3; mfma_frac_direct_count = the "
+                         "direct-convolution count over the same time (may exceed what is executed by 2.25x on the Winograd layers)",
            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-           "kernels": "backbone conv fwd/dgrad (Winograd F(2x2,3x3) where 3x3 stride 1) /wgrad + train-mode BN on the library's HIP kernels (HVPR_TRAIN_CONV=hip), memory addressing on "
-                      "hvpr_memory_train_*, flat fused Adam; head 1x1 convs / PointNet++ MLPs / losses through torch"}
+           "kernels": "every training module on the library's HIP kernels: voxelizer, point-stream index ops + gathers, VFE forward/backward, "
+                      "get_score top-k, memory addressing, scatter, backbone + head convolutions fwd/dgrad/wgrad (Winograd F(2x2,3x3) where 3x3 "
+                      "stride 1), train-mode BatchNorm, flat fused Adam; target assigner + losses are device-side torch code"}
     del model, opt, pool
     torch.cuda.empty_cache()
     return res
@@ -332,6 +386,8 @@ def main():
     ap.add_argument("--conv-precision", choices=["fp32", "bf16x3", "bf16x6"], default="fp32",
                     help="fp32: exact fp32 matrix-core convolutions; bf16x3: 3-term split-bf16 trunk/SFM convolutions")
     ap.add_argument("--skip-single", action="store_true", help="profiling: do not time the single-graph latency mode")
+    ap.add_argument("--alt", action="store_true", help="also time the opt-in modes (bf16x6 / bf16x3 split-precision convolutions, direct "
+                    "fp32 convolutions) and report them as `alt_precision` (never `value`); off by default: three more pipelines")
     ap.add_argument("--cls-bias", type=float, default=-4.59511985013459, help="conv_cls.bias of the synthetic weights")
     args = ap.parse_args()
 
@@ -410,7 +466,7 @@ def main():
                         "on three HIP streams (frame latency = 3 steps)")
 
         dt_rank = dt_local[0]      # this rank's own time of the headline run (`dt` is the max over ranks)
-        if not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32" and not args.skip_single:
+        if args.alt and not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32":
             # reported next to the headline, never as `value`: the same pipeline with the trunk/SFM 3x3 convolutions on the bf16
             # matrix cores with split operands
             alt = []
@@ -574,7 +630,8 @@ def main():
         del model, batches, staged
         torch.cuda.empty_cache()
         res["group_other_configs"] = extra_group_lines(device)
-        res["train_step"] = train_step_line(device)
+        res["train_step"] = train_step_line(device, "car", 16)
+        res["train_step_3class_b8"] = train_step_line(device, "3class", 8)          # BASELINE.json configs[3], one GPU's share
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, params)
     else:

@@ -76,9 +76,11 @@ def main():
     rng = np.random.default_rng(rank)
     pool = [make_batch(rank * 1000 + 100 * i, args.batch, device, rng, len(cfg.CLASS_NAMES)) for i in range(2)]
     losses = []
-    # batches come one ahead (optim.prefetching): the point-stream index kernels of batch i + 1 run beside step i; one batch more
-    # than steps is fed so that every timed step also enqueues the index work of its successor (nothing is moved out of the
-    # timed region).  --no-prefetch: the plain loop.
+    # batches come one ahead (optim.prefetching): the generator enqueues the point-stream index kernels of batch i + 1 on a side
+    # stream BEFORE it yields batch i.  The clock therefore starts right after step warmup - 1 (so that the index work of batch
+    # warmup + 1 is enqueued inside the timed region) and stops after step warmup + steps - 1: `steps` steps and `steps` index
+    # plans are inside, nothing is moved out of the timed region.  --no-prefetch: the plain loop.
+    assert args.warmup >= 1
     n_all = args.warmup + args.steps
     feed = (dict(pool[i % 2]) for i in range(n_all + 1))
     batches = feed if args.no_prefetch else optim.prefetching(model, feed)
@@ -86,11 +88,11 @@ def main():
     for it, b in enumerate(batches):
         if it == n_all:
             break
-        if it == args.warmup:
+        loss, _ = optim.train_step(model, opt, sched, b, it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+        if it == args.warmup - 1:
             distributed.barrier(device)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        loss, _ = optim.train_step(model, opt, sched, b, it, cfg.OPTIMIZATION.GRAD_NORM_CLIP)
         if it >= args.warmup:
             losses.append(loss)
     distributed.barrier(device)
