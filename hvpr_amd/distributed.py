@@ -132,8 +132,10 @@ def wrap_ddp(model, device):
     """Data-parallel training wrapper (reference: tools/train.py:143-145): one process per GPU, gradient all-reduce over
     RCCL ("nccl" backend) overlapped with backward in ~25 MB buckets; the ~62 MB of fp32 gradients take ~0.7 ms on the
     8-GPU xGMI ring, far below the backward time.  find_unused_parameters stays False: every parameter of
-    the training graph gets a gradient."""
+    the training graph gets a gradient.  gradient_as_bucket_view stays False (torch's default, what the reference's train.py
+    gets): DDP then writes the reduced buckets back INTO the existing p.grad tensors, which with FusedAdamOneCycle are views of
+    its flat gradient buffer — p.grad keeps its address and the optimiser steps straight from the flat buffer."""
     if not dist.is_initialized():
         return model
     ids = [device.index] if device.type == "cuda" else None
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, broadcast_buffers=True, gradient_as_bucket_view=True)
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, broadcast_buffers=True, gradient_as_bucket_view=False)

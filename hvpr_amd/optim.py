@@ -122,7 +122,8 @@ class FusedAdamOneCycle:
         rest, bn = split_bn_params(model)
         self.params = rest + bn
         self.n_rest = len(rest)
-        assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), "FusedAdamOneCycle: fp32 parameters on the GPU"
+        assert self.params and all(p.dtype == torch.float32 for p in self.params), "FusedAdamOneCycle: fp32 parameters"
+        assert len({p.device for p in self.params}) == 1, "FusedAdamOneCycle: one device"
         dev = self.params[0].device
         self.offsets, off = [], 0
         for p in self.params:
@@ -157,14 +158,23 @@ class FusedAdamOneCycle:
                 {"params": self.params[self.n_rest:], "lr": self._lr, "betas": (self._mom, self.beta2)}]
 
     def zero_grad(self):
+        """Gradients are zeroed, never set to None: autograd then accumulates in place into the flat views, and p.grad keeps its
+        address from step to step.  Under DistributedDataParallel(gradient_as_bucket_view=True) DDP owns p.grad (a view into its
+        all-reduce bucket): such a gradient is zeroed where it lives instead of being re-pointed (re-pointing made DDP copy the
+        whole gradient set into its buckets and re-point back every step), and _collect_grads copies the reduced values in."""
         self.flat_g.zero_()
-        self._point_grads()
+        for p, g in zip(self.params, self._grad_views):
+            if p.grad is None:
+                p.grad = g
+            elif p.grad.data_ptr() != g.data_ptr():
+                p.grad.zero_()
         self._scale = None
 
     @torch.no_grad()
     def _collect_grads(self):
-        """Gradients normally accumulate straight into the flat buffer; anything that re-pointed p.grad (DDP bucket views, a
-        zero_grad(set_to_none) elsewhere) is copied back in."""
+        """Gradients normally accumulate straight into the flat buffer (also under DDP's default gradient_as_bucket_view=False,
+        which copies the reduced bucket back into the existing p.grad); a gradient that lives elsewhere (DDP bucket views) is
+        copied in."""
         for p, g in zip(self.params, self._grad_views):
             if p.grad is None:
                 g.zero_()
@@ -182,15 +192,21 @@ class FusedAdamOneCycle:
 
     @torch.no_grad()
     def step(self):
-        from ._lib import check, lib
         if self._scale is None:
             self._collect_grads()
         self.steps += 1
+        self._launch()
+        self._scale = None
+
+    def _launch(self):
+        """ONE launch of hvpr_fused_adam_truewd_f32 over the flat buffers."""
+        from ._lib import check, lib
+        if not self.flat_p.is_cuda:
+            raise RuntimeError("hvpr_amd: FusedAdamOneCycle steps on the GPU (the HIP path has no CPU fallback)")
         check(lib().hvpr_fused_adam_truewd_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                                self.exp_avg_sq.data_ptr(), self.numel, self._lr, self._mom, self.beta2, self.eps,
                                                self.wd, self.steps, None if self._scale is None else self._scale.data_ptr(),
                                                self._kernels._stream()), "hvpr_fused_adam_truewd_f32")
-        self._scale = None
 
     def state_dict(self):
         state = {}

@@ -138,6 +138,106 @@ def test_ddp_gradients_are_the_rank_mean():
         assert n > 20 and worst < 1e-4, (rank, n, worst)
 
 
+# ------------------------------------------------------------------------------------------------ a14 + a15: flat optimiser under DDP
+def _flat_adam_on_cpu(opt):
+    """TEST stand-in for the ONE kernel launch of FusedAdamOneCycle._launch (hvpr_fused_adam_truewd_f32, csrc/train_ops.hip): the
+    same arithmetic with torch ops on the flat buffers.  Everything around it — the flat parameter / gradient views, zero_grad,
+    the gradient collection under DDP, the device-side clip scale — is the product's code and is what this test exercises."""
+    import math
+    import torch
+    gs = 1.0 if opt._scale is None else float(opt._scale)
+    g = opt.flat_g * gs
+    bc1, bc2 = 1.0 - opt._mom ** opt.steps, 1.0 - opt.beta2 ** opt.steps
+    opt.flat_p.mul_(1.0 - opt.wd * opt._lr)
+    opt.exp_avg.add_((g - opt.exp_avg) * (1.0 - opt._mom))
+    opt.exp_avg_sq.mul_(opt.beta2).add_((1.0 - opt.beta2) * g * g)
+    opt.flat_p.sub_((opt._lr / bc1) * opt.exp_avg / (opt.exp_avg_sq.sqrt() / math.sqrt(bc2) + opt.eps))
+
+
+def _flat_opt_worker(rank, world, port, q, bucket_view):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import copy
+    import types
+    import torch
+    torch.set_num_threads(2)
+    from hvpr_amd import distributed, optim
+    distributed.init("gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, bias=False), torch.nn.BatchNorm2d(8), torch.nn.ReLU(), torch.nn.Flatten(),
+                              torch.nn.Linear(8 * 6 * 6, 4))
+    ref_nets = [copy.deepcopy(net) for _ in range(world)]                # what each rank would compute alone
+    if bucket_view:
+        ddp = torch.nn.parallel.DistributedDataParallel(net, gradient_as_bucket_view=True)
+    else:
+        ddp = distributed.wrap_ddp(net, torch.device("cpu"))
+        assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    opt = optim.FusedAdamOneCycle(ddp, wd=0.01)
+    opt._launch = types.MethodType(_flat_adam_on_cpu, opt)
+    ref = copy.deepcopy(net)                                             # same weights (views into flat_p are deep-copied as tensors)
+    ref_opt = optim.AdamOneCycle(ref, wd=0.01)
+    xs = [[torch.randn(5, 3, 8, 8, generator=torch.Generator().manual_seed(100 * it + r)) for r in range(world)] for it in range(4)]
+    ptrs, worst = [], 0.0
+    for it in range(4):
+        opt.zero_grad()
+        ddp(xs[it][rank]).pow(2).mean().backward()
+        ptrs.append([p.grad.data_ptr() for p in opt.params])
+        opt.clip_grad_norm(0.05)
+        opt.step()
+        # reference: the rank-mean gradient through the per-tensor optimiser
+        ref_opt.zero_grad()
+        grads = []
+        for r in range(world):
+            m = copy.deepcopy(ref).train()
+            m(xs[it][r]).pow(2).mean().backward()
+            grads.append([p.grad for p in m.parameters()])
+        ref.train()
+        ref(xs[it][rank])                                               # running statistics of this rank's own batch, as DDP keeps them
+        for i, p in enumerate(ref.parameters()):
+            p.grad = sum(g[i] for g in grads) / world
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+        ref_opt.step()
+        for a, b in zip(net.parameters(), ref.parameters()):
+            worst = max(worst, float((a.detach() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-12)))
+    own = [g.data_ptr() for g in opt._grad_views]
+    # DDP itself rebuilds its buckets once, after the first backward (gradient-ready order): with bucket views the addresses may
+    # move between step 0 and step 1, never afterwards
+    first = 1 if bucket_view else 0
+    stable = all(p == ptrs[first] for p in ptrs[first:])
+    in_flat = ptrs[0] == own
+    distributed.finalize()
+    q.put((rank, stable, in_flat, worst))
+
+
+def _run_flat_opt(bucket_view):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_opt_worker, args=(r, 2, port, q, bucket_view)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    return sorted(q.get(timeout=10) for _ in procs)
+
+
+def test_flat_optimizer_under_ddp_keeps_grad_addresses_and_matches_adam_onecycle():
+    """FusedAdamOneCycle inside DistributedDataParallel, two gloo ranks: p.grad keeps ONE address over the steps (no re-pointing
+    between the optimiser and DDP), with wrap_ddp's setting the gradients live in the optimiser's own flat buffer, and four
+    clipped steps equal AdamOneCycle on the rank-mean gradients."""
+    for rank, stable, in_flat, worst in _run_flat_opt(bucket_view=False):
+        assert stable and in_flat, (rank, stable, in_flat)
+        assert worst < 2e-5, (rank, worst)
+
+
+def test_flat_optimizer_under_ddp_bucket_views():
+    """The same with gradient_as_bucket_view=True (DDP owns p.grad): addresses stay stable as well — zero_grad zeroes the bucket
+    views in place instead of re-pointing — and the results are the same."""
+    for rank, stable, in_flat, worst in _run_flat_opt(bucket_view=True):
+        assert stable, rank
+        assert worst < 2e-5, (rank, worst)
+
+
 # ------------------------------------------------------------------------------------------------ the --gpus N launcher
 def test_launch_local_two_ranks(tmp_path):
     """distributed.launch_local — what `bench.py --gpus N` / `tools/bench_train.py --gpus N` call when WORLD_SIZE is unset:

@@ -10,12 +10,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_one_rank_rccl_group_ddp_and_fused_optimizer(tmp_path):
+def test_one_rank_rccl_group_real_detector_in_ddp_with_fused_optimizer(tmp_path):
+    """Row a15 on the hardware this pool has: the real MixAnchor_Memory inside DistributedDataParallel over a one-rank RCCL group,
+    FusedAdamOneCycle + the point-index prefetch, three steps — against the same steps without DDP.  The gradients stay in the
+    optimiser's flat buffer under DDP (no re-pointing); DDP vs plain may differ only by what two plain runs differ by (float
+    atomics in the scatter-add gradients), bounded at 1e-4 of each tensor's scale after three steps."""
     from hvpr_amd import distributed
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_worker.py")
     out = tmp_path / "rank0.json"
-    rc = distributed.launch_local(1, [worker, str(out)], timeout=600)
+    rc = distributed.launch_local(1, [worker, str(out)], timeout=900)
     assert rc == 0
     r = json.load(open(out))
-    assert r["backend"] == "nccl" and r["seen"] == 1 and r["ddp"] == "DistributedDataParallel" and r["slowest"] == 1.5
-    assert all(np.isfinite(r["losses"]))
+    print(r)
+    assert r["backend"] == "nccl" and r["seen"] == 1 and r["ddp"] == "DistributedDataParallel" and r["plain"] == "MixAnchor_Memory"
+    assert r["slowest"] == 1.5
+    assert r["grads_in_flat_buffer_plain"] and r["grads_in_flat_buffer_ddp"]
+    assert all(np.isfinite(r["losses_ddp"])) and len(r["losses_ddp"]) == 3
+    np.testing.assert_allclose(r["losses_ddp"], r["losses_plain"], rtol=1e-5)
+    assert r["state_diff_ddp_vs_plain"] <= max(1e-4, 3 * r["state_diff_rerun_vs_plain"]), r
