@@ -48,6 +48,15 @@ SIGNATURES = {
     "hvpr_group_points_grad_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "hvpr_three_interpolate_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "hvpr_three_interpolate_grad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "hvpr_group_rows_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "hvpr_group_rows_grad_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "hvpr_max_samples_f32": (_I, [_P, _c.c_longlong, _I, _I, _P, _P, _P]),
+    "hvpr_max_samples_grad_f32": (_I, [_P, _P, _c.c_longlong, _I, _I, _P, _P]),
+    "hvpr_fp_rows_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "hvpr_fp_rows_grad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "hvpr_spatial_gate_train_workspace_bytes": (_Z, [_I, _I, _I]),
+    "hvpr_spatial_gate_train_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "hvpr_spatial_gate_train_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "hvpr_conv2d_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "hvpr_conv2d_wgrad_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _Z, _P]),
     "hvpr_bn_workspace_bytes": (_Z, [_c.c_longlong, _I]),

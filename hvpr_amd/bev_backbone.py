@@ -224,12 +224,16 @@ class BaseBEVBackbone_Scale(nn.Module):
                 k += 3
             return t
 
-        def gate(pooled):
-            """SpatialAttention on the pooled scale stream (spatial_attention.py:57-63): a 2 -> 1 channel 3x3 conv + BatchNorm +
-            sigmoid on a (N,2,H,W) tensor — left to torch; called once per use, as the reference does, so that its BatchNorm
-            sees the same number of running-statistics updates."""
+        def gate(y, uses):
+            """SpatialAttention on the scale stream (spatial_attention.py:57-63) with batch statistics, forward and backward on
+            hvpr_spatial_gate_train_*: ChannelPool -> conv3x3 2 -> 1 -> BatchNorm2d(1) -> sigmoid.  The reference calls the module
+            once per SFM step and stream with the SAME input (:250-257): the values are identical every time, so the gate is
+            computed once per level (its gradient accumulates over the uses through autograd) and the BatchNorm's running
+            statistics receive the `uses` identical updates in closed form."""
             sp = self.attention.spatial
-            return torch.sigmoid(sp.norm(sp.conv(pooled))).permute(0, 2, 3, 1).contiguous()       # (N,H,W,1)
+            g, mean, var = ct.spatial_gate_train(y, sp.conv.weight, sp.conv.bias, sp.norm.weight, sp.norm.bias, sp.norm.eps)
+            ct.update_running_repeated(sp.norm, mean, var, y.numel() // y.shape[-1], uses)
+            return g                                                                       # (N,H,W,1)
 
         x, xp = nhwc(data_dict["spatial_features"]), nhwc(data_dict["spatial_features_point"])
         y = nhwc(data_dict["spatial_scale_features"])
@@ -238,11 +242,13 @@ class BaseBEVBackbone_Scale(nn.Module):
             x = cbr(self.blocks[i], x)
             xp = cbr(self.blocks[i], xp)
             y = cbr(self.scale_layers[i], y)
-            pooled = torch.cat((y.amax(dim=-1, keepdim=True), y.mean(dim=-1, keepdim=True)), dim=-1).permute(0, 3, 1, 2)
             xa, xpa = x, xp
-            for _ in range(self.sfm_layer_nums[i]):
-                xa = cbr(self.sfmblocks_down[i], xa, gate=gate(pooled), resid=xa)
-                xpa = cbr(self.sfmblocks_down[i], xpa, gate=gate(pooled), resid=xpa)
+            nsfm = self.sfm_layer_nums[i]
+            if nsfm > 0:
+                g = gate(y, 2 * nsfm)
+                for _ in range(nsfm):
+                    xa = cbr(self.sfmblocks_down[i], xa, gate=g, resid=xa)
+                    xpa = cbr(self.sfmblocks_down[i], xpa, gate=g, resid=xpa)
             de = self.deblocks[i]
             ups.append(ct.bn_relu(ct.deconv(xa, de[0].weight), de[1]))
             ups_p.append(ct.bn_relu(ct.deconv(xpa, de[0].weight), de[1]))

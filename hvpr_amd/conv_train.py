@@ -313,3 +313,69 @@ def bn_relu(z, bn, relu=True, gate=None, resid=None, partials=None):
             bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
             bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
     return y
+
+
+class _GateTrain(torch.autograd.Function):
+    """SpatialAttention with batch statistics on hvpr_spatial_gate_train_fwd/bwd_f32 (csrc/gate_train.hip): y (N,H,W,C) ->
+    gate (N,H,W,1) = sigmoid(BN_train(conv3x3_{2->1}(cat[max_c y, mean_c y]) + bias)); spatial_attention.py:47-63."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, gamma, beta, eps):
+        y = y.contiguous()
+        N, H, W, C = y.shape
+        dev = y.device
+        w18 = weight.detach().reshape(18).contiguous()
+        b, g_, be = bias.detach().reshape(1).contiguous(), gamma.detach().reshape(1).contiguous(), beta.detach().reshape(1).contiguous()
+        pooled = torch.empty((N, H, W, 2), dtype=torch.float32, device=dev)
+        argmax = torch.empty((N, H, W), dtype=torch.int32, device=dev)
+        a = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+        stats = torch.empty(3, dtype=torch.float32, device=dev)
+        gate = torch.empty((N, H, W, 1), dtype=torch.float32, device=dev)
+        ws = _workspace(lib().hvpr_spatial_gate_train_workspace_bytes(N, H, W), dev)
+        check(lib().hvpr_spatial_gate_train_fwd_f32(kernels._ptr(y, torch.float32, "y"), N, H, W, C, w18.data_ptr(), b.data_ptr(), g_.data_ptr(),
+                                                    be.data_ptr(), float(eps), pooled.data_ptr(), argmax.data_ptr(), a.data_ptr(),
+                                                    stats.data_ptr(), gate.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()),
+              "hvpr_spatial_gate_train_fwd_f32")
+        ctx.save_for_backward(gate, a, stats, pooled, argmax, w18, g_)
+        ctx.dims = (N, H, W, C)
+        ctx.wshape = tuple(weight.shape)
+        mean, var = stats[0:1], stats[1:2]
+        ctx.mark_non_differentiable(mean, var)
+        return gate, mean, var
+
+    @staticmethod
+    def backward(ctx, dgate, _dm, _dv):
+        gate, a, stats, pooled, argmax, w18, g_ = ctx.saved_tensors
+        N, H, W, C = ctx.dims
+        dev = gate.device
+        dgate = dgate.contiguous()
+        dy = torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
+        dw = torch.empty(18, dtype=torch.float32, device=dev)
+        db, dgam, dbet = (torch.empty(1, dtype=torch.float32, device=dev) for _ in range(3))
+        ws = _workspace(lib().hvpr_spatial_gate_train_workspace_bytes(N, H, W), dev)
+        check(lib().hvpr_spatial_gate_train_bwd_f32(kernels._ptr(dgate, torch.float32, "dgate"), gate.data_ptr(), a.data_ptr(), stats.data_ptr(),
+                                                    pooled.data_ptr(), argmax.data_ptr(), w18.data_ptr(), g_.data_ptr(), N, H, W, C, dy.data_ptr(),
+                                                    dw.data_ptr(), db.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                    kernels._stream()), "hvpr_spatial_gate_train_bwd_f32")
+        return dy, dw.view(ctx.wshape), db, dgam, dbet, None
+
+
+def spatial_gate_train(y, weight, bias, gamma, beta, eps):
+    """-> (gate (N,H,W,1), batch mean (1,), biased batch variance (1,)) of SpatialAttention in training mode."""
+    return _GateTrain.apply(y, weight, bias, gamma, beta, eps)
+
+
+def update_running_repeated(bn, mean, var, n, times):
+    """`times` running-statistics updates of nn.BatchNorm with the SAME batch statistics, in closed form:
+    r <- (1 - m)^k r + (1 - (1 - m)^k) s; num_batches_tracked += k."""
+    if not bn.track_running_stats or times < 1:
+        return
+    with torch.no_grad():
+        if bn.momentum is None:      # cumulative average: every update is its own step
+            for _ in range(times):
+                _update_running(bn, mean, var, n)
+            return
+        keep = (1.0 - bn.momentum) ** times
+        bn.num_batches_tracked += times
+        bn.running_mean.mul_(keep).add_(mean.view_as(bn.running_mean), alpha=1.0 - keep)
+        bn.running_var.mul_(keep).add_(var.view_as(bn.running_var), alpha=(1.0 - keep) * n / max(n - 1, 1))

@@ -4,7 +4,9 @@
     C-ABI: furthest point sampling, ball query, three-NN (indices) and grouping / gather / three-interpolate with their
     backward (autograd.Function over hvpr_group_points_f32 / hvpr_three_interpolate_f32 and their _grad twins);
   * PointnetSAModuleMSG / PointnetFPModule with the constructor kwargs used at
-    pcdet/models/backbones_3d/pointnet2_backbone.py:27-34,43-47 and OpenPCDet's parameter names (mlps.{i}.{j}, mlp.{j});
+    pcdet/models/backbones_3d/pointnet2_backbone.py:27-34,43-47 and OpenPCDet's parameter names (mlps.{i}.{j}, mlp.{j}); their
+    shared MLPs (1x1 convolution + train-mode BatchNorm + ReLU) run on the library's matrix-core convolution and BatchNorm kernels
+    over a ROW layout (points x channels), with hvpr_group_rows / hvpr_max_samples / hvpr_fp_rows around them (csrc/point_mlp.hip);
   * PointNet2MSG, pcdet/models/backbones_3d/pointnet2_backbone.py:9-95 (registry key of backbones_3d).
 """
 import torch
@@ -121,6 +123,132 @@ def three_interpolate(features, idx, weight):
     return _ThreeInterpolate.apply(features, _i32(idx), weight.detach())
 
 
+# ------------------------------------------------------------------------------------------------ row-layout pieces (HIP)
+def _cpad(c):
+    return (c + 7) // 8 * 8
+
+
+class _GroupRows(torch.autograd.Function):
+    """QueryAndGroup (use_xyz) in ROW layout: xyz (B,N,3), features (B,N,C) or None, new_xyz (B,np,3), idx (B,np,ns) i32 ->
+    (B*np*ns, cpad) rows [xyz[idx] - new_xyz | features[idx] | 0]; backward scatter-adds the feature columns (hvpr_group_rows_*)."""
+
+    @staticmethod
+    def forward(ctx, xyz, features, new_xyz, idx, cpad):
+        B, N, _ = xyz.shape
+        _, np_, ns = idx.shape
+        C = 0 if features is None else features.shape[-1]
+        xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
+        features = None if features is None else features.contiguous()
+        out = torch.empty((B * np_ * ns, cpad), dtype=torch.float32, device=xyz.device)
+        check(lib().hvpr_group_rows_f32(kernels._ptr(xyz, torch.float32, "xyz"), kernels._ptr(features, torch.float32, "features"),
+                                        kernels._ptr(new_xyz, torch.float32, "new_xyz"), kernels._ptr(idx, torch.int32, "idx"), B, N, C, np_, ns,
+                                        cpad, out.data_ptr(), kernels._stream()), "hvpr_group_rows_f32")
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, C, np_, ns, cpad)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx,) = ctx.saved_tensors
+        B, N, C, np_, ns, cpad = ctx.dims
+        if C == 0 or not ctx.needs_input_grad[1]:
+            return None, None, None, None, None
+        grad = grad.contiguous()
+        gf = torch.empty((B, N, C), dtype=torch.float32, device=grad.device)
+        check(lib().hvpr_group_rows_grad_f32(kernels._ptr(grad, torch.float32, "grad_out"), idx.data_ptr(), B, N, C, np_, ns, cpad, gf.data_ptr(),
+                                             kernels._stream()), "hvpr_group_rows_grad_f32")
+        return None, gf, None, None, None
+
+
+class _MaxSamples(torch.autograd.Function):
+    """y (G*ns, C) rows -> (G, C): max over the ns samples of every group (the max-pool over the sample axis of
+    PointnetSAModuleMSG); the gradient goes to the arg-max sample."""
+
+    @staticmethod
+    def forward(ctx, y, ns):
+        y = y.contiguous()
+        C = y.shape[1]
+        G = y.shape[0] // ns
+        out = torch.empty((G, C), dtype=torch.float32, device=y.device)
+        arg = torch.empty((G, C), dtype=torch.uint8, device=y.device)
+        check(lib().hvpr_max_samples_f32(kernels._ptr(y, torch.float32, "y"), G, ns, C, out.data_ptr(), arg.data_ptr(), kernels._stream()),
+              "hvpr_max_samples_f32")
+        ctx.save_for_backward(arg)
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (arg,) = ctx.saved_tensors
+        grad = grad.contiguous()
+        G, C = grad.shape
+        gy = torch.empty((G * ctx.ns, C), dtype=torch.float32, device=grad.device)
+        check(lib().hvpr_max_samples_grad_f32(kernels._ptr(grad, torch.float32, "grad_out"), arg.data_ptr(), G, ctx.ns, C, gy.data_ptr(),
+                                              kernels._stream()), "hvpr_max_samples_grad_f32")
+        return gy, None
+
+
+class _FpRows(torch.autograd.Function):
+    """PointnetFPModule's input in ROW layout: known (B,m,C1), idx / weight (B,n,3), skip (B,n,C2) or None -> (B*n, cpad) rows
+    [three_interpolate(known) | skip | 0]  (hvpr_fp_rows_*; the weights carry no gradient, as in the reference's op)."""
+
+    @staticmethod
+    def forward(ctx, known, idx, weight, skip, cpad):
+        known, weight = known.contiguous(), weight.contiguous()
+        skip = None if skip is None else skip.contiguous()
+        B, m, C1 = known.shape
+        n = idx.shape[1]
+        C2 = 0 if skip is None else skip.shape[-1]
+        out = torch.empty((B * n, cpad), dtype=torch.float32, device=known.device)
+        check(lib().hvpr_fp_rows_f32(kernels._ptr(known, torch.float32, "known"), kernels._ptr(idx, torch.int32, "idx"),
+                                     kernels._ptr(weight, torch.float32, "weight"), kernels._ptr(skip, torch.float32, "skip"), B, m, n, C1, C2, cpad,
+                                     out.data_ptr(), kernels._stream()), "hvpr_fp_rows_f32")
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (B, m, n, C1, C2, cpad)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        idx, weight = ctx.saved_tensors
+        B, m, n, C1, C2, cpad = ctx.dims
+        grad = grad.contiguous()
+        gk = torch.empty((B, m, C1), dtype=torch.float32, device=grad.device)
+        gs = torch.empty((B, n, C2), dtype=torch.float32, device=grad.device) if (C2 > 0 and ctx.needs_input_grad[3]) else None
+        check(lib().hvpr_fp_rows_grad_f32(kernels._ptr(grad, torch.float32, "grad_out"), idx.data_ptr(), weight.data_ptr(), B, m, n, C1, C2, cpad,
+                                          gk.data_ptr(), kernels._ptr(gs), kernels._stream()), "hvpr_fp_rows_grad_f32")
+        return gk, None, None, gs, None
+
+
+def _rows_image(x):
+    """(S, C) rows as the (1, H, W, C) image the convolution / BatchNorm kernels take (any factorisation is the same 1x1 conv)."""
+    S = x.shape[0]
+    w = 64
+    while w > 1 and S % w:
+        w //= 2
+    return x.view(1, S // w, w, x.shape[1])
+
+
+def shared_mlp_rows(seq, x):
+    """The shared MLP `seq` = [Conv2d 1x1 (no bias), BatchNorm2d, ReLU] x L of pointnet2_backbone.py:27-47 on rows x (S, cpad):
+    every layer = hvpr_conv2d_nhwc_f32 (forward / data gradient) + hvpr_conv2d_wgrad_nhwc_f32 + the train-mode hvpr_bn_* kernels
+    (batch statistics over all S rows, differentiated through; running statistics updated like nn.BatchNorm2d)."""
+    from . import conv_train as ct
+    mods = list(seq)
+    assert len(mods) % 3 == 0
+    t = _rows_image(x)
+    for k in range(0, len(mods), 3):
+        conv, bn = mods[k], mods[k + 1]
+        w = conv.weight
+        if conv.bias is not None or tuple(conv.kernel_size) != (1, 1) or w.shape[0] % 8 != 0:
+            raise ValueError("hvpr_amd: the point-stream MLP kernels take 1x1 convolutions without bias and widths that are multiples of 8")
+        pad = t.shape[-1] - w.shape[1]
+        assert pad >= 0
+        if pad:
+            w = torch.cat([w, w.new_zeros((w.shape[0], pad, 1, 1))], dim=1)
+        t = ct.bn_relu(ct.conv(t, w), bn)
+    return t.reshape(x.shape[0], -1)
+
+
 # ------------------------------------------------------------------------------------------------ modules
 class QueryAndGroup(nn.Module):
     def __init__(self, radius, nsample, use_xyz=True):
@@ -128,6 +256,7 @@ class QueryAndGroup(nn.Module):
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
     def forward(self, xyz, new_xyz, features=None, idx=None):
+        """The reference's channel-major form: (B, 3 + C, npoint, nsample), xyz channels first."""
         if idx is None:
             idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
@@ -145,18 +274,21 @@ def _shared_mlp(widths):
 
 
 class PointnetSAModuleMSG(nn.Module):
-    """Set abstraction with multi-scale grouping: FPS -> per scale (ball query, group, shared MLP, max over samples) -> concat."""
+    """Set abstraction with multi-scale grouping: FPS -> per scale (ball query, group, shared MLP, max over samples) -> concat.
+    Everything runs on the library's kernels in ROW layout (points x channels); forward() keeps the reference's channel-major
+    signature, forward_rows() is what PointNet2MSG chains."""
 
     def __init__(self, *, npoint, radii, nsamples, mlps, use_xyz=True, bn=True):
         super().__init__()
         assert len(radii) == len(nsamples) == len(mlps)
+        if not use_xyz or not bn:
+            raise NotImplementedError("hvpr_amd: PointnetSAModuleMSG is built for use_xyz=True, bn=True (pointnet2_backbone.py:27-34)")
         self.npoint = npoint
         self.groupers = nn.ModuleList(QueryAndGroup(r, n, use_xyz) for r, n in zip(radii, nsamples))
         self.mlps = nn.ModuleList()
         for spec in mlps:
             spec = list(spec)
-            if use_xyz:
-                spec[0] += 3
+            spec[0] += 3
             self.mlps.append(_shared_mlp(spec))
 
     def indices(self, xyz):
@@ -165,30 +297,46 @@ class PointnetSAModuleMSG(nn.Module):
         new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
         return idx, new_xyz, [ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
 
-    def forward(self, xyz, features=None, pre=None):
+    def forward_rows(self, xyz, features=None, pre=None):
+        """xyz (B,N,3), features (B,N,C) rows or None -> new_xyz (B,npoint,3), features (B,npoint,C') rows."""
         idx, new_xyz, balls = pre if pre is not None else self.indices(xyz)
+        B = xyz.shape[0]
+        C = 0 if features is None else features.shape[-1]
         outs = []
         for grouper, mlp, bidx in zip(self.groupers, self.mlps, balls):
-            f = mlp(grouper(xyz, new_xyz, features, idx=bidx))            # (B, C', npoint, nsample)
-            outs.append(f.max(dim=-1)[0])
-        return new_xyz, torch.cat(outs, dim=1)
+            x = _GroupRows.apply(xyz, features, new_xyz, bidx, _cpad(3 + C))          # (B*npoint*nsample, cpad)
+            outs.append(_MaxSamples.apply(shared_mlp_rows(mlp, x), grouper.nsample))  # (B*npoint, C')
+        return new_xyz, torch.cat(outs, dim=1).view(B, self.npoint, -1)
+
+    def forward(self, xyz, features=None, pre=None):
+        """Reference signature: features (B,C,N) -> (B,C',npoint)."""
+        rows = None if features is None else features.transpose(1, 2).contiguous()
+        new_xyz, out = self.forward_rows(xyz, rows, pre=pre)
+        return new_xyz, out.transpose(1, 2).contiguous()
 
 
 class PointnetFPModule(nn.Module):
-    """Feature propagation: inverse-distance interpolation from the 3 nearest known points, concat skip, shared MLP."""
+    """Feature propagation: inverse-distance interpolation from the 3 nearest known points, concat skip, shared MLP — rows."""
 
     def __init__(self, *, mlp, bn=True):
         super().__init__()
         self.mlp = _shared_mlp(list(mlp))
 
-    def forward(self, unknown, known, unknow_feats, known_feats, pre=None):
+    def forward_rows(self, unknown, known, unknow_feats, known_feats, pre=None):
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,n,C2) rows or None, known_feats (B,m,C1) rows -> (B,n,C') rows."""
         dist, idx = pre if pre is not None else three_nn(unknown, known)
         w = 1.0 / (dist + 1e-8)
         w = w / w.sum(dim=2, keepdim=True)
-        f = three_interpolate(known_feats, idx, w)
-        if unknow_feats is not None:
-            f = torch.cat([f, unknow_feats], dim=1)
-        return self.mlp(f.unsqueeze(-1)).squeeze(-1)
+        B, n = idx.shape[0], idx.shape[1]
+        c = known_feats.shape[-1] + (0 if unknow_feats is None else unknow_feats.shape[-1])
+        x = _FpRows.apply(known_feats, _i32(idx), w.detach(), unknow_feats, _cpad(c))
+        return shared_mlp_rows(self.mlp, x).view(B, n, -1)
+
+    def forward(self, unknown, known, unknow_feats, known_feats, pre=None):
+        """Reference signature: channel-major features (B,C,n) / (B,C,m) -> (B,C',n)."""
+        uf = None if unknow_feats is None else unknow_feats.transpose(1, 2).contiguous()
+        out = self.forward_rows(unknown, known, uf, known_feats.transpose(1, 2).contiguous(), pre=pre)
+        return out.transpose(1, 2).contiguous()
 
 
 def _tensors_of(obj):
@@ -246,7 +394,7 @@ class PointNet2MSG(nn.Module):
         bidx, xyz, feats = pts[:, 0], pts[:, 1:4].contiguous(), (pts[:, 4:].contiguous() if pts.shape[1] > 4 else None)
         assert pts.shape[0] % B == 0, "PointNet2MSG needs the same number of points in every sample (pointnet2_backbone.py:76)"
         xyz = xyz.view(B, -1, 3)
-        feats = feats.view(B, -1, feats.shape[-1]).permute(0, 2, 1).contiguous() if feats is not None else None
+        feats = feats.view(B, -1, feats.shape[-1]) if feats is not None else None          # ROW layout (B, N, C) end to end
         plan = batch_dict.pop("_pn2_plan", None)
         if plan is not None:                     # computed ahead on another stream: wait for it, keep its memory alive for us
             plan, ready = plan
@@ -256,14 +404,14 @@ class PointNet2MSG(nn.Module):
                 t.record_stream(cur)
         l_xyz, l_feat = [xyz], [feats]
         for k, sa in enumerate(self.SA_modules):
-            nx, nf = sa(l_xyz[-1], l_feat[-1], pre=plan["sa"][k] if plan is not None else None)
+            nx, nf = sa.forward_rows(l_xyz[-1], l_feat[-1], pre=plan["sa"][k] if plan is not None else None)
             l_xyz.append(nx)
             l_feat.append(nf)
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
-            l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_feat[i - 1], l_feat[i],
-                                               pre=plan["fp"][i] if plan is not None else None)
-        pf = l_feat[0].permute(0, 2, 1).contiguous()
-        batch_dict["point_features"] = pf.view(-1, pf.shape[-1])
+            l_feat[i - 1] = self.FP_modules[i].forward_rows(l_xyz[i - 1], l_xyz[i], l_feat[i - 1], l_feat[i],
+                                                            pre=plan["fp"][i] if plan is not None else None)
+        pf = l_feat[0]
+        batch_dict["point_features"] = pf.reshape(-1, pf.shape[-1])
         batch_dict["point_coords"] = torch.cat((bidx[:, None].float(), l_xyz[0].reshape(-1, 3)), dim=1)
         batch_dict["point_batch_idx"] = bidx
         return batch_dict

@@ -182,9 +182,23 @@ def _train_forward(self, batch_dict, voxels, num, coords):
     if M > 0:
         _update_running(l0.norm, m0, v0, M * P)
         _update_running(l1.norm, m1, v1, M * P)
-    s = torch.cat([n.unsqueeze(1), torch.norm(mean, 2, 2), mean.squeeze(1)], dim=-1)
-    for seq in self.pfn_scale_layers:
-        s = seq(s)
+    # scale stream (pillar_vfe.py:213-216): [n, |mean|, mean] (5 columns, zero-padded to the convolution kernel's 8) through
+    # Linear (no bias) + train-mode BatchNorm1d + ReLU twice, as 1x1 convolutions over the M rows on the library's kernels
+    from . import conv_train as ct
+    s = torch.cat([n.unsqueeze(1), torch.norm(mean, 2, 2), mean.squeeze(1), mean.new_zeros((M, 3))], dim=-1)
+    if M > 0:
+        t = s.view(1, 1, M, 8)
+        for seq in self.pfn_scale_layers:
+            lin, bn = seq[0], seq[1]
+            w = lin.weight
+            if lin.bias is not None or w.shape[0] % 8 != 0 or w.shape[1] > t.shape[-1]:
+                raise ValueError("hvpr_amd: the VFE scale stream kernels take bias-free layers with widths that are multiples of 8")
+            pad = t.shape[-1] - w.shape[1]
+            w = w if pad == 0 else torch.cat([w, w.new_zeros((w.shape[0], pad))], dim=1)
+            t = ct.bn_relu(ct.conv(t, w.view(w.shape[0], w.shape[1], 1, 1)), bn)
+        s = t.view(M, -1)
+    else:
+        s = s.new_zeros((0, self.num_scale_features[-1]))
     batch_dict["pillar_features"] = x.reshape(M, -1)
     batch_dict["pillar_scale_features"] = s
     batch_dict["pillar_mask"] = mask

@@ -293,6 +293,48 @@ int hvpr_three_interpolate_f32(const float *features, const int32_t *idx, const 
                                float *out, hvpr_stream_t stream);
 int hvpr_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx, const float *weight, int B, int C, int m, int n,
                                     float *grad_features, hvpr_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * a9 (training)  Row-layout data movement around the shared MLPs of the point stream (PointnetSAModuleMSG,
+ *     pcdet/models/backbones_3d/pointnet2_backbone.py:27-34; PointnetFPModule :40-47,86-89).  The MLPs themselves (1x1 convolution
+ *     + train-mode BatchNorm + ReLU per layer) run on hvpr_conv2d_nhwc_f32 / hvpr_conv2d_wgrad_nhwc_f32 / hvpr_bn_* over rows
+ *     [samples, cpad]: channels contiguous, zero columns up to cpad (a multiple of 8).
+ *     hvpr_group_rows_f32:       QueryAndGroup(use_xyz): xyz [B,N,3], features [B,N,C] (null when C == 0), new_xyz [B,npoint,3],
+ *                                idx [B,npoint,nsample] i32 -> out [B*npoint*nsample, cpad], row = [xyz[idx] - new_xyz | features[idx] | 0].
+ *     hvpr_group_rows_grad_f32:  grad_out [rows, cpad] -> grad_features [B,N,C], overwritten (zeroed + fp32 atomics).
+ *     hvpr_max_samples_f32:      y [G, nsample, C] -> out [G, C] = max over the samples of a group, argmax [G, C] u8 (lowest sample
+ *                                on ties); nsample <= 255.        hvpr_max_samples_grad_f32: grad_out [G,C] -> grad_y [G,nsample,C].
+ *     hvpr_fp_rows_f32:          PointnetFPModule's input: known [B,m,C1], idx / weight [B,n,3], skip [B,n,C2] (null when C2 == 0)
+ *                                -> out [B*n, cpad], row = [(k0 w0 + k1 w1) + k2 w2 | skip | 0].
+ *     hvpr_fp_rows_grad_f32:     grad_out [B*n, cpad] -> grad_known [B,m,C1] (zeroed + fp32 atomics), grad_skip [B,n,C2] (may be null).
+ * ------------------------------------------------------------------------------------------- */
+int hvpr_group_rows_f32(const float *xyz, const float *features, const float *new_xyz, const int32_t *idx, int B, int N, int C,
+                        int npoint, int nsample, int cpad, float *out, hvpr_stream_t stream);
+int hvpr_group_rows_grad_f32(const float *grad_out, const int32_t *idx, int B, int N, int C, int npoint, int nsample, int cpad,
+                             float *grad_features, hvpr_stream_t stream);
+int hvpr_max_samples_f32(const float *y, long long G, int nsample, int C, float *out, uint8_t *argmax, hvpr_stream_t stream);
+int hvpr_max_samples_grad_f32(const float *grad_out, const uint8_t *argmax, long long G, int nsample, int C, float *grad_y,
+                              hvpr_stream_t stream);
+int hvpr_fp_rows_f32(const float *known, const int32_t *idx, const float *weight, const float *skip, int B, int m, int n, int C1,
+                     int C2, int cpad, float *out, hvpr_stream_t stream);
+int hvpr_fp_rows_grad_f32(const float *grad_out, const int32_t *idx, const float *weight, int B, int m, int n, int C1, int C2,
+                          int cpad, float *grad_known, float *grad_skip, hvpr_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * a11 (training)  SpatialAttention with BATCH statistics (pcdet/models/backbones_2d/spatial_attention.py:47-63): ChannelPool ->
+ *     conv3x3 2 -> 1 (+ bias) -> BatchNorm2d(1) -> sigmoid, forward and backward on NHWC y [N,H,W,C] (C % 4 == 0).  Parameters are
+ *     DEVICE pointers (w18 = conv weight [1,2,3,3] flattened, conv_bias / gamma / beta one float each).
+ *     fwd: pooled [N,H,W,2] (max, mean), argmax [N,H,W] i32, a [N,H,W] (conv output), stats [3] = batch mean, biased variance,
+ *          1/sqrt(var + eps) of a, gate [N,H,W].     bwd: dgate [N,H,W] -> dy [N,H,W,C] (overwritten), dw18 [18], dbias, dgamma,
+ *          dbeta [1] each; the batch statistics are differentiated through.  Sums: per-workgroup fp32 partials, final sums in
+ *          double in a fixed order (deterministic).
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_spatial_gate_train_workspace_bytes(int N, int H, int W);
+int hvpr_spatial_gate_train_fwd_f32(const float *y, int N, int H, int W, int C, const float *w18, const float *conv_bias,
+                                    const float *gamma, const float *beta, float eps, float *pooled, int32_t *argmax, float *a,
+                                    float *stats, float *gate, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+int hvpr_spatial_gate_train_bwd_f32(const float *dgate, const float *gate, const float *a, const float *stats, const float *pooled,
+                                    const int32_t *argmax, const float *w18, const float *gamma, int N, int H, int W, int C,
+                                    float *dy, float *dw18, float *dbias, float *dgamma, float *dbeta, void *workspace,
+                                    size_t workspace_bytes, hvpr_stream_t stream);
 /* a10 (training)  the index half of get_score (pointpillar_scatter.py:70-75): for every pillar row of `pillars` [M,64] the k
  * rows of `points` [N,64] with the largest dot product, idx [M,k] i32 in DESCENDING order (ties: lower index first).  N is
  * unlimited (items are walked in blocks of 2048); points_packed = hvpr_memory_bank_pack_f32(points, N) (fp16 operand tiles +

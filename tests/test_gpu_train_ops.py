@@ -238,3 +238,91 @@ def test_pillar_vfe_train_fwd_bwd_match_float64_autograd(M):
         mod.zero_grad()
         o_t = run(mod, torch.float32)
     assert float((o_t.double() - o_ref).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 40, 48, 32), (1, 31, 45, 64), (2, 9, 7, 128), (3, 5, 6, 8)])
+def test_spatial_gate_train_fwd_bwd_match_torch_autograd(N, H, W, C):
+    """hvpr_spatial_gate_train_fwd/bwd_f32 (ChannelPool -> conv3x3 2->1 + bias -> BatchNorm2d(1) with batch statistics -> sigmoid,
+    spatial_attention.py:47-63) against torch autograd of the same formula in float64: gate, batch statistics, and the gradients
+    of y, the convolution weight / bias and the BatchNorm affine."""
+    from hvpr_amd import conv_train as ct
+    g = torch.Generator().manual_seed(C + H)
+    y = torch.relu(torch.randn(N, H, W, C, generator=g)).to(DEV).requires_grad_(True)       # post-ReLU scale stream
+    w = (torch.randn(1, 2, 3, 3, generator=g) * 0.4).to(DEV).requires_grad_(True)
+    b = torch.tensor([0.3], device=DEV, requires_grad=True)
+    gamma = torch.tensor([1.3], device=DEV, requires_grad=True)
+    beta = torch.tensor([-0.2], device=DEV, requires_grad=True)
+    eps = 1e-3
+    gate, mean, var = ct.spatial_gate_train(y, w, b, gamma, beta, eps)
+    dg = torch.randn(N, H, W, 1, generator=g).to(DEV)
+    got = torch.autograd.grad(gate, (y, w, b, gamma, beta), dg)
+    y64, w64, b64, g64, be64 = (t.detach().double().requires_grad_(True) for t in (y, w, b, gamma, beta))
+    yc = y64.permute(0, 3, 1, 2)
+    pooled = torch.cat((yc.max(dim=1, keepdim=True)[0], yc.mean(dim=1, keepdim=True)), dim=1)
+    a = torch.nn.functional.conv2d(pooled, w64, b64, padding=1)
+    m, v = a.mean(), a.var(unbiased=False)
+    ref = torch.sigmoid((a - m) / torch.sqrt(v + eps) * g64 + be64).permute(0, 2, 3, 1)
+    want = torch.autograd.grad(ref, (y64, w64, b64, g64, be64), dg.double())
+    np.testing.assert_allclose(gate.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(mean), float(m), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(float(var), float(v), rtol=1e-4)
+    for a_, b_, what in zip(got, want, ("dy", "dw", "dbias", "dgamma", "dbeta")):
+        scale = float(b_.abs().max())
+        if what == "dbias":        # exact gradient of a bias in front of a batch-statistics BatchNorm is zero
+            assert float(a_.abs().max()) < 1e-4 * float(want[1].abs().max()), what
+            continue
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-3, atol=2e-5 * scale, err_msg=what)
+
+
+@pytest.mark.parametrize("B,N,C,npoint,ns", [(2, 500, 1, 64, 16), (1, 300, 67 - 3, 40, 32), (3, 64, 5, 7, 4)])
+def test_group_rows_max_samples_and_fp_rows_match_torch(B, N, C, npoint, ns):
+    """The row-layout data movement of the point stream (csrc/point_mlp.hip) against torch indexing: grouping (+ scatter-add
+    gradient), max over the samples (+ arg-max gradient), feature-propagation rows (+ both gradients)."""
+    from hvpr_amd import pointnet2 as P
+    g = torch.Generator().manual_seed(B * 100 + C)
+    xyz = torch.randn(B, N, 3, generator=g).to(DEV)
+    feat = torch.randn(B, N, C, generator=g).to(DEV).requires_grad_(True)
+    new_xyz = torch.randn(B, npoint, 3, generator=g).to(DEV)
+    idx = torch.randint(0, N, (B, npoint, ns), generator=g).int().to(DEV)
+    cpad = P._cpad(3 + C)
+    rows = P._GroupRows.apply(xyz, feat, new_xyz, idx, cpad)
+    ar = torch.arange(B, device=DEV)[:, None, None]
+    fr = feat.detach().clone().requires_grad_(True)
+    want = torch.cat([xyz[ar, idx.long()] - new_xyz.unsqueeze(2), fr[ar, idx.long()],
+                      torch.zeros(B, npoint, ns, cpad - 3 - C, device=DEV)], dim=-1).reshape(-1, cpad)
+    assert torch.equal(rows, want)
+    go = torch.randn(rows.shape, generator=g).to(DEV)
+    (gf,) = torch.autograd.grad(rows, feat, go)
+    (gw,) = torch.autograd.grad(want, fr, go)
+    torch.testing.assert_close(gf, gw, rtol=1e-4, atol=1e-5)
+    # max over samples
+    y = torch.randn(B * npoint * ns, 24, generator=g).to(DEV)
+    y[: ns] = 0.0                                                       # a group of exact ties: the lowest sample takes the gradient
+    y = y.requires_grad_(True)
+    out = P._MaxSamples.apply(y, ns)
+    yr = y.detach().clone().requires_grad_(True)
+    wout = yr.view(-1, ns, 24).max(dim=1)[0]
+    assert torch.equal(out, wout)
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    (gy,) = torch.autograd.grad(out, y, go)
+    assert torch.equal(gy[0], go[0]) and float(gy[1:ns].abs().max()) == 0.0
+    (gyr,) = torch.autograd.grad(wout, yr, go)
+    assert torch.equal(gy[ns:], gyr[ns:])
+    # feature propagation rows
+    m, n, C1, C2 = N, npoint * 3, 16, C
+    known = torch.randn(B, m, C1, generator=g).to(DEV).requires_grad_(True)
+    skip = torch.randn(B, n, C2, generator=g).to(DEV).requires_grad_(True)
+    i3 = torch.randint(0, m, (B, n, 3), generator=g).int().to(DEV)
+    w3 = torch.rand(B, n, 3, generator=g).to(DEV)
+    cp = P._cpad(C1 + C2)
+    rows = P._FpRows.apply(known, i3, w3, skip, cp)
+    kr, sr = known.detach().clone().requires_grad_(True), skip.detach().clone().requires_grad_(True)
+    gk = kr[ar, i3.long()]
+    want = torch.cat([(gk[:, :, 0] * w3[:, :, 0:1] + gk[:, :, 1] * w3[:, :, 1:2]) + gk[:, :, 2] * w3[:, :, 2:3], sr,
+                      torch.zeros(B, n, cp - C1 - C2, device=DEV)], dim=-1).reshape(-1, cp)
+    torch.testing.assert_close(rows, want, rtol=1e-6, atol=1e-6)
+    go = torch.randn(rows.shape, generator=g).to(DEV)
+    got = torch.autograd.grad(rows, (known, skip), go)
+    wantg = torch.autograd.grad(want, (kr, sr), go)
+    torch.testing.assert_close(got[0], wantg[0], rtol=1e-4, atol=1e-5)
+    assert torch.equal(got[1], wantg[1])

@@ -116,10 +116,45 @@ def head_train(self, data_dict):
     return self._finish_train(data_dict)
 
 
+# ------------------------------------------------------------------------------------------------ a9 point-stream modules
+def sa_forward_rows(self, xyz, features=None, pre=None):
+    """PointnetSAModuleMSG (pointnet2_backbone.py:27-34) with torch gathers, torch 1x1 Conv2d + BatchNorm2d + ReLU and torch max;
+    the index tensors (FPS, ball query) come from `pre` or the module's own index kernels."""
+    idx, new_xyz, balls = pre if pre is not None else self.indices(xyz)
+    B = xyz.shape[0]
+    ar = torch.arange(B, device=xyz.device)[:, None, None]
+    outs = []
+    for mlp, bidx in zip(self.mlps, balls):
+        bi = bidx.long()                                               # (B, npoint, nsample)
+        g = xyz[ar, bi] - new_xyz.unsqueeze(2)                         # (B, npoint, nsample, 3): xyz channels first
+        if features is not None:
+            g = torch.cat([g, features[ar, bi]], dim=-1)
+        f = mlp(g.permute(0, 3, 1, 2))                                 # (B, C', npoint, nsample)
+        outs.append(f.max(dim=-1)[0])
+    return new_xyz, torch.cat(outs, dim=1).transpose(1, 2).contiguous()
+
+
+def fp_forward_rows(self, unknown, known, unknow_feats, known_feats, pre=None):
+    """PointnetFPModule (pointnet2_backbone.py:40-47, 86-89) with torch gathers and the torch shared MLP."""
+    from hvpr_amd import pointnet2
+    dist, idx = pre if pre is not None else pointnet2.three_nn(unknown, known)
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(dim=2, keepdim=True)
+    B = idx.shape[0]
+    ar = torch.arange(B, device=idx.device)[:, None, None]
+    g = known_feats[ar, idx.long()]                                    # (B, n, 3, C1)
+    f = (g[:, :, 0] * w[:, :, 0:1] + g[:, :, 1] * w[:, :, 1:2]) + g[:, :, 2] * w[:, :, 2:3]
+    if unknow_feats is not None:
+        f = torch.cat([f, unknow_feats], dim=-1)
+    return self.mlp(f.transpose(1, 2).unsqueeze(-1)).squeeze(-1).transpose(1, 2).contiguous()
+
+
 # ------------------------------------------------------------------------------------------------ swapping them in
 def _table():
-    from hvpr_amd import anchor_head, bev_backbone, map_to_bev, vfe
+    from hvpr_amd import anchor_head, bev_backbone, map_to_bev, pointnet2, vfe
     return {
+        pointnet2.PointnetSAModuleMSG: {"forward_rows": sa_forward_rows},
+        pointnet2.PointnetFPModule: {"forward_rows": fp_forward_rows},
         bev_backbone.BaseBEVBackbone_Scale: {"_forward_train": backbone_train},
         vfe.PillarVFE_Scale: {"_forward_train": vfe_train},
         map_to_bev.MemoryUnit_Agg: {"_forward_train": memory_train},
