@@ -70,7 +70,8 @@ def conv_fwd_raw(x, weight, stride=1, adjoint=False, stats=False):
     stats: return (z, partials) — partials = the batch statistics' per-tile sums when the Winograd kernel produced them, else None.
     adjoint: weight is the (Cin', Cout', 3, 3) filter of the layer whose data gradient is wanted and x its output gradient.
     Stride-1 3x3: the Winograd kernel (packed on the device per call) unless HVPR_CONV_ALGO=direct."""
-    if weight.shape[2] == 3 and stride == 1 and kernels.conv_algo() == "winograd" and weight.shape[1 if adjoint else 0] % 4 == 0:
+    if weight.shape[2] == 3 and stride == 1 and kernels.conv_algo() == "winograd" and weight.shape[1 if adjoint else 0] % 4 == 0 \
+            and weight.shape[0 if adjoint else 1] % 8 == 0:
         g = _wino_groups()
         partials = None
         if stats and g == 1 and os.environ.get("HVPR_TRAIN_BN_STATS", "fused") == "fused":
@@ -264,7 +265,7 @@ class _SfmStep(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            if kernels.conv_algo() == "winograd" and cin % 4 == 0:
+            if kernels.conv_algo() == "winograd" and cin % 4 == 0 and cout % 8 == 0:
                 pc = kernels.pack_conv_wino(weight, relu=False, px_groups=_wino_groups(), adjoint=True)
                 dx = kernels.conv2d_wino_nhwc(dz, pc, gate=_ones(tuple(dz.shape[:3]), dz.device), resid=dy)    # + the residual path
             else:

@@ -1,7 +1,7 @@
 // ABI bookkeeping for libhvpr_amd.so (include/hvpr_amd.h).
 #include "common.h"
 
-extern "C" int hvpr_abi_version(void) { return 3; }   // 2: packed memory bank (bank_packed argument); 3: bank_packed is required and holds bf16 tiles + channel maxima
+extern "C" int hvpr_abi_version(void) { return 3; }   // 2: packed memory bank (bank_packed argument); 3: bank_packed is required and holds IEEE fp16 tiles (v_mfma_f32_16x16x32_f16) + channel maxima
 
 extern "C" const char *hvpr_status_string(int status) {
     switch (status) {

@@ -398,7 +398,7 @@ extern "C" int hvpr_conv2d_wino_nhwc_f32(const float *in, int N, int H, int W, i
     if ((gate == nullptr) != (resid == nullptr)) return HVPR_ERR_INVALID_ARG;
     if (Cin % KC != 0) return HVPR_ERR_UNSUPPORTED;
     if (cout % 4 != 0 || out_cstride % 4 != 0 || out_coff % 4 != 0 || (resid && resid_cstride % 4 != 0)) return HVPR_ERR_UNSUPPORTED;
-    if ((long long)H * W * Cin * 4 >= (1ll << 32)) return HVPR_ERR_UNSUPPORTED;      // 32-bit byte offsets inside one image
+    if ((long long)H * W * Cin * 4 >= (1ll << 31)) return HVPR_ERR_UNSUPPORTED;      // byte offsets inside one image are formed in signed 32-bit arithmetic
     WinoArgs a;
     a.in = in; a.wpk = w_packed; a.bias = bias; a.out = out; a.gate = gate; a.resid = resid;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin;

@@ -97,8 +97,8 @@ def pillar_vfe_fwd(voxels, num_points, coords, folded, voxel_size, offsets, m_de
 
 # ------------------------------------------------------------------------------------------------ memory + scatter
 class PackedBank:
-    """Memory bank with its streaming copy for the read-out kernel (hvpr_memory_bank_pack_f32): bf16 tiles in the matrix-core
-    operand layout ([tile of 16 items][channel half][64 lanes] x 8 bf16, 1 KB contiguous per load instruction) + the 64
+    """Memory bank with its streaming copy for the read-out kernel (hvpr_memory_bank_pack_f32): IEEE fp16 tiles in the matrix-core
+    operand layout ([tile of 16 items][channel half][64 lanes] x 8 fp16, 1 KB contiguous per load instruction) + the 64
     channel maxima max_j |W_jc| that bound the pre-filter's rounding error.  The fp32 rows stay next to it: candidates are
     re-checked and the k selected rows are read in exact fp32."""
 
@@ -467,7 +467,7 @@ def conv_algo():
 
 def pack_conv_auto(weight, scale=None, shift=None, stride=1, relu=True, tile_cfg=1, px_groups=1):
     """pack_conv_wino for a 3x3 / stride-1 layer when conv_algo() is "winograd", pack_conv otherwise; conv2d_nhwc takes either."""
-    if weight.shape[2] == 3 and stride == 1 and weight.shape[0] % 4 == 0 and conv_algo() == "winograd":
+    if weight.shape[2] == 3 and stride == 1 and weight.shape[0] % 4 == 0 and weight.shape[1] % 8 == 0 and conv_algo() == "winograd":
         return pack_conv_wino(weight, scale, shift, relu=relu, px_groups=px_groups)
     return pack_conv(weight, scale, shift, stride=stride, relu=relu, tile_cfg=tile_cfg)
 

@@ -221,7 +221,7 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         with torch.no_grad():
             idx = self._topk_points(pillars.detach(), points.detach())            # (M, k), descending
         positives = _GatherRows.apply(points, idx)                                          # (M, k, C)
-        w = torch.softmax(torch.bmm(pillars.unsqueeze(1), positives.transpose(1, 2)).squeeze(1), dim=1)
+        w = torch.softmax((pillars.unsqueeze(1) * positives).sum(dim=2), dim=1)            # (M, k) logits of the k positives
         return (w.detach().unsqueeze(2) * positives).sum(dim=1), positives
 
     def _topk_points(self, pillars, points):

@@ -116,9 +116,9 @@ int hvpr_pillar_vfe_bwd_f32(const float *voxels, const int32_t *num_points, cons
  *     softmax over the k selected logits, weighted sum of the k items.
  *     f [M,64], bank [n_items,64] -> out [M,64]; topk_idx [M,k] i32 (may be NULL; the k selected ids, order unspecified).
  *     k <= 32, channels == 64.
- *     bank_packed (REQUIRED): the output of hvpr_memory_bank_pack_f32 for the same bank — bf16 tiles in the matrix-core
+ *     bank_packed (REQUIRED): the output of hvpr_memory_bank_pack_f32 for the same bank (only that function may produce it) — IEEE fp16 tiles in the matrix-core
  *     operand layout + the 64 channel maxima max_j |bank[j][c]|; pack once per weight update.  The kernel pre-filters on the
- *     bf16 matrix cores with a rigorous rounding-error bound and re-checks the ~30 surviving candidates per row in exact
+ *     fp16 matrix cores (v_mfma_f32_16x16x32_f16) with a rigorous rounding-error bound and re-checks the ~30 surviving candidates per row in exact
  *     fp32 from `bank` (logit = butterfly-tree sum of the 64 fp32 products), so the selected ids are the exact fp32 top-k
  *     (value descending, id ascending on ties); the k selected rows are read from `bank` too.
  * ------------------------------------------------------------------------------------------- */
