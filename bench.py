@@ -194,29 +194,27 @@ class GroupGraphs:
                 model.stage_encode(dict(inp))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graphs, pool = [], None
-        for inp in self.inputs:
-            g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g, pool=pool):
+        # ONE hipGraph holding the group of every pool frame back to back (a different frame each time, all on the same persistent
+        # canvas pair): the interval between two events around a replay is then the group's kernels and the gaps between them,
+        # as inside a frame graph — with one graph per frame every group also paid the start-up of a graph launch
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            for inp in self.inputs:
                 self.bd = model.stage_encode(dict(inp))
-            pool = g.pool()
-            self.graphs.append(g)
+        self.n = len(self.inputs)
         self.captured = detector._CapturedState(model)
 
     def time_us(self, rounds=5):
         self.captured.check()
-        n = len(self.graphs)
-        for g in self.graphs:
-            g.replay()
+        self.graph.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(rounds):
-            for g in self.graphs:
-                g.replay()
+            self.graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / (rounds * n)
+        return e0.elapsed_time(e1) * 1e3 / (rounds * self.n)
 
 
 def group_bytes(n_pts, nx, ny, batch):
@@ -560,10 +558,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath))
-    # per-kernel averages of the committed rocprofv3 --kernel-trace --stats run of this command (serial frame graph): the group
-    # above is timed live; its members, and the one bandwidth-bound kernel among them, are quoted from the profile
+    # per-kernel averages of the committed rocprofv3 --kernel-trace --stats run of this command (serial single-stream frame graph,
+    # HVPR_BEV_STREAMS=1 --no-pipeline): the group above is timed live; its members are quoted from the profile
     members = {}
-    spath = os.path.join(ROOT, "profiles", "r02_kernel_stats_single_graph.csv")
+    spath = os.path.join(ROOT, "profiles", "r03_kernel_stats_serial.csv")
     if os.path.exists(spath):
         import csv
         for r in csv.DictReader(open(spath)):
@@ -594,9 +592,9 @@ def main():
                      "frac": round(group_bytes_ / group_s / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": group_bytes_,
                      "avg_duration_us": round(group_s * 1e6, 2),
                      "single_replay_between_events_us": round(float(stage[0]) * 1e3, 2),
-                     "timing": "HIP events around 40 back-to-back replays of the captured group (8 graphs, one per pool frame, on ONE persistent "
-                               "canvas pair: every replay encodes a DIFFERENT frame, so the stale-cell clear of the previous frame is inside the "
-                               "interval), / 40; single_replay_between_events_us additionally holds the start-up of one graph launch",
+                     "timing": "HIP events around 5 replays of ONE captured hipGraph that holds the group of the 8 pool frames back to back (on ONE "
+                               "persistent canvas pair: every group encodes a DIFFERENT frame, so the stale-cell clear of the previous frame is inside "
+                               "the interval), / 40; single_replay_between_events_us additionally holds the start-up of one graph launch",
                      "traffic": None if traffic is None else traffic.get("vfe_scatter_group_bytes"),
                      "achieved_physical": None if traffic is None else round(traffic.get("vfe_scatter_group_bytes") / group_s / 1e9, 2),
                      "frac_physical": None if traffic is None else round(traffic.get("vfe_scatter_group_bytes") / group_s / 1e9 / HBM_PEAK_GBPS, 5),
