@@ -49,15 +49,17 @@ struct Rows {           // what a lane (slot p of its half-wave's pillar) knows 
     float y0[C0];
     int n;
     bool act;           // the half-wave has a pillar
+    bool ex;            // this lane's slot exists: p < PS, the configured points per pillar (<= P = 32 lanes)
 };
 
 __device__ __forceinline__ void load_rows(const float4 *__restrict__ voxels, const int *__restrict__ num, const int4 *__restrict__ coords,
-                                          long long m, long long M, int p, const Geom &g, const float *__restrict__ w0, Rows &r) {
+                                          long long m, long long M, int p, int PS, const Geom &g, const float *__restrict__ w0, Rows &r) {
     r.act = m < M;
+    r.ex = p < PS;
     const long long mm = r.act ? m : 0;
-    float4 v = voxels[mm * P + p];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r.act && r.ex) v = voxels[mm * PS + p];
     r.n = r.act ? num[mm] : 0;
-    if (!r.act) v = make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 c = coords[mm];                                  // [b, z, y, x]
     const float inv_n = 1.f / (float)(r.n > 0 ? r.n : 1);
     const float mx = hvpr_reduce_sum<32>(v.x) * inv_n, my = hvpr_reduce_sum<32>(v.y) * inv_n, mz = hvpr_reduce_sum<32>(v.z) * inv_n;
@@ -80,7 +82,7 @@ __device__ __forceinline__ void layer0(const Rows &r, const Scratch *__restrict_
 #pragma unroll
     for (int c = 0; c < C0; ++c) {
         z0[c] = fmaxf(fmaf(r.y0[c], s->sc0[c], s->sh0[c]), 0.f);
-        m0[c] = hvpr_reduce_max<32>(z0[c]);
+        m0[c] = hvpr_reduce_max<32>(r.ex ? z0[c] : -INFINITY);      // lanes past PS are not slots (padded slots p >= n are)
     }
 }
 
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256) k_vfe_reduce_rows(const float *__restrict
 // MODE 0: statistics of y0.  MODE 1: statistics of y1.  MODE 2: out [M, 64].
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) k_vfe_train_fwd(const float4 *__restrict__ voxels, const int *__restrict__ num,
-                                                            const int4 *__restrict__ coords, long long M, Geom g,
+                                                            const int4 *__restrict__ coords, long long M, int PS, Geom g,
                                                             const float *__restrict__ w0, const float *__restrict__ w1,
                                                             const Scratch *__restrict__ sc, float *__restrict__ part, float *__restrict__ out) {
     __shared__ float s_row[MODE == 2 ? 1 : kF2];
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_fwd(const float4 *__rest
     for (long long pair = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6); pair < n_pairs; pair += (long long)kBlocks * kWaves) {
         const long long m = pair * 2 + half;
         Rows r;
-        load_rows(voxels, num, coords, m, M, p, g, w0, r);
+        load_rows(voxels, num, coords, m, M, p, PS, g, w0, r);
         if (MODE == 0) {
             if (r.act) {
 #pragma unroll
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_fwd(const float4 *__rest
             float y1[16];
             layer1_chunk(z0, m0, w1, cb, y1);
             if (MODE == 1) {
-                if (r.act) {
+                if (r.act && r.ex) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { acc[cb + i] += y1[i]; acc[C1 + cb + i] = fmaf(y1[i], y1[i], acc[C1 + cb + i]); }
                 }
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_fwd(const float4 *__rest
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float z = fmaxf(fmaf(y1[i], sc->sc1[cb + i], sc->sh1[cb + i]), 0.f);
-                    const float mx = hvpr_reduce_max<32>(z);
+                    const float mx = hvpr_reduce_max<32>(r.ex ? z : -INFINITY);
                     if (r.act && p == ((cb + i) & 31)) out[m * C1 + cb + i] = mx;
                 }
             }
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(256) k_vfe_fin_stats(const double *__restrict_
 
 // backward, layer 1: sums for dbeta1 / dgamma1, the sparse part of dW1 and the moments s1, S1
 __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd1(const float4 *__restrict__ voxels, const int *__restrict__ num,
-                                                             const int4 *__restrict__ coords, long long M, Geom g,
+                                                             const int4 *__restrict__ coords, long long M, int PS, Geom g,
                                                              const float *__restrict__ w0, const float *__restrict__ w1,
                                                              const Scratch *__restrict__ sc, const float *__restrict__ d_out,
                                                              float *__restrict__ part) {
@@ -223,17 +225,17 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd1(const float4 *__res
     for (long long pair = (long long)blockIdx.x * kWaves + wv; pair < n_pairs; pair += (long long)kBlocks * kWaves) {
         const long long m = pair * 2 + half;
         Rows r;
-        load_rows(voxels, num, coords, m, M, p, g, w0, r);
+        load_rows(voxels, num, coords, m, M, p, PS, g, w0, r);
         float z0[C0], m0[C0];
         layer0(r, sc, z0, m0);
         // x1 rows of the pillar to LDS (a padded slot's row is the same for every padded slot: written once more as row P)
 #pragma unroll
         for (int j = 0; j < C0; ++j) { x1[p][j] = z0[j]; x1[p][C0 + j] = m0[j]; }
-        if (p == (r.n < P ? r.n : 0)) {
+        if (p == (r.n < PS ? r.n : 0)) {
 #pragma unroll
             for (int j = 0; j < C0; ++j) { x1[P][j] = z0[j]; x1[P][C0 + j] = m0[j]; }
         }
-        const float wpad = r.act ? (float)(P - r.n) : 0.f;     // multiplicity of the padded row
+        const float wpad = r.act ? (float)(PS - r.n) : 0.f;    // multiplicity of the padded row
         // moments over the live rows + the padded row (wave-uniform trip count: the larger of the two pillars)
         const int n_loop = max(__shfl(r.n, 0, 64), __shfl(r.n, 32, 64));
         for (int q = 0; q <= n_loop; ++q) {
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd1(const float4 *__res
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int c = cb + i;
-                const float z = fmaxf(fmaf(y1[i], sc->sc1[c], sc->sh1[c]), 0.f);
+                const float z = r.ex ? fmaxf(fmaf(y1[i], sc->sc1[c], sc->sh1[c]), 0.f) : -INFINITY;
                 const float mx = hvpr_reduce_max<32>(z);
                 const int am = first_in_half(z == mx, half);
                 const float y_at = __shfl(y1[i], (half << 5) + am, 64);
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(256) k_vfe_fin_bwd1(const double *__restrict__
 
 // backward, layer 0: g_x1 of every slot, through the max / ReLU of layer 0; sums for dbeta0 / dgamma0, sparse dW0, s0, S0
 __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd0(const float4 *__restrict__ voxels, const int *__restrict__ num,
-                                                             const int4 *__restrict__ coords, long long M, Geom g,
+                                                             const int4 *__restrict__ coords, long long M, int PS, Geom g,
                                                              const float *__restrict__ w0, const float *__restrict__ w1,
                                                              const float *__restrict__ gamma1, const Scratch *__restrict__ sc,
                                                              const float *__restrict__ d_out, float *__restrict__ part) {
@@ -333,7 +335,7 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd0(const float4 *__res
     for (long long pair = (long long)blockIdx.x * kWaves + wv; pair < n_pairs; pair += (long long)kBlocks * kWaves) {
         const long long m = pair * 2 + half;
         Rows r;
-        load_rows(voxels, num, coords, m, M, p, g, w0, r);
+        load_rows(voxels, num, coords, m, M, p, PS, g, w0, r);
         float z0[C0], m0[C0];
         layer0(r, sc, z0, m0);
         // dense part of g_x1: -(Q x1[p] + w)
@@ -345,7 +347,7 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd0(const float4 *__res
             for (int j = 0; j < C0; ++j) a = fmaf(sc->q[k * K1 + j], z0[j], a);
 #pragma unroll
             for (int j = 0; j < C0; ++j) a = fmaf(sc->q[k * K1 + C0 + j], m0[j], a);
-            gx[k] = -a;
+            gx[k] = r.ex ? -a : 0.f;              // lanes past PS are not slots: nothing flows through them
         }
         // sparse part: + c1 g_c W1[c] on the arg-max slot of every channel
 #pragma unroll
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd0(const float4 *__res
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int c = cb + i;
-                const float z = fmaxf(fmaf(y1[i], sc->sc1[c], sc->sh1[c]), 0.f);
+                const float z = r.ex ? fmaxf(fmaf(y1[i], sc->sc1[c], sc->sh1[c]), 0.f) : -INFINITY;
                 const float mx = hvpr_reduce_max<32>(z);
                 const int am = first_in_half(z == mx, half);
                 const float gc = mx > 0.f ? d_out[(r.act ? m : 0) * C1 + c] * gamma1[c] * sc->inv1[c] : 0.f;
@@ -370,9 +372,9 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd0(const float4 *__res
 #pragma unroll
         for (int c = 0; c < C0; ++c) {
             const float gm = hvpr_reduce_sum<32>(gx[C0 + c]);
-            const int am0 = first_in_half(z0[c] == m0[c], half);
+            const int am0 = first_in_half(r.ex && z0[c] == m0[c], half);
             const float gz = gx[c] + (p == am0 ? gm : 0.f);
-            ga[c] = (r.act && z0[c] > 0.f) ? gz : 0.f;
+            ga[c] = (r.act && r.ex && z0[c] > 0.f) ? gz : 0.f;
             a_db[c] += ga[c];
             a_dg[c] = fmaf(ga[c], (r.y0[c] - sc->mu0[c]) * sc->inv0[c], a_dg[c]);
         }
@@ -432,24 +434,24 @@ size_t ws_bytes() { return kPartBytes + kSumBytes + sizeof(Scratch) + 256; }
 extern "C" size_t hvpr_pillar_vfe_train_workspace_bytes(void) { return ws_bytes(); }
 
 // statistics of both layers into the workspace scratch (and mean / biased variance out); MODE 2 pass when `out` is given
-static int vfe_train_forward(const float *voxels, const int32_t *num_points, const int32_t *coords, long long M, const float *w0,
+static int vfe_train_forward(const float *voxels, const int32_t *num_points, const int32_t *coords, long long M, int PS, const float *w0,
                              const float *gamma0, const float *beta0, const float *w1, const float *gamma1, const float *beta1, float eps,
                              Geom g, float *out, float *mean0, float *var0, float *mean1, float *var1, void *workspace, hipStream_t s) {
     float *part = (float *)workspace;
     double *sums = (double *)((char *)workspace + kPartBytes);
     Scratch *sc = (Scratch *)((char *)workspace + kPartBytes + kSumBytes);
-    const double count = (double)M * P;
-    hipLaunchKernelGGL(k_vfe_train_fwd<0>, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords, M, g,
+    const double count = (double)M * PS;
+    hipLaunchKernelGGL(k_vfe_train_fwd<0>, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords, M, PS, g,
                        w0, w1, sc, part, nullptr);
     hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kF1, 256)), dim3(256), 0, s, part, kF1, sums);
     hipLaunchKernelGGL(k_vfe_fin_stats, dim3(1), dim3(256), 0, s, sums, C0, count, eps, gamma0, beta0, 0, sc, mean0, var0);
-    hipLaunchKernelGGL(k_vfe_train_fwd<1>, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords, M, g,
+    hipLaunchKernelGGL(k_vfe_train_fwd<1>, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords, M, PS, g,
                        w0, w1, sc, part, nullptr);
     hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kF2, 256)), dim3(256), 0, s, part, kF2, sums);
     hipLaunchKernelGGL(k_vfe_fin_stats, dim3(1), dim3(256), 0, s, sums, C1, count, eps, gamma1, beta1, 1, sc, mean1, var1);
     if (out)
         hipLaunchKernelGGL(k_vfe_train_fwd<2>, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords, M,
-                           g, w0, w1, sc, part, out);
+                           PS, g, w0, w1, sc, part, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -461,10 +463,10 @@ extern "C" int hvpr_pillar_vfe_train_fwd_f32(const float *voxels, const int32_t 
     if (!voxels || !num_points || !coords || !w0 || !gamma0 || !beta0 || !w1 || !gamma1 || !beta1 || !pillar_features || !mean0 || !var0 ||
         !mean1 || !var1 || !workspace || M < 1)
         return HVPR_ERR_INVALID_ARG;
-    if (P_ != P) return HVPR_ERR_UNSUPPORTED;
+    if (P_ < 1 || P_ > P) return HVPR_ERR_UNSUPPORTED;      // one lane per slot of a half-wave
     if (workspace_bytes < ws_bytes()) return HVPR_ERR_WORKSPACE;
     const Geom g = {vs_x, vs_y, vs_z, off_x, off_y, off_z};
-    if (vfe_train_forward(voxels, num_points, coords, M, w0, gamma0, beta0, w1, gamma1, beta1, eps, g, pillar_features, mean0, var0, mean1,
+    if (vfe_train_forward(voxels, num_points, coords, M, P_, w0, gamma0, beta0, w1, gamma1, beta1, eps, g, pillar_features, mean0, var0, mean1,
                           var1, workspace, (hipStream_t)stream) != 0)
         return HVPR_ERR_LAUNCH;
     return HVPR_OK;
@@ -478,7 +480,7 @@ extern "C" int hvpr_pillar_vfe_bwd_f32(const float *voxels, const int32_t *num_p
     if (!voxels || !num_points || !coords || !w0 || !gamma0 || !beta0 || !w1 || !gamma1 || !beta1 || !d_pillar_features || !dw0 || !dgamma0 ||
         !dbeta0 || !dw1 || !dgamma1 || !dbeta1 || !workspace || M < 1)
         return HVPR_ERR_INVALID_ARG;
-    if (P_ != P) return HVPR_ERR_UNSUPPORTED;
+    if (P_ < 1 || P_ > P) return HVPR_ERR_UNSUPPORTED;
     if (workspace_bytes < ws_bytes()) return HVPR_ERR_WORKSPACE;
     const Geom g = {vs_x, vs_y, vs_z, off_x, off_y, off_z};
     hipStream_t s = (hipStream_t)stream;
@@ -487,16 +489,16 @@ extern "C" int hvpr_pillar_vfe_bwd_f32(const float *voxels, const int32_t *num_p
     Scratch *sc = (Scratch *)((char *)workspace + kPartBytes + kSumBytes);
     // the batch statistics are recomputed (two passes) instead of being trusted from a caller: the workspace carries no state
     // between calls, and the dgamma1 / dbeta1 outputs serve as the throw-away mean / variance destinations until they are written
-    if (vfe_train_forward(voxels, num_points, coords, M, w0, gamma0, beta0, w1, gamma1, beta1, eps, g, nullptr, dgamma0, dbeta0, dgamma1,
+    if (vfe_train_forward(voxels, num_points, coords, M, P_, w0, gamma0, beta0, w1, gamma1, beta1, eps, g, nullptr, dgamma0, dbeta0, dgamma1,
                           dbeta1, workspace, s) != 0)
         return HVPR_ERR_LAUNCH;
-    const double count = (double)M * P;
+    const double count = (double)M * P_;
     hipLaunchKernelGGL(k_vfe_train_bwd1, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords,
-                       (long long)M, g, w0, w1, sc, d_pillar_features, part);
+                       (long long)M, P_, g, w0, w1, sc, d_pillar_features, part);
     hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kB1, 256)), dim3(256), 0, s, part, kB1, sums);
     hipLaunchKernelGGL(k_vfe_fin_bwd1, dim3(1), dim3(256), 0, s, sums, count, w1, gamma1, sc, dw1, dgamma1, dbeta1);
     hipLaunchKernelGGL(k_vfe_train_bwd0, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords,
-                       (long long)M, g, w0, w1, gamma1, sc, d_pillar_features, part);
+                       (long long)M, P_, g, w0, w1, gamma1, sc, d_pillar_features, part);
     hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kB2, 256)), dim3(256), 0, s, part, kB2, sums);
     hipLaunchKernelGGL(k_vfe_fin_bwd0, dim3(1), dim3(256), 0, s, sums, count, w0, gamma0, sc, dw0, dgamma0, dbeta0);
     HVPR_CHECK_LAUNCH();
