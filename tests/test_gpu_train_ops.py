@@ -325,3 +325,28 @@ def test_group_rows_max_samples_and_fp_rows_match_torch(B, N, C, npoint, ns):
     wantg = torch.autograd.grad(want, (kr, sr), go)
     torch.testing.assert_close(got[0], wantg[0], rtol=1e-4, atol=1e-5)
     assert torch.equal(got[1], wantg[1])
+
+
+def test_row_kernels_without_features_and_without_skip():
+    """The first SA level of a 3-channel cloud has no point features (rows = [xyz offsets | 0]) and the last FP level of such a
+    cloud has no skip features: both forms of hvpr_group_rows_f32 / hvpr_fp_rows_f32."""
+    from hvpr_amd import pointnet2 as P
+    g = torch.Generator().manual_seed(9)
+    B, N, npoint, ns = 2, 200, 30, 8
+    xyz = torch.randn(B, N, 3, generator=g).to(DEV)
+    new_xyz = torch.randn(B, npoint, 3, generator=g).to(DEV)
+    idx = torch.randint(0, N, (B, npoint, ns), generator=g).int().to(DEV)
+    rows = P._GroupRows.apply(xyz, None, new_xyz, idx, 8)
+    ar = torch.arange(B, device=DEV)[:, None, None]
+    want = torch.cat([xyz[ar, idx.long()] - new_xyz.unsqueeze(2), torch.zeros(B, npoint, ns, 5, device=DEV)], dim=-1).reshape(-1, 8)
+    assert torch.equal(rows, want)
+    known = torch.randn(B, N, 16, generator=g).to(DEV).requires_grad_(True)
+    i3 = torch.randint(0, N, (B, 50, 3), generator=g).int().to(DEV)
+    w3 = torch.rand(B, 50, 3, generator=g).to(DEV)
+    rows = P._FpRows.apply(known, i3, w3, None, 16)
+    gk = known[ar, i3.long()]
+    want = ((gk[:, :, 0] * w3[:, :, 0:1] + gk[:, :, 1] * w3[:, :, 1:2]) + gk[:, :, 2] * w3[:, :, 2:3]).reshape(-1, 16)
+    torch.testing.assert_close(rows, want, rtol=1e-6, atol=1e-6)
+    (gkn,) = torch.autograd.grad(rows, known, torch.ones_like(rows))
+    (gw,) = torch.autograd.grad(want, known, torch.ones_like(want))
+    torch.testing.assert_close(gkn, gw, rtol=1e-4, atol=1e-5)

@@ -25,14 +25,27 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_whole_train_step_hip_equals_torch_forms():
-    cfg = hvpr_car_cfg()
-    model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg, training=True))
+@pytest.mark.parametrize("which", ["car", "3class"])
+def test_whole_train_step_hip_equals_torch_forms(which):
+    from hvpr_amd.config import hvpr_3class_cfg
+    cfg = hvpr_car_cfg() if which == "car" else hvpr_3class_cfg()        # BASELINE.json configs[2] / configs[3] model
+    n_class = len(cfg.CLASS_NAMES)
+    model = detector.build_network(cfg.MODEL, n_class, detector.SyntheticDataset(cfg, training=True))
     synthetic_weights.load_synthetic(model, seed=21, cls_bias=-4.595)
     hip = model.to(DEV).train()
     ref = copy.deepcopy(hip)
     torch_forms.patch(ref)
     batch = _train_batch([200, 201], np.random.default_rng(21))
+    if n_class > 1:                 # every class present: sizes of the class anchors, labels 1..3
+        sizes = np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]], np.float32)
+        gt = batch["gt_boxes"].cpu().numpy()
+        for b in range(gt.shape[0]):
+            for k in range(gt.shape[1]):
+                if gt[b, k, 7] > 0:
+                    c = (k + b) % 3
+                    gt[b, k, 3:6] = sizes[c] * (gt[b, k, 3:6] / np.array([3.9, 1.6, 1.56], np.float32))
+                    gt[b, k, 7] = c + 1
+        batch["gt_boxes"] = torch.from_numpy(gt).to(DEV)
     ocfg = copy.deepcopy(cfg.OPTIMIZATION)
     opt_h = optim.build_optimizer(hip, ocfg)
     assert isinstance(opt_h, optim.FusedAdamOneCycle)
