@@ -626,7 +626,8 @@ class PointPillar(_VoxelizingDetector):
 
     def forward(self, batch_dict, sync=True):
         if self.training:
-            raise NotImplementedError("hvpr_amd: the training step is not built yet")
+            raise NotImplementedError("hvpr_amd: plain PointPillar has no training path (the reference's own detectors/pointpillar.py:24-32 unpacks "
+                                      "two values from a get_loss that returns five, anchor_head_template.py:291); train MixAnchor_Memory")
         if "voxels" not in batch_dict:
             batch_dict = self.voxelize_on_device(batch_dict)
         for m in self.module_list:
