@@ -169,10 +169,21 @@ int hvpr_oracle_nms_sorted(const float *boxes, int n, float thresh, int64_t *kee
     const int nb = (n + 63) / 64;
     uint64_t *mask = (uint64_t *)calloc((size_t)n * (nb ? nb : 1), sizeof(uint64_t));
     uint64_t *remv = (uint64_t *)calloc(nb ? nb : 1, sizeof(uint64_t));
+    /* Pairs whose circumscribed circles are more than 10 cm apart cannot intersect (the in-box margin widens a box by
+     * 1.42 cm at most): their overlap is exactly 0, so `iou > thresh` is false for every thresh >= 0 and the polygon routine
+     * need not run.  Same result as the all-pairs form, ~10x fewer clips on a KITTI-like scene (the CPU baseline of bench.py
+     * was otherwise dominated by this loop). */
+    double *rad = (double *)malloc(sizeof(double) * (n ? n : 1));
+    for (int i = 0; i < n; ++i) rad[i] = 0.5 * sqrt((double)boxes[7 * i + 3] * boxes[7 * i + 3] + (double)boxes[7 * i + 4] * boxes[7 * i + 4]);
     for (int i = 0; i < n; ++i)
-        for (int j = i + 1; j < n; ++j)
+        for (int j = i + 1; j < n; ++j) {
+            const double dx = (double)boxes[7 * i] - boxes[7 * j], dy = (double)boxes[7 * i + 1] - boxes[7 * j + 1];
+            const double reach = rad[i] + rad[j] + 0.1;
+            if (thresh >= 0.f && dx * dx + dy * dy > reach * reach) continue;
             if (hvpr_oracle_iou_bev(boxes + 7 * i, boxes + 7 * j) > thresh)
                 mask[(size_t)i * nb + j / 64] |= 1ULL << (j % 64);
+        }
+    free(rad);
     int nk = 0;
     for (int i = 0; i < n; ++i) {
         if (!(remv[i / 64] & (1ULL << (i % 64)))) {
