@@ -82,3 +82,42 @@ def test_weight_gradient_in_the_winograd_domain():
     sign[3, :] *= -1
     sign[:, 3] *= -1                       # k_wgrad_wino_reduce: negative when exactly one of (a == 3), (b == 3)
     np.testing.assert_allclose(G.T @ (dU_kernel * sign) @ G, want, atol=1e-10)
+
+
+def test_f4x4_rounding_error_in_fp32_against_f2x2():
+    """The evidence behind DESIGN.md §4.2c ("next factor"): Winograd F(4x4, 3x3) with fp32 transforms and fp32 accumulation over 128
+    input channels sits ~15x above F(2x2, 3x3) in rounding error (5.5e-6 vs 3.8e-7 of the output scale at 128 channels; 1.1e-5 ..
+    1.3e-5 at 256 / 512) — inside a 2e-5 per-layer budget, not inside F(2x2)'s 1e-6 class."""
+    rng = np.random.default_rng(0)
+    mats = {
+        2: (np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64),
+            np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64),
+            np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)),
+        4: (np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                      [0, 4, 0, -5, 0, 1]], np.float64),
+            np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                      [0, 0, 1]], np.float64),
+            np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], np.float64)),
+    }
+    C, K, H = 128, 16, 8
+    x = np.maximum(rng.normal(0, 1, (C, H, H)), 0).astype(np.float32)
+    w = (rng.normal(0, 1, (K, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+    xp64 = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1)))
+    ref = sum(np.einsum("kc,chw->khw", w[:, :, u, v].astype(np.float64), xp64[:, u:u + H, v:v + H]) for u in range(3) for v in range(3))
+    err = {}
+    for m, (bt, g, at) in mats.items():
+        t = m + 2
+        U = np.einsum("ab,kcbd,ed->kcae", g, w.astype(np.float64), g).astype(np.float32)     # filter transform in double, rounded once
+        btf, atf = bt.astype(np.float32), at.astype(np.float32)
+        xp = np.pad(x, ((0, 0), (1, 1 + t), (1, 1 + t)))
+        out = np.zeros((K, H, H), np.float32)
+        for by in range(0, H, m):
+            for bx in range(0, H, m):
+                V = np.einsum("ab,cbd,ed->cae", btf, xp[:, by:by + t, bx:bx + t], btf).astype(np.float32)
+                M = np.einsum("kcae,cae->kae", U, V).astype(np.float32)
+                Y = np.einsum("ab,kbd,ed->kae", atf, M, atf).astype(np.float32)
+                hh, ww = min(m, H - by), min(m, H - bx)
+                out[:, by:by + hh, bx:bx + ww] = Y[:, :hh, :ww]
+        err[m] = float(np.abs(out - ref).max() / np.abs(ref).max())
+    assert err[2] < 2e-6 and err[4] < 2e-5, err            # both algebraically exact ...
+    assert err[4] > 4 * err[2], err                        # ... and F(4x4) pays for its 1/24 .. 8 transform constants
