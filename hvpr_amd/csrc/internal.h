@@ -19,6 +19,9 @@ struct VoxWs {
     int4 *vox_rec;     // [N] by global rank: {cell, point count, arena offset, first point index} — one 16-byte load per voxel
     int *arena;        // [N]  point indices, grouped by voxel (unordered inside a voxel)
     float4 *arena_pt;  // [N]  the points themselves next to their indices (fused encode path only: one load level less)
+    int4 *arena_rec;   // [N]  fused encode path: {point index, voxel rank or -1 (voxel dropped by the cap), voxel point count, cell}
+                       //      per arena position — a pillar wave reads a window of the arena and needs nothing else
+    int *arena_total;  // [1]  number of arena positions in use (= in-range points), written by K2
     int *frame_base;   // [B+1] rank of the first voxel of each frame (uncapped)
     unsigned long long *tile_state;   // [tiles]
     int *ticket;       // [1]
@@ -34,6 +37,8 @@ static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell) 
     w.vox_rec = c.take<int4>(n);
     w.arena = c.take<int>(n);
     w.arena_pt = c.take<float4>(n);
+    w.arena_rec = c.take<int4>(n);
+    w.arena_total = c.take<int>(1);
     w.frame_base = c.take<int>(batch + 1);
     w.tile_state = c.take<unsigned long long>(hvpr_cdiv(n > 0 ? n : 1, kScanTile));
     w.ticket = c.take<int>(1);

@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(kScanThreads) k2_scan(int n, const int *__rest
             }
             if (i == n - 1) {
                 const int total = (int)(ra + fl[k]);
+                *w.arena_total = (int)(rb + ct[k]);
                 for (int bb = batch; bb >= 0 && foff[bb] == n; --bb) w.frame_base[bb] = total;
             }
         }
@@ -184,10 +185,15 @@ __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ fo
     const int local = r - w.frame_base[b];
     const int slot = atomicSub(&w.cell_count[g], 1) - 1;   // returns the map to its idle 0
     if (!for_encode) w.cell_first[g] = kIdle;              // idle again (benign same-value race)
-    if (local < max_voxels) {
-        const int pos = w.vox_rec[r].z + slot;
+    const int4 rec = w.vox_rec[r];
+    const int pos = rec.z + slot;
+    if (for_encode) {
+        // every arena position gets its record, the ones of voxels beyond the cap too (rank -1): a pillar wave reads
+        // fixed windows of the arena and must be able to tell what it is looking at
+        w.arena_rec[pos] = make_int4(i, local < max_voxels ? r : -1, rec.y, g);
+        if (local < max_voxels) w.arena_pt[pos] = pt;
+    } else if (local < max_voxels) {
         w.arena[pos] = i;
-        if (for_encode) w.arena_pt[pos] = pt;
     }
 }
 
