@@ -12,32 +12,46 @@ namespace {
 //
 // The top-k of the EXACT fp32 logits is found with a half-precision pre-filter and an exact re-check, so that the matrix
 // cores run at the fp16 rate (16x the fp32 MFMA rate) and the bank streams as 256 KB instead of 512 KB per workgroup:
-//   1. A[p][j] ~ f[p] . bank[j] on v_mfma_f32_16x16x32_f16 (operands rounded to fp16, fp32 accumulate), rows in LDS
-//      (never in HBM: the reference materialises M x 2000 floats twice).
+//   1. A[p][j] ~ f[p] . bank[j] on v_mfma_f32_16x16x32_f16 (operands rounded to fp16, fp32 accumulate).  The logits never
+//      leave the registers of the wave that computed them (round 4; rounds 1-3 kept 128 KB of rows in LDS and every pillar
+//      wave read its row back): wave w owns tiles w, w + 16, ..., lane (p, q) the items 16 t + 4 q .. + 3 of pillar p.
 //   2. Error bound per pillar: |A - L| <= eps_p for every item, L = the exact logit.  fp16 round-to-nearest errs by at most
 //      2^-11 |x| for a normal result and by at most 2^-14 = 6.1e-5 when the result is subnormal (assumed flushed to zero by
 //      the matrix cores: the weaker assumption), so with wmax_c = max_j |W_jc|
 //         eps_p = 1.0e-3 * sum_c |f_c| wmax_c  +  6.2e-5 * (sum_c |f_c| + sum_c wmax_c)  (+ 1e-30)
 //      ((1 + 2^-11)^2 - 1 = 0.00097680; the rest of 1.0e-3 covers the fp32 accumulation of both sides); a value beyond the
 //      fp16 range makes eps_p infinite (everything becomes a candidate: exact slow path).
-//      tau = a lower bound of the k-th largest A (k-th largest of the 64 lane maxima, 16 leading bits).  Every item of the
-//      exact top-k has A >= tau - 2 eps_p:  k items have A >= tau, hence L >= tau - eps, so the k-th largest L is
-//      >= tau - eps, and an item with L >= tau - eps has A >= tau - 2 eps.
-//   3. The ~25 candidates with A >= tau - 2 eps_p get their exact logit: L_j = butterfly-tree sum over the 64 channels of
-//      the fp32 products f_c * W_jc (rows gathered coalesced, lane = channel, and KEPT in registers; 32 candidates reduced
-//      at once by a vector-halving butterfly — the same summation tree as hvpr_reduce_sum<64>).
-//   4. top-k of (L desc, index asc) among the candidates = the exact top-k; softmax over the selected L (memory_module.py:
-//      70-72 recomputes the same dot products); weighted sum of the selected rows straight from the registers of step 3.
+//      tau = a lower bound of the k-th largest A: the k-th largest (16 leading bits) of the 64 per-lane maxima of the pillar
+//      (each the maximum of 32 items; they travel through 4 KB of LDS).  Every item of the exact top-k has
+//      A >= tau - 2 eps_p:  k items have A >= tau, hence L >= tau - eps, so the k-th largest L is >= tau - eps, and an item
+//      with L >= tau - eps has A >= tau - 2 eps.
+//   3. Every wave compares its 32 accumulators per lane with its pillar's threshold (sign bits of A - threshold shifted into
+//      one mask: two instructions per value) and appends its ~1.6 hits per pillar to the pillar's segment of a candidate
+//      table in LDS; the order inside the table is a fixed function of the item ids (wave, quarter, tile), so a pillar's
+//      result does not depend on its place in the batch.
+//   4. One wave per pillar: the ~25 candidates get their exact logit, LANE = CANDIDATE: each lane reads its own bank row
+//      (16 x 16 bytes) and runs a 64-term fma chain against the pillar's features (four partial sums) — no cross-lane
+//      reduction, up to 64 candidates in one go.  top-k of (L desc, index asc) among the candidates = the exact top-k;
+//      softmax over the selected L (memory_module.py:70-72 recomputes the same dot products); the selected (index, weight)
+//      pairs are compacted to the first lanes and their rows summed with lane = channel.
 // More than 64 candidates (mass ties, e.g. an all-zero feature row) takes an exact slow path over all items.
 // ------------------------------------------------------------------------------------------------
 constexpr int kC = 64;            // feature channels
 constexpr int kPillars = 16;      // pillars per workgroup
-constexpr int kItemsPad = 2048;   // logits row length in LDS
-constexpr int kPitch = kItemsPad + 4;   // row pitch in floats: the 16 pillar rows of one ds_write_b128 land in distinct banks
-constexpr int kThreads = 1024;    // 16 waves: one pillar per wave in the selection phase
+constexpr int kItemsPad = 2048;   // most items
+constexpr int kThreads = 1024;    // 16 waves: a 16th of the items each in steps 1 and 3, one pillar each in steps 2 and 4
+constexpr int kWaves = kThreads / 64, kMaxTiles = kItemsPad / 16 / kWaves;    // 8 tiles per wave at most
+constexpr int kSeg = 12;          // candidate slots per (pillar, wave); ~1.6 expected, more than kSeg: slow path
 constexpr float kRelErr = 1.0e-3f, kAbsErr = 6.2e-5f, kHalfMax = 65000.f;    // see 2. above
 
 using namespace hvpr_sel;
+
+__device__ __forceinline__ float vmaxr(float a, float b) {   // v_max_f32 without the operand quieting fmaxf() adds
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+struct op_maxr { __device__ __forceinline__ float operator()(float a, float b) const { return vmaxr(a, b); } };
 
 __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__restrict__ f, int M,
                                                              const int *__restrict__ m_device,
@@ -48,10 +62,12 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                                                              const int4 *__restrict__ coords, int batch, int nx, int ny,
                                                              int *__restrict__ cell_map, float *__restrict__ canvas,
                                                              int canvas_channels, int canvas_offset) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_logit = (float *)smem;                              // [kPillars][kPitch]
-    float *s_f = s_logit + kPillars * kPitch;                    // [kPillars][kC]
-    unsigned long long *s_cand = (unsigned long long *)(s_f + kPillars * kC);   // [waves][64]
+    __shared__ __attribute__((aligned(16))) float s_f[kPillars * kC];
+    __shared__ __attribute__((aligned(16))) float s_pm[kPillars * 64];       // per-lane maxima: [pillar][wave * 4 + quarter]
+    __shared__ float s_tau[kPillars];
+    __shared__ int s_cnt[kPillars * kWaves];                                 // hits of wave w for pillar p: [p][w]
+    __shared__ int s_cand[kPillars * kWaves * kSeg];                         // their item ids: [p][w][slot]
+    __shared__ __attribute__((aligned(16))) int s_list[kWaves * 64 * 2];     // per pillar wave: candidate list, then (index, weight) of the selected
     if (m_device) M = min(M, *m_device);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p0 = blockIdx.x * kPillars;
@@ -59,25 +75,25 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
     const int np = min(kPillars, M - p0);
 
 #ifdef HVPR_EXP_TIMING
-    const long long tt0 = __builtin_readcyclecounter();
+#define RO_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[i] = __builtin_readcyclecounter(); } while (0)
+    long long ts[12];
+#else
+#define RO_STAMP(i)
 #endif
+    RO_STAMP(0);
     for (int i = tid; i < kPillars * kC; i += kThreads) {
         const int p = i / kC;
         s_f[i] = p < np ? f[(size_t)(p0 + p) * kC + (i % kC)] : 0.f;
     }
-    // items past n_items never win: their logits are -inf (written once; the partial last tile stores only its live rows)
-    for (int i = tid; i < kPillars * (kItemsPad - n_items); i += kThreads)
-        s_logit[(i / (kItemsPad - n_items)) * kPitch + n_items + i % (kItemsPad - n_items)] = -INFINITY;
     __syncthreads();
+    RO_STAMP(1);
 
-#ifdef HVPR_EXP_TIMING
-    const long long tt1 = __builtin_readcyclecounter();
-#endif
-    // ---- phase 1: A[p][j] on the fp16 matrix cores.  D (16 items x 16 pillars) = A (items x K) . B (K x pillars), K = 2 x 32
+    // ---- step 1: A[p][j] on the fp16 matrix cores.  D (16 items x 16 pillars) = A (items x K) . B (K x pillars), K = 2 x 32
     // channels.  Lane (l15, q) holds channels 32h + 8q .. 32h + 8q + 7 of item / pillar l15 for both operands (the k index of
     // an MFMA is a free permutation as long as A and B agree).  B (the 16 pillars) stays in registers.
+    const int l15 = lane & 15, q = lane >> 4;
+    f32x4 acc[kMaxTiles];
     {
-        const int l15 = lane & 15, q = lane >> 4;
         f16x8_t bfrag[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -88,111 +104,162 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
             bfrag[h] = __builtin_bit_cast(f16x8_t, u);
         }
         // the wave's tiles of the packed bank ([tile][half][lane] 16 bytes: every load instruction reads 1 KB contiguous), all
-        // requested up front.  (Requesting them before the feature fetch was measured slower: the features then queue behind
-        // 16 KB per wave in vmcnt order.)
-        constexpr int kWaves = kThreads / 64, kMaxTiles = kItemsPad / 16 / kWaves;    // 8 tiles per wave at most
+        // requested up front
         const int n_tiles = (n_items + 15) >> 4;
-        const int first = (int)((__builtin_amdgcn_readfirstlane((unsigned)wid) + blockIdx.x) % (unsigned)kWaves);   // de-phase the workgroups' bank streams
         uint4 a[kMaxTiles][2];
 #pragma unroll
         for (int i = 0; i < kMaxTiles; ++i) {
-            const int t = first + i * kWaves;                      // wave-uniform
+            const int t = wid + i * kWaves;                      // wave-uniform
             if (t < n_tiles) {
                 a[i][0] = bank_bf[(size_t)t * 128 + lane];
                 a[i][1] = bank_bf[(size_t)t * 128 + 64 + lane];
             }
         }
-        float *const lrow = s_logit + l15 * kPitch + 4 * q;       // this lane's logits slot inside tile 0
+        float lmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < kMaxTiles; ++i) {
-            const int t = first + i * kWaves;
+            const int t = wid + i * kWaves;
+            acc[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};     // items past n_items never win
             if (t < n_tiles) {
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[i][0]), bfrag[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[i][1]), bfrag[1], acc, 0, 0, 0);
+                f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[i][0]), bfrag[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[i][1]), bfrag[1], c, 0, 0, 0);
                 // C/D map of 16x16: column (pillar) = lane & 15, row (item) = 4 * (lane >> 4) + reg
-                if (16 * t + 16 <= n_items) {
-                    *(float4 *)(lrow + t * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                } else {
+                if (16 * t + 16 > n_items) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (16 * t + 4 * q + r < n_items) lrow[t * 16 + r] = acc[r];
+                        if (16 * t + 4 * q + r >= n_items) c[r] = -INFINITY;
                 }
+                acc[i] = c;
+                lmax = vmaxr(vmaxr(lmax, vmaxr(c[0], c[1])), vmaxr(c[2], c[3]));
+            }
+        }
+        s_pm[l15 * 64 + wid * 4 + q] = lmax;
+    }
+    RO_STAMP(2);
+    __syncthreads();
+    RO_STAMP(3);
+
+    // ---- step 2: wave w -> threshold of pillar w ----
+    const float wm = wmax[lane];
+    float fc = 0.f;
+    bool exact_all = false;     // this wave's pillar is outside the fp16 range: no pre-filter
+    if (wid < np) {
+        fc = s_f[wid * kC + lane];                      // lane = channel
+        const float wsum = hvpr_reduce_sum<64>(wm), wtop = hvpr_reduce<64>(wm, op_maxr());
+        // 2 eps_p: the bound on |A - L| of this pillar, doubled (see the header); infinite outside the fp16 range
+        const float fa = fabsf(fc);
+        float eps2 = 2.f * (hvpr_reduce_sum<64>(fmaf(kRelErr * wm, fa, kAbsErr * fa)) + kAbsErr * wsum + 1e-30f);
+        if (!(hvpr_reduce<64>(fa, op_maxr()) <= kHalfMax) || !(wtop <= kHalfMax)) eps2 = INFINITY;
+        exact_all = !(eps2 < INFINITY);
+        // tau <= k-th largest of the 64 lane maxima (its 16 leading bits): a lower bound of the k-th largest A
+        const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(s_pm[wid * 64 + lane]), k));
+        // tau = -inf or eps2 = inf / NaN let every live item through; the -inf padding past n_items never passes
+        if (lane == 0) s_tau[wid] = fmaxf(tau - eps2, -3.4028235e38f);
+    }
+    RO_STAMP(4);
+    __syncthreads();
+    RO_STAMP(5);
+
+    // ---- step 3: every wave: which of its 32 values per lane reach the threshold of the lane's pillar ----
+    {
+        const float tl = s_tau[l15];
+        unsigned below = 0u;    // bit 31 - (4 i + r): A < threshold (the sign of the difference; -inf padding stays below)
+#pragma unroll
+        for (int i = 0; i < kMaxTiles; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) below = __builtin_amdgcn_alignbit(below, __float_as_uint(acc[i][r] - tl), 31);
+        unsigned hits = l15 < np ? ~below : 0u;
+        const int mine = __popc(hits);
+        // position inside the (pillar, wave) segment: the lanes of the lower quarters first
+        const int c1 = __shfl_up(mine, 16, 64), c2 = __shfl_up(mine, 32, 64), c3 = __shfl_up(mine, 48, 64);
+        int pos = (q >= 1 ? c1 : 0) + (q >= 2 ? c2 : 0) + (q >= 3 ? c3 : 0);
+        if (q == 3) s_cnt[l15 * kWaves + wid] = pos + mine;
+        int *seg = s_cand + (l15 * kWaves + wid) * kSeg;
+        while (__ballot(hits != 0u) != 0ull) {
+            if (hits != 0u) {
+                const int b = __clz((int)hits);           // 4 i + r, ascending item order
+                hits &= ~(0x80000000u >> b);
+                if (pos < kSeg) seg[pos] = 16 * (wid + (b >> 2) * kWaves) + 4 * q + (b & 3);
+                ++pos;
             }
         }
     }
+    RO_STAMP(6);
     __syncthreads();
+    RO_STAMP(7);
 
-#ifdef HVPR_EXP_TIMING
-    const long long tt2 = __builtin_readcyclecounter();
-    long long tt3 = tt2, tt4 = tt2, tt5 = tt2;
-    int t_cnt = 0;
-#endif
-    // ---- phase 2-4: one wave per pillar ----
-    unsigned long long *cand = s_cand + wid * 64;
-    // sum_c wmax_c and max_c wmax_c (the same for every pillar)
-    const float wm = wmax[lane];
-    const float wsum = hvpr_reduce_sum<64>(wm), wtop = hvpr_reduce_max<64>(wm);
-    for (int p = wid; p < np; p += kThreads / 64) {
-        const float *row = s_logit + p * kPitch;
-        const float fc = s_f[p * kC + lane];                      // lane = channel
-        // 2 eps_p: the bound on |A - L| of this pillar, doubled (see the header); infinite outside the fp16 range
-        const float fa = fabsf(fc);
-        float eps2 = 2.f * (hvpr_reduce_sum<64>(fmaf(kRelErr * wm, fa, kAbsErr * fa)) + kAbsErr * wsum + 1e-30f);   // one reduction
-        if (!(hvpr_reduce_max<64>(fa) <= kHalfMax) || !(wtop <= kHalfMax)) eps2 = INFINITY;
-        float v[kItemsPad / 64];
-        float lmax = -INFINITY;
+    // ---- step 4: one wave per pillar ----
+    if (wid >= np) return;
+    {
+        const int p = wid;
+        int *list = s_list + wid * 128;
+        // candidate list of the pillar: the 16 wave segments back to back
+        int cw = lane < kWaves ? s_cnt[p * kWaves + lane] : 0;
+        const bool over = __ballot(cw > kSeg) != 0ull;
+        int pf = cw;                                      // inclusive prefix over lanes 0..15 (one DPP row)
+        pf += __builtin_amdgcn_update_dpp(0, pf, 0x111, 0xf, 0xf, true);
+        pf += __builtin_amdgcn_update_dpp(0, pf, 0x112, 0xf, 0xf, true);
+        pf += __builtin_amdgcn_update_dpp(0, pf, 0x114, 0xf, 0xf, true);
+        pf += __builtin_amdgcn_update_dpp(0, pf, 0x118, 0xf, 0xf, true);
+        int cnt = __builtin_amdgcn_readlane(pf, 15);
+        if (over || exact_all) cnt = 65;
+        if (cnt <= 64) {
+            const int w2 = lane >> 2, s2 = lane & 3;      // lane (wave segment, slot)
+            const int cw2 = __shfl(cw, w2, 64), base2 = __shfl(pf - cw, w2, 64);
 #pragma unroll
-        for (int t = 0; t < kItemsPad / 64; ++t) { v[t] = row[lane + 64 * t]; lmax = fmaxf(lmax, v[t]); }
-        // tau <= k-th largest of the 64 lane maxima (its 16 leading bits): a lower bound of the k-th largest A
-        const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(lmax), k));
-        // tau = -inf or eps2 = inf / NaN let every live item through; the -inf padding past n_items never passes
-        const float tau_lo = fmaxf(tau - eps2, -3.4028235e38f);
-        // candidates (not below tau_lo) per lane as a bit mask, then compacted rank by rank: rank r of every lane with more
-        // than r candidates goes to LDS at a ballot-prefix position.  ~25 candidates, at most a few per lane.
-        unsigned hits = 0u;
-#pragma unroll
-        for (int t = 0; t < kItemsPad / 64; ++t) hits |= v[t] >= tau_lo ? (1u << t) : 0u;
-        int cnt = 0;
-        for (unsigned left = hits; __ballot(left != 0u) != 0ull;) {
-            const bool has = left != 0u;
-            const unsigned long long m = __ballot(has);
-            const int t = has ? __ffs((int)left) - 1 : 0;
-            left &= left - 1u;
-            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-            if (has && pos < 64) cand[pos] = (unsigned long long)(unsigned)(lane + 64 * t);
-            cnt += __popcll(m);
+            for (int r = 0; r < kSeg / 4; ++r)
+                if (s2 + 4 * r < cw2) list[base2 + s2 + 4 * r] = s_cand[(p * kWaves + w2) * kSeg + s2 + 4 * r];
         }
-        if (!(eps2 < INFINITY)) cnt = 65;     // out of the fp16 range (A may be inf / NaN): no pre-filter, exact slow path
-#ifdef HVPR_EXP_TIMING
-        tt3 = __builtin_readcyclecounter(); t_cnt = cnt;
-#endif
+        RO_STAMP(8);
         // From here lane c < 64 owns candidate c: its item id, its exact logit, whether it is selected, its softmax weight.
         int my_idx = 0;
         float L = -INFINITY;
         bool sel = false;
-        float rows0[32];                   // the rows of candidates 0..31 (lane = channel), kept for the weighted sum
         if (cnt <= 64) {
-            my_idx = lane < cnt ? (int)cand[lane] : 0;
+            my_idx = lane < cnt ? list[lane] : 0;
+            // exact logits, FOUR LANES PER CANDIDATE: lane (c4, qq) reads channels 16 qq .. 16 qq + 15 of candidate 16 g + c4
+            // (a lane per candidate would touch 64 cache lines per load instruction: measured 25 % slower than rounds 1-3),
+            // four fma chains each, the quad is summed by two DPP exchanges, then the sums move to lane = candidate
+            const int c4 = lane >> 2, qq = lane & 3;
+            float4 fq[4];
 #pragma unroll
-            for (int r = 0; r < 32; ++r)   // lanes past cnt hold item 0: harmless
-                rows0[r] = bank[(size_t)__builtin_amdgcn_readlane(my_idx, r) * kC + lane];
-            {
-                float x[32];
+            for (int i = 0; i < 4; ++i) fq[i] = *(const float4 *)(s_f + p * kC + 16 * qq + 4 * i);
+            // candidates 0..31 (two groups of 16) are requested at once, unconditionally; 32..63 only when there are that many
+            float4 rv[4][4];
 #pragma unroll
-                for (int r = 0; r < 32; ++r) x[r] = __fmul_rn(rows0[r], fc);
-                const float s0 = wave_sum32(x, lane);              // lane l: exact logit of candidate l & 31
-                if (lane < 32) L = s0;
+            for (int g = 0; g < 2; ++g) {
+                const int id = 16 * g + c4 < cnt ? list[16 * g + c4] : 0;
+                const float4 *rowp = (const float4 *)(bank + (size_t)id * kC + 16 * qq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rv[g][i] = rowp[i];
             }
-            if (cnt > 32) {                                        // wave-uniform, uncommon: candidates 32..63
-                float x[32];
+            if (cnt > 32) {
 #pragma unroll
-                for (int r = 0; r < 32; ++r) x[r] = bank[(size_t)__builtin_amdgcn_readlane(my_idx, 32 + r) * kC + lane];
+                for (int g = 2; g < 4; ++g) {
+                    const int id = 16 * g + c4 < cnt ? list[16 * g + c4] : 0;
+                    const float4 *rowp = (const float4 *)(bank + (size_t)id * kC + 16 * qq);
 #pragma unroll
-                for (int r = 0; r < 32; ++r) x[r] = __fmul_rn(x[r], fc);
-                const float s1 = wave_sum32(x, lane);
-                if (lane >= 32) L = s1;
+                    for (int i = 0; i < 4; ++i) rv[g][i] = rowp[i];
+                }
             }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 2 || cnt > 32) {      // wave-uniform
+                    float a0 = rv[g][0].x * fq[0].x, a1 = rv[g][0].y * fq[0].y, a2 = rv[g][0].z * fq[0].z, a3 = rv[g][0].w * fq[0].w;
+#pragma unroll
+                    for (int i = 1; i < 4; ++i) {
+                        a0 = fmaf(rv[g][i].x, fq[i].x, a0); a1 = fmaf(rv[g][i].y, fq[i].y, a1);
+                        a2 = fmaf(rv[g][i].z, fq[i].z, a2); a3 = fmaf(rv[g][i].w, fq[i].w, a3);
+                    }
+                    float sq = (a0 + a1) + (a2 + a3);
+                    sq += hvpr_dpp<0xB1>(sq);    // quad_perm [1,0,3,2]
+                    sq += hvpr_dpp<0x4E>(sq);    // quad_perm [2,3,0,1]
+                    const float t = __shfl(sq, 4 * (lane & 15), 64);
+                    if ((lane >> 4) == g) L = t;
+                }
+            }
+            if (lane >= cnt) L = -INFINITY;
             const unsigned long long key = lane < cnt ? (((unsigned long long)ord_bits(L) << 32) | (unsigned)(0xffffffffu - (unsigned)my_idx)) : 0ull;
             const int kk = min(k, cnt);
             // select on the 32 value bits; the 32 index bits only matter when equal values straddle the k-th place
@@ -206,18 +273,25 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                 sel = key != 0ull && key >= kth;
             }
         } else {
-            // exact slow path (mass ties): the exact logit of EVERY item (one reduction each), then k rounds of wave arg-max
-            // with (value desc, index asc) order; winner r goes to lane r
-#pragma unroll
+            // exact slow path (mass ties, values outside the fp16 range): the exact logit of EVERY item (the same four partial
+            // sums, one lane per item), then k rounds of wave arg-max with (value desc, index asc) order; winner r goes to lane r
+            float v[kItemsPad / 64];
+#pragma unroll 1
             for (int t = 0; t < kItemsPad / 64; ++t) {
-                float mine = -INFINITY;
-                for (int i = 0; i < 64; ++i) {
-                    const int j = 64 * t + i;                       // wave-uniform
-                    if (j >= n_items) break;
-                    const float s = hvpr_reduce_sum<64>(__fmul_rn(bank[(size_t)j * kC + lane], fc));
-                    if (lane == i) mine = s;
+                const int j = 64 * t + lane;
+                float s = -INFINITY;
+                if (j < n_items) {
+                    const float4 *rowp = (const float4 *)(bank + (size_t)j * kC);
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < kC / 4; ++i) {
+                        const float4 rv = rowp[i];
+                        const float4 fv = *(const float4 *)(s_f + p * kC + 4 * i);
+                        a0 = fmaf(rv.x, fv.x, a0); a1 = fmaf(rv.y, fv.y, a1); a2 = fmaf(rv.z, fv.z, a2); a3 = fmaf(rv.w, fv.w, a3);
+                    }
+                    s = (a0 + a1) + (a2 + a3);
                 }
-                v[t] = mine;
+                v[t] = s;
             }
             unsigned long long prev = ~0ull, key = 0ull;
             for (int r = 0; r < k; ++r) {
@@ -241,20 +315,17 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
             sel = lane < k && key != 0ull;
             L = sel ? ord_to_float((unsigned)(key >> 32)) : -INFINITY;
             my_idx = sel ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0;
-#pragma unroll
-            for (int r = 0; r < 32; ++r)   // k <= 32 winners sit in lanes 0..k-1
-                rows0[r] = bank[(size_t)__builtin_amdgcn_readlane(my_idx, r) * kC + lane];
         }
-#ifdef HVPR_EXP_TIMING
-        tt4 = __builtin_readcyclecounter();
-#endif
+        RO_STAMP(9);
         // softmax over the selected exact logits, in place: two DPP wave reductions (unselected lanes carry -inf / 0)
         const float logit = sel ? L : -INFINITY;
-        const float mx = hvpr_reduce_max<64>(logit);
+        const float mx = hvpr_reduce<64>(logit, op_maxr());
         const float e = sel ? __expf(logit - mx) : 0.f;
         const float a = e / hvpr_reduce_sum<64>(e);
         const unsigned long long selmask = __ballot(sel);
-        if (topk_idx && sel) topk_idx[(size_t)(p0 + p) * k + __popcll(selmask & ((1ull << lane) - 1ull))] = my_idx;
+        const int rank = __popcll(selmask & ((1ull << lane) - 1ull));
+        const int nsel = __popcll(selmask);
+        if (topk_idx && sel) topk_idx[(size_t)(p0 + p) * k + rank] = my_idx;
         long long cell = -1;           // fused a3+a4: this pillar's BEV cell (pointpillar_scatter.py:192, nz == 1)
         if (cell_map || canvas) {
             const int4 c = coords[p0 + p];
@@ -262,26 +333,44 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
                 cell = ((long long)c.x * ny + c.z) * nx + c.w;
             if (cell_map && lane == 0 && cell >= 0) cell_map[cell] = p0 + p;   // gather-form scatter: k_cell_map's job
         }
-        // lane = channel: weighted sum over candidates 0..31 from the rows already in registers (weight 0 if not selected);
-        // selected candidates 32..63 (uncommon) are read again, one row each
-        float acc = 0.f;
+        // the selected (index, weight) pairs move to the first lanes, then lane = channel: weighted sum of their rows
+        if (sel) { list[2 * rank] = my_idx; list[2 * rank + 1] = __float_as_int(a); }
+        const int2 mine = lane < nsel ? *(const int2 *)(list + 2 * lane) : make_int2(0, 0);
+        // (lanes past nsel carry item 0 with weight 0: the loads go out unconditionally, all in flight at once; rows past k
+        // are skipped as a block)
+        float rows[32];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), r)), rows0[r], acc);
-        for (unsigned long long m = selmask >> 32; m != 0ull; m &= m - 1ull) {
-            const int c = 32 + (__ffsll((long long)m) - 1);         // wave-uniform
-            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), c));
-            acc = fmaf(w, bank[(size_t)__builtin_amdgcn_readlane(my_idx, c) * kC + lane], acc);
+        for (int r = 0; r < 16; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
+        if (nsel > 16) {
+#pragma unroll
+            for (int r = 16; r < 24; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
         }
-        out[(size_t)(p0 + p) * kC + lane] = acc;
+        if (nsel > 24) {
+#pragma unroll
+            for (int r = 24; r < 32; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
+        }
+        float o = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
+        if (nsel > 16) {
+#pragma unroll
+            for (int r = 16; r < 24; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
+        }
+        if (nsel > 24) {
+#pragma unroll
+            for (int r = 24; r < 32; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
+        }
+        out[(size_t)(p0 + p) * kC + lane] = o;
         // fused encode path: the memory channels of this pillar's cell, straight into the pre-cleared NHWC canvas
-        if (canvas && cell >= 0) canvas[(size_t)cell * canvas_channels + canvas_offset + lane] = acc;
-    }
+        if (canvas && cell >= 0) canvas[(size_t)cell * canvas_channels + canvas_offset + lane] = o;
 #ifdef HVPR_EXP_TIMING
-    tt5 = __builtin_readcyclecounter();
-    if ((blockIdx.x == 3 || blockIdx.x == 100) && lane == 0 && (wid & 3) == 0)
-        printf("readout wg %d wave %d: features %lld | logits %lld | select %lld (cands %d) | exact+topk %lld | softmax+gather %lld cycles\n",
-               (int)blockIdx.x, wid, tt1 - tt0, tt2 - tt1, tt3 - tt2, t_cnt, tt4 - tt3, tt5 - tt4);
+        RO_STAMP(10);
+        if ((blockIdx.x == 3 || blockIdx.x == 100) && lane == 0 && (wid & 7) == 0)
+            printf("readout wg %d wave %d: features %lld | logits %lld | bar %lld | tau %lld | bar %lld | hits %lld | bar %lld | list %lld (cands %d) | "
+                   "exact+topk %lld | softmax+gather %lld cycles\n", (int)blockIdx.x, wid, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3],
+                   ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6], ts[8] - ts[7], cnt, ts[9] - ts[8], ts[10] - ts[9]);
 #endif
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -370,13 +459,10 @@ int hvpr_i_readout(const float *f, int M, const int32_t *m_device, const float *
     if (!f || !bank || !bank_packed || !out) return HVPR_ERR_INVALID_ARG;   // the packed copy is required (fp16 tiles + channel maxima)
     if ((cell_map || canvas) && !coords) return HVPR_ERR_INVALID_ARG;
     if (canvas && canvas_offset + kC > canvas_channels) return HVPR_ERR_INVALID_ARG;
-    const size_t lds = (size_t)kPillars * kPitch * 4 + kPillars * kC * 4 + (kThreads / 64) * 64 * 8;
-    static unsigned long long lds_set = 0ull;   // per device
-    if (hvpr_ensure_dyn_lds((const void *)k_memory_readout, (int)lds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
     const int n_tiles = hvpr_cdiv(n_items, 16);
     const uint4 *bank_bf = (const uint4 *)bank_packed;
     const float *wmax = bank_packed + (size_t)n_tiles * 512;      // 2 KB of fp16 per tile = 512 floats
-    hipLaunchKernelGGL(k_memory_readout, dim3(hvpr_cdiv(M, kPillars)), dim3(kThreads), lds, stream, f, M, m_device, bank,
+    hipLaunchKernelGGL(k_memory_readout, dim3(hvpr_cdiv(M, kPillars)), dim3(kThreads), 0, stream, f, M, m_device, bank,
                        bank_bf, wmax, n_items, k, out, topk_idx, (const int4 *)coords, batch, nx, ny, cell_map, canvas, canvas_channels,
                        canvas_offset);
     HVPR_CHECK_LAUNCH();
