@@ -81,6 +81,7 @@ struct GatherSrc {
     int idx_bits;           // bits of the largest point index
     int n_points;
     FastDiv div_nx, div_cells;   // by nx, by nx * ny
+    int split;              // one round of windows: a second set of workgroups takes every wave's passes after the first (below)
 };
 
 struct VfeParams {
@@ -428,9 +429,19 @@ __device__ __forceinline__ void vfe_pass(const Wreg &W, WaveLds &L, const float 
 __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, GatherSrc g) {
     const int fill_blocks = (int)gridDim.x - g.work_blocks;   // dispatched first: they are the bandwidth work
     if ((int)blockIdx.x < fill_blocks) {
+#ifdef HVPR_EXP_TIMING
+        const long long f0 = __builtin_amdgcn_s_memrealtime();
+#endif
         hvpr_canvas_clear(g.clear, blockIdx.x, fill_blocks);
+#ifdef HVPR_EXP_TIMING
+        if ((blockIdx.x == 0 || blockIdx.x == fill_blocks - 1 || blockIdx.x == fill_blocks / 2) && threadIdx.x == 0)
+            printf("vfe-abs fill blk %d: %lld .. %lld (x10 ns)\n", (int)blockIdx.x, f0, (long long)__builtin_amdgcn_s_memrealtime());
+#endif
         return;
     }
+#ifdef HVPR_EXP_TIMING
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     __shared__ __attribute__((aligned(16))) WaveLds s_wave[4];
     __shared__ __attribute__((aligned(16))) float s_zt[4][160];
     __shared__ int s_sel[4][32];
@@ -442,8 +453,15 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
 #endif
     static_assert(sizeof(s_wave) >= (C1 * 36 + CS1 * 20 + C0 * CIN) * sizeof(float), "weight staging area");
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31;
-    const long long wave0 = ((long long)(blockIdx.x - fill_blocks) * blockDim.x + threadIdx.x) >> 6;
-    const long long n_waves = ((long long)g.work_blocks * blockDim.x) >> 6;
+    // One frame is a single round of windows with most SIMDs idle, and the launch lasts as long as its slowest wave: a wave
+    // whose window needs a second pass (a voxel with more points than slots, a pillar that did not fit) takes twice as long as
+    // the others.  With g.split the upper half of the work groups walks the same windows and takes over every pass AFTER the
+    // first (role 1), the lower half stops after its first pass (role 0): same results, the chain of every wave is one pass long.
+    const int role_blocks = g.split ? g.work_blocks / 2 : g.work_blocks;
+    const int wblk = (int)blockIdx.x - fill_blocks;
+    const int role = wblk >= role_blocks ? 1 : 0;
+    const long long wave0 = ((long long)(wblk - role * role_blocks) * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)role_blocks * blockDim.x) >> 6;
 
     // the first window is requested before anything else: the weight staging below hides its round trip
     int4 rec = make_int4(0, -2, 0, 0);
@@ -495,7 +513,11 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
         const unsigned long long startmask = __ballot(flag);
         unsigned long long todo = __ballot(flag && lane <= kWin && rec.y >= 0);
 
+        bool first = true;
         while (todo != 0ull) {
+            const bool mine = !g.split || (first ? role == 0 : role == 1);
+            if (g.split && role == 0 && !first) break;
+            first = false;
             const int s = __ffsll((long long)todo) - 1;   // wave-uniform: the pass begins at this pillar start
             const int cnt_s = __builtin_amdgcn_readlane(rec.z, s);
             float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -506,6 +528,7 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                 // ---- a voxel with more points than slots (~1 %): a pass of its own.  Select the P smallest point indices of
                 // its arena segment, ascending, then fetch the points
                 todo &= todo - 1ull;
+                if (!mine) continue;
                 const long long a0 = base + s;
                 const int cnt = cnt_s, slot = col;
                 cell = __builtin_amdgcn_readlane(rec.w, s);
@@ -593,6 +616,10 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                         if (rc < g.w.frame_base[b + 1]) cutoff = g.w.vox_rec[rc].w;
                     }
                 }
+                if (!mine) {   // the other role's pass: only which pillars it takes
+                    todo &= ~((__ballot(proc && col == seg0) & 0xffffffffull) << s);
+                    continue;
+                }
                 // The points of a pillar go by ascending index.  K3 hands out a voxel's arena slots from the top, so when the
                 // points arrived in index order — the usual case, workgroups are dispatched in order — every segment is already
                 // DESCENDING and reading it backwards is all it takes; otherwise a sorting network on (segment, index, source
@@ -646,7 +673,7 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
             vfe_pass<true>(W, L, s_zt[wid], v, pt, live, live, proc, proc && n < P, n, seg0, cd, row, cell, endmask, startsproc, g.spatial,
                            g.spatial_channels, g.spatial_scale VFE_TPASS);
 #ifdef HVPR_EXP_TIMING
-            if (((blockIdx.x - fill_blocks) % 97 == 0) && threadIdx.x == 0)
+            if (false)
                 printf("vfe wg %d pass %d (pillars %d): prologue %lld | to first pass %lld | front %lld | decor %lld | l0+a %lld | xmax %lld | "
                        "pillar mfma %lld | combine %lld | final %lld cycles\n", (int)blockIdx.x - fill_blocks, t_passes, __popc(endmask),
                        tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4],
@@ -656,6 +683,12 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
         rec = rec_next;
         apt = apt_next;
     }
+#ifdef HVPR_EXP_TIMING
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if ((wblk % 37) == 0 && threadIdx.x == 0)
+        printf("vfe-abs work blk %d role %d passes %d: %lld .. %lld (x10 ns), prologue %lld cycles\n", wblk, role, t_passes, rt0,
+               (long long)__builtin_amdgcn_s_memrealtime(), tstamp[1] - tstamp[0]);
+#endif
 }
 
 // separate-call form: padded voxels in, one pillar per pass
@@ -703,6 +736,8 @@ int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxe
     int blocks = hvpr_cdiv(windows, 4);
     if (blocks > 512) blocks = 512;   // two workgroups per CU: beyond one round the waves walk their windows (one weight staging each)
     if (blocks < 1) blocks = 1;
+    const int split = blocks <= 256 ? 1 : 0;   // one round with room to spare: first passes and later passes on different waves
+    if (split) blocks *= 2;
     int idx_bits = 1;
     while (idx_bits < 22 && (1ll << idx_bits) < (long long)a.n_points) ++idx_bits;
     const long long n_cells = (long long)a.batch * a.nx * a.ny;
@@ -710,7 +745,7 @@ int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxe
                       spatial_scale, 0, n_cells, canvas_state};
     GatherSrc g{a.points, a.point_stride, a.xyz_col, a.batch, a.nx, a.ny, a.nz, a.max_voxels, a.cap_mode, capacity, w,
                 voxel_offsets, voxels, coords, num_points, spatial, spatial_channels, spatial_scale, blocks, cj, idx_bits, a.n_points,
-                make_fastdiv((unsigned)a.nx), make_fastdiv((unsigned)(a.nx * a.ny))};
+                make_fastdiv((unsigned)a.nx), make_fastdiv((unsigned)(a.nx * a.ny)), split};
     const VfeParams vp{v.vs_x, v.vs_y, v.vs_z, v.off_x, v.off_y, v.off_z, v.w0, v.b0, v.w1, v.b1, v.ws0, v.bs0, v.ws1, v.bs1,
                        pillar_features, scale_features, pillar_mask};
     // three 64-cell steps per wave: few, long-lived workgroups — they hold slots the pillar workgroups want
