@@ -601,6 +601,12 @@ def cfg_from_model_cfg(cfg):
 # a9 (training)  PointNet++ index ops — pcdet/ops/pointnet2/pointnet2_batch (ABSENT from the reference,
 # setup.py:94-109; restated from SURVEY.md Appendix B.4).  PARITY UNPINNED.  fp32 distances computed as
 # (dx*dx + dy*dy) + dz*dz; ties resolve to the lowest index (the build's defined rule).
+# NOTE on the tie rule: upstream's furthest_point_sampling kernel takes a strided per-thread arg-max followed by a tree reduction
+# that keeps the FIRST operand on equal distances — on exact ties its winner depends on the block size and need not be the lowest
+# index.  Exact ties do occur: sample_points pads short clouds with DUPLICATES of existing points (data_processor.py:100-104).  A
+# duplicate has distance 0 to the set as soon as its twin is picked, so a tie can only move the pick between two copies of the same
+# coordinates: the sampled COORDINATES, hence every feature, are the same under either rule; only the index bookkeeping may differ.
+# This rule is therefore the build's own, unpinnable (source absent), and harmless to features.
 # ----------------------------------------------------------------------------------------
 def _d2(a, b):
     d = (a - b).astype(np.float32)

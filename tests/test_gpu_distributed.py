@@ -35,3 +35,20 @@ def test_one_rank_rccl_group_real_detector_in_ddp_with_fused_optimizer(tmp_path)
     # of -+lr, so the worst relative difference of a tensor is O(1e-2) between ANY two runs (measured 0.019 both for DDP vs plain and
     # for plain vs plain); the equal losses of steps 2 and 3 above are the sharp statement, this one only excludes a gross error
     assert r["state_diff_ddp_vs_plain"] <= max(0.1, 5 * r["state_diff_rerun_vs_plain"]), r
+
+
+def test_bench_train_step_ddp_line_over_one_rank_rccl(tmp_path):
+    """`bench.py --gpus N` (N > 1) also times the config-4 training step inside DistributedDataParallel, so that the driver's
+    scaling run measures the RCCL gradient all-reduce (reference tools/train.py:143-145) without a code change.  Here: the same
+    function over a one-rank RCCL group (all this pool can run), batch 2."""
+    from hvpr_amd import distributed
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bench_ddp_worker.py")
+    out = tmp_path / "ddp_line.json"
+    rc = distributed.launch_local(1, [worker, str(out), "2"], timeout=900)
+    assert rc == 0
+    r = json.load(open(out))
+    print(r)
+    assert r["backend"] == "nccl" and r["ranks"] == 1 and r["parallelism"] == "dp1"
+    assert 55.0 < r["allreduce_MB"] < 70.0                      # ~15.5 M fp32 gradients (SURVEY.md §8a a15)
+    assert r["ms_per_step"] > 0 and r["frames_per_s_global"] > 0
+    assert all(np.isfinite(r["loss_first_last"]))

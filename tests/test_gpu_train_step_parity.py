@@ -86,8 +86,10 @@ def test_whole_train_step_hip_equals_torch_forms(which):
           f"median {np.median(errs):.2e} max {errs.max():.2e} ({len(rows)} tensors)")
     for k, e in sorted(rows, key=lambda r: -r[1])[:5]:
         print(f"   {k:60s} {e:.2e}")
-    assert abs(tot_h - tot_r) <= 1e-2 * tot_r
-    assert np.median(errs) <= 1e-2 and errs.max() <= 1e-1, sorted(rows, key=lambda r: -r[1])[:5]
+    # bars at ~3x what the two configurations measure (round 4: total norm 1e-5, per-tensor median 2.2e-3 / 1.8e-3, max 6.6e-3 / 7.8e-3
+    # — the fp32 round-off of ~25 stacked convolutions through two streams), so that a real regression trips them
+    assert abs(tot_h - tot_r) <= 1e-4 * tot_r
+    assert np.median(errs) <= 7e-3 and errs.max() <= 2.5e-2, sorted(rows, key=lambda r: -r[1])[:5]
     # after the optimiser step (fused flat Adam + device-side clip vs per-tensor torch.optim.Adam + torch's clip): Adam's first update
     # is lr * g / (|g| + eps) ~ lr * sign(g), so the per-element comparison is of SIGNS of gradients — they agree except where the
     # gradient itself is within its own error of zero; norm-wise the update may differ by 2 * sqrt(fraction of such elements)
@@ -101,6 +103,6 @@ def test_whole_train_step_hip_equals_torch_forms(which):
         assert float((dh - dr).abs().max()) <= 2.05 * lr_now + 1e-7, k     # no element moves by more than one full Adam step apart
     ue = np.array([e for _, e in upd])
     print(f"   parameter update difference (norm-wise, relative to the update): median {np.median(ue):.2e} max {ue.max():.2e}")
-    assert np.median(ue) <= 5e-2, sorted(upd, key=lambda r: -r[1])[:5]
+    assert np.median(ue) <= 1e-3, sorted(upd, key=lambda r: -r[1])[:5]      # measured 2.1e-4 / 2.0e-4
     for k in br:                                     # running statistics of every BatchNorm after the step
         torch.testing.assert_close(bh[k], br[k], rtol=1e-4, atol=1e-5, msg=k)
