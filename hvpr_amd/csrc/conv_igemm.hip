@@ -346,6 +346,7 @@ extern "C" int hvpr_conv2d_nhwc_f32(const float *in, int N, int H, int W, int Ci
     if (up > 1 && (taps != 1 || gate)) return HVPR_ERR_UNSUPPORTED;
     // the epilogue moves four consecutive channels per access
     if (cout % 4 != 0 || out_cstride % 4 != 0 || out_coff % 4 != 0 || (resid && resid_cstride % 4 != 0)) return HVPR_ERR_UNSUPPORTED;
+    if ((long long)H * W * Cin * 4 >= (1ll << 31)) return HVPR_ERR_UNSUPPORTED;      // byte offsets inside one image are formed in signed 32-bit arithmetic
     ConvArgs a;
     a.in = in; a.wpk = w_packed; a.bias = bias; a.out = out; a.gate = gate; a.resid = resid;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin;

@@ -88,9 +88,11 @@ __global__ void __launch_bounds__(256) k_gt_conv(const float2 *__restrict__ pool
                 acc = fmaf(w18[ky * 3 + kx], q.x, acc);
                 acc = fmaf(w18[9 + ky * 3 + kx], q.y, acc);
             }
+        // statistics of the value BEFORE the bias is added: the variance does not depend on the shift, and a large conv bias
+        // (|mean| >> std) would otherwise cancel in E[a^2] - mean^2 of fp32 partial sums
+        v[0] = acc; v[1] = acc * acc;
         acc += bias[0];
         a[((size_t)n * H + oy) * W + ox] = acc;
-        v[0] = acc; v[1] = acc * acc;
     }
     const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     block_sums<2>(v, part + blk * 2);
@@ -115,13 +117,15 @@ __device__ __forceinline__ void final_sums(const float *__restrict__ part, int b
     }
 }
 
-__global__ void __launch_bounds__(256) k_gt_stats(const float *__restrict__ part, int blocks, double count, float eps, float *__restrict__ stats) {
+__global__ void __launch_bounds__(256) k_gt_stats(const float *__restrict__ part, int blocks, double count, float eps,
+                                                  const float *__restrict__ bias, float *__restrict__ stats) {
     double t[2];
-    final_sums<2>(part, blocks, t);
+    final_sums<2>(part, blocks, t);     // sums of (a - bias) and (a - bias)^2
     if (threadIdx.x == 0) {
-        const double m = t[0] / count;
-        double var = t[1] / count - m * m;
+        const double ms = t[0] / count;
+        double var = t[1] / count - ms * ms;
         if (var < 0.0) var = 0.0;
+        const double m = ms + (double)bias[0];
         stats[0] = (float)m; stats[1] = (float)var; stats[2] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
@@ -262,7 +266,7 @@ extern "C" int hvpr_spatial_gate_train_fwd_f32(const float *y, int N, int H, int
     const int n_tiles = (int)(tiles.x * tiles.y * tiles.z);
     hipLaunchKernelGGL(k_gt_pool, dim3(hvpr_cdiv(P, 32)), dim3(256), 0, s, y, P, C, (float2 *)pooled, argmax);
     hipLaunchKernelGGL(k_gt_conv, tiles, dim3(256), 0, s, (const float2 *)pooled, H, W, w18, conv_bias, a, part);
-    hipLaunchKernelGGL(k_gt_stats, dim3(1), dim3(256), 0, s, (const float *)part, n_tiles, (double)P, eps, stats);
+    hipLaunchKernelGGL(k_gt_stats, dim3(1), dim3(256), 0, s, (const float *)part, n_tiles, (double)P, eps, conv_bias, stats);
     hipLaunchKernelGGL(k_gt_apply, dim3(hvpr_cdiv(P, 256)), dim3(256), 0, s, (const float *)a, P, (const float *)stats, gamma, beta, gate);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;

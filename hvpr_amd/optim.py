@@ -159,9 +159,14 @@ class FusedAdamOneCycle:
 
     def zero_grad(self):
         """Gradients are zeroed, never set to None: autograd then accumulates in place into the flat views, and p.grad keeps its
-        address from step to step.  Under DistributedDataParallel(gradient_as_bucket_view=True) DDP owns p.grad (a view into its
-        all-reduce bucket): such a gradient is zeroed where it lives instead of being re-pointed (re-pointing made DDP copy the
-        whole gradient set into its buckets and re-point back every step), and _collect_grads copies the reduced values in."""
+        address from step to step.  distributed.wrap_ddp builds DistributedDataParallel with gradient_as_bucket_view=False (torch's
+        default, what the reference's train.py gets): DDP copies each reduced bucket back into the EXISTING p.grad tensors, i.e.
+        into the flat buffer — one extra device copy of the gradient set (~62 MB, ~25 us at HBM speed) per step in exchange for
+        addresses that never move.  The other mode (gradient_as_bucket_view=True: DDP owns p.grad, a view into its all-reduce
+        bucket) is still handled — such a gradient is zeroed where it lives instead of being re-pointed (re-pointing made DDP
+        copy the whole gradient set into its buckets and re-point back every step) and _collect_grads copies the reduced values
+        in — and covered by tests/test_distributed_gloo.py in both modes; it saves nothing measurable here (the copy it avoids is
+        replaced by the copy into the flat buffer)."""
         self.flat_g.zero_()
         for p, g in zip(self.params, self._grad_views):
             if p.grad is None:

@@ -170,6 +170,9 @@ def _train_forward(self, batch_dict, voxels, num, coords):
     mask = (torch.arange(P, device=voxels.device).view(1, -1) < num.view(-1, 1)).unsqueeze(-1).to(voxels.dtype)
     if not (voxels.is_cuda and voxels.dtype == torch.float32):
         raise RuntimeError("hvpr_amd: PillarVFE_Scale's training forward needs fp32 GPU tensors (the HIP path has no CPU fallback)")
+    if M == 0:
+        raise ValueError("hvpr_amd: PillarVFE_Scale's training forward got a batch without a single pillar (train-mode BatchNorm has "
+                         "no statistics to take; the reference divides by zero there)")
     if len(self.pfn_layers) != 2:
         raise ValueError("hvpr_amd: the VFE training kernels are built for two PFN layers (hvpr.yaml NUM_FILTERS: [32, 64])")
     l0, l1 = self.pfn_layers[0], self.pfn_layers[1]
@@ -179,26 +182,22 @@ def _train_forward(self, batch_dict, voxels, num, coords):
     x, m0, v0, m1, v1 = _PfnTrain.apply(voxels.contiguous(), _as_i32(num).contiguous(), _as_i32(coords).contiguous(),
                                         l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight,
                                         l1.norm.bias, l0.norm.eps, self.voxel_size, self.offsets)
-    if M > 0:
-        _update_running(l0.norm, m0, v0, M * P)
-        _update_running(l1.norm, m1, v1, M * P)
+    _update_running(l0.norm, m0, v0, M * P)
+    _update_running(l1.norm, m1, v1, M * P)
     # scale stream (pillar_vfe.py:213-216): [n, |mean|, mean] (5 columns, zero-padded to the convolution kernel's 8) through
     # Linear (no bias) + train-mode BatchNorm1d + ReLU twice, as 1x1 convolutions over the M rows on the library's kernels
     from . import conv_train as ct
     s = torch.cat([n.unsqueeze(1), torch.norm(mean, 2, 2), mean.squeeze(1), mean.new_zeros((M, 3))], dim=-1)
-    if M > 0:
-        t = s.view(1, 1, M, 8)
-        for seq in self.pfn_scale_layers:
-            lin, bn = seq[0], seq[1]
-            w = lin.weight
-            if lin.bias is not None or w.shape[0] % 8 != 0 or w.shape[1] > t.shape[-1]:
-                raise ValueError("hvpr_amd: the VFE scale stream kernels take bias-free layers with widths that are multiples of 8")
-            pad = t.shape[-1] - w.shape[1]
-            w = w if pad == 0 else torch.cat([w, w.new_zeros((w.shape[0], pad))], dim=1)
-            t = ct.bn_relu(ct.conv(t, w.view(w.shape[0], w.shape[1], 1, 1)), bn)
-        s = t.view(M, -1)
-    else:
-        s = s.new_zeros((0, self.num_scale_features[-1]))
+    t = s.view(1, 1, M, 8)
+    for seq in self.pfn_scale_layers:
+        lin, bn = seq[0], seq[1]
+        w = lin.weight
+        if lin.bias is not None or w.shape[0] % 8 != 0 or w.shape[1] > t.shape[-1]:
+            raise ValueError("hvpr_amd: the VFE scale stream kernels take bias-free layers with widths that are multiples of 8")
+        pad = t.shape[-1] - w.shape[1]
+        w = w if pad == 0 else torch.cat([w, w.new_zeros((w.shape[0], pad))], dim=1)
+        t = ct.bn_relu(ct.conv(t, w.view(w.shape[0], w.shape[1], 1, 1)), bn)
+    s = t.view(M, -1)
     batch_dict["pillar_features"] = x.reshape(M, -1)
     batch_dict["pillar_scale_features"] = s
     batch_dict["pillar_mask"] = mask
