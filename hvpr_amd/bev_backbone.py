@@ -45,25 +45,18 @@ def _conv_bn_relu(cin, cout, stride=1, zero_pad=False):
 
 # Workgroup tile of hvpr_conv2d_nhwc_f32 per layer group and level: 0 = 128 px x 128 ch, 1 = 64 px x 64 ch, 2 = 128 px x 64 ch.
 # Measured on MI355X at batch 1 inside the whole frame (bench.py; the two streams of the backbone interact, so the per-layer
-# micro-benchmarks tools/bench_conv.py / bench_conv1x1.py do not decide alone).  HVPR_CONV_TILES="ttt sss ccc ddd" (trunk, sfm,
-# scale, deconv per level) or HVPR_CONV_TILE=<one digit for all> override it for experiments.
+# micro-benchmarks tools/bench_conv.py / bench_conv1x1.py do not decide alone); the sweeps are in profiles/NOTES_r04.md.
 _TILES = {"trunk": (1, 1, 1), "sfm": (1, 1, 1), "scale": (1, 1, 1), "deconv": (1, 1, 1)}   # deconv level 2: 128 x 64 won 0.2 % in round 1's 3-stage pipeline, 64 x 64 wins 0.7 % in the 4-stage one
 
 
 def _tile_cfg(kind, level):
-    forced = os.environ.get("HVPR_CONV_TILE")
-    if forced is not None:
-        return int(forced)
-    table = os.environ.get("HVPR_CONV_TILES")
-    if table is not None:
-        groups = table.split()
-        return int(groups[("trunk", "sfm", "scale", "deconv").index(kind)][min(level, 2)])
     return _TILES[kind][min(level, 2)]
 
 
 def _wino_groups(level):
-    """Pixel groups per workgroup of the Winograd kernel per level (1: 8 x 16 px, 2: 16 x 16 px); HVPR_WINO_GROUPS="111"."""
-    return int(os.environ.get("HVPR_WINO_GROUPS", "111")[min(level, 2)])
+    """Pixel groups per workgroup of the Winograd kernel: 1 = 8 x 16 px x 64 channels on every level (16 x 16 px workgroups and
+    32-channel tiles were measured slower inside the frame pipeline, profiles/NOTES_r04.md)."""
+    return 1
 
 
 class BaseBEVBackbone_Scale(nn.Module):
@@ -215,8 +208,7 @@ class BaseBEVBackbone_Scale(nn.Module):
                     k += 1
                 conv, bn = mods[k], mods[k + 1]
                 last = k + 3 >= len(mods)
-                if last and gate is not None and resid is t and conv.stride[0] == 1 and conv.kernel_size[0] == 3 \
-                        and os.environ.get("HVPR_TRAIN_SFM", "fused") == "fused":
+                if last and gate is not None and resid is t and conv.stride[0] == 1 and conv.kernel_size[0] == 3:
                     t = ct.sfm_step(t, conv.weight, bn, gate)            # the SFM step as one autograd node
                 else:
                     z, partials = ct.conv(t, conv.weight, conv.stride[0], stats=True)
@@ -377,10 +369,10 @@ class BaseBEVBackbone_Scale(nn.Module):
 
     def split_buffers(self, batch_size, H, W, device, level=None):
         """Boundary buffers of the two-phase forward for canvases of (H, W): x[i] (trunk output of every level i >= level), y
-        (scale output of level - 1), out (the concat).  level defaults to the last one (HVPR_PIPE_SPLIT overrides); >= 1."""
+        (scale output of level - 1), out (the concat).  level defaults to the last one; >= 1."""
         n_lv = len(self.blocks)
         if level is None:
-            level = int(os.environ.get("HVPR_PIPE_SPLIT", n_lv - 1))
+            level = n_lv - 1
         assert 1 <= level <= n_lv - 1
         h, w, hw = H, W, []
         for s in self.layer_strides:

@@ -14,8 +14,6 @@ Activations are NHWC tensors (N, H, W, C) — what torch calls channels_last —
                       hvpr_bn_relu_fwd_nhwc_f32, hvpr_bn_relu_bwd_nhwc_f32; running statistics updated like nn.BatchNorm2d
                       (momentum, unbiased variance, one update per CALL — SURVEY.md B.5).
 """
-import os
-
 import torch
 
 from . import kernels
@@ -36,15 +34,12 @@ def _workspace(nbytes, device):
 
 def _tile_cfg(cout):
     """Workgroup tile of hvpr_conv2d_nhwc_f32 (0 = 128 px x 128 ch, 1 = 64 x 64, 2 = 128 x 64).  Measured on the batch-16 training
-    step: 612 / 593 / 595 ms — the 64 x 64 tile the kernel was tuned on at batch 1 also wins here.  HVPR_TRAIN_TILE overrides."""
-    forced = os.environ.get("HVPR_TRAIN_TILE")
-    if forced is not None and (int(forced) != 0 or cout % 128 == 0):
-        return int(forced)
+    step: 612 / 593 / 595 ms — the 64 x 64 tile the kernel was tuned on at batch 1 also wins here."""
     return 1
 
 
 def _wino_groups():
-    return int(os.environ.get("HVPR_TRAIN_WINO_GROUPS", "1"))
+    return 1          # 8 x 16 px x 64 channel Winograd workgroups (the only form with fused BatchNorm statistics)
 
 
 def bn_statistics(z, eps, partials=None):
@@ -74,7 +69,7 @@ def conv_fwd_raw(x, weight, stride=1, adjoint=False, stats=False):
             and weight.shape[0 if adjoint else 1] % 8 == 0:
         g = _wino_groups()
         partials = None
-        if stats and g == 1 and os.environ.get("HVPR_TRAIN_BN_STATS", "fused") == "fused":
+        if stats and g == 1:
             N, H, W, _ = x.shape
             cout = weight.shape[1 if adjoint else 0]
             partials = torch.empty((lib().hvpr_conv2d_wino_stats_rows(N, H, W), 2, cout), dtype=torch.float32, device=x.device)
@@ -92,7 +87,7 @@ def conv_wgrad(x, dz, taps, stride, cout, cin):
     OH, OW = dz.shape[1], dz.shape[2]
     k = 3 if taps == 9 else 1
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
-    if taps == 9 and stride == 1 and kernels.conv_algo() == "winograd" and os.environ.get("HVPR_TRAIN_WGRAD", "winograd") == "winograd":
+    if taps == 9 and stride == 1 and kernels.conv_algo() == "winograd":
         nbytes = lib().hvpr_conv2d_wino_wgrad_workspace_bytes(N, H, W, cin, cout)
         ws = _workspace(nbytes, x.device)
         check(lib().hvpr_conv2d_wino_wgrad_nhwc_f32(kernels._ptr(x, torch.float32, "x"), N, H, W, cin, kernels._ptr(dz, torch.float32, "dz"),

@@ -37,9 +37,12 @@ namespace {
 // More than 64 candidates (mass ties, e.g. an all-zero feature row) takes an exact slow path over all items.
 // ------------------------------------------------------------------------------------------------
 constexpr int kC = 64;            // feature channels
-constexpr int kPillars = 16;      // pillars per workgroup
+constexpr int kSets = 1;           // sets of 16 pillars (the matrix-core columns) per workgroup.  2 (the bank tiles read once for 32 pillars, each wave
+                                   // two pillars in turn) measured SLOWER at every size: 22.1 / 166.9 / 608 us against 12.0 / 161.2 / 587 us (batch 1 /
+                                   // batch 16 / dense scene) — the chain of a workgroup gets longer and nothing overlaps it (one workgroup per CU)
+constexpr int kPillars = 16 * kSets;   // pillars per workgroup
 constexpr int kItemsPad = 2048;   // most items
-constexpr int kThreads = 1024;    // 16 waves: a 16th of the items each in steps 1 and 3, one pillar each in steps 2 and 4
+constexpr int kThreads = 1024;    // 16 waves: a 16th of the items each in steps 1 and 3, one pillar of every set each in steps 2 and 4
 constexpr int kWaves = kThreads / 64, kMaxTiles = kItemsPad / 16 / kWaves;    // 8 tiles per wave at most
 constexpr int kSeg = 12;          // candidate slots per (pillar, wave); ~1.6 expected, more than kSeg: slow path
 constexpr float kRelErr = 1.0e-3f, kAbsErr = 6.2e-5f, kHalfMax = 65000.f;    // see 2. above
@@ -92,90 +95,106 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
     // channels.  Lane (l15, q) holds channels 32h + 8q .. 32h + 8q + 7 of item / pillar l15 for both operands (the k index of
     // an MFMA is a free permutation as long as A and B agree).  B (the 16 pillars) stays in registers.
     const int l15 = lane & 15, q = lane >> 4;
-    f32x4 acc[kMaxTiles];
+    f32x4 acc[kSets][kMaxTiles];
     {
-        f16x8_t bfrag[2];
+        f16x8_t bfrag[kSets][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4 lo = *(const float4 *)(s_f + l15 * kC + 32 * h + 8 * q), hi = *(const float4 *)(s_f + l15 * kC + 32 * h + 8 * q + 4);
-            const unsigned w0 = f16_rne(lo.x) | (f16_rne(lo.y) << 16), w1 = f16_rne(lo.z) | (f16_rne(lo.w) << 16);
-            const unsigned w2 = f16_rne(hi.x) | (f16_rne(hi.y) << 16), w3 = f16_rne(hi.z) | (f16_rne(hi.w) << 16);
-            const uint4 u = make_uint4(w0, w1, w2, w3);
-            bfrag[h] = __builtin_bit_cast(f16x8_t, u);
-        }
+        for (int st = 0; st < kSets; ++st)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *fp = s_f + (16 * st + l15) * kC + 32 * h + 8 * q;
+                const float4 lo = *(const float4 *)fp, hi = *(const float4 *)(fp + 4);
+                const unsigned w0 = f16_rne(lo.x) | (f16_rne(lo.y) << 16), w1 = f16_rne(lo.z) | (f16_rne(lo.w) << 16);
+                const unsigned w2 = f16_rne(hi.x) | (f16_rne(hi.y) << 16), w3 = f16_rne(hi.z) | (f16_rne(hi.w) << 16);
+                const uint4 u = make_uint4(w0, w1, w2, w3);
+                bfrag[st][h] = __builtin_bit_cast(f16x8_t, u);
+            }
         // the wave's tiles of the packed bank ([tile][half][lane] 16 bytes: every load instruction reads 1 KB contiguous), all
         // requested up front
         const int n_tiles = (n_items + 15) >> 4;
-        uint4 a[kMaxTiles][2];
+        float lmax[kSets];
 #pragma unroll
-        for (int i = 0; i < kMaxTiles; ++i) {
-            const int t = wid + i * kWaves;                      // wave-uniform
-            if (t < n_tiles) {
-                a[i][0] = bank_bf[(size_t)t * 128 + lane];
-                a[i][1] = bank_bf[(size_t)t * 128 + 64 + lane];
-            }
-        }
-        float lmax = -INFINITY;
+        for (int st = 0; st < kSets; ++st) lmax[st] = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < kMaxTiles; ++i) {
-            const int t = wid + i * kWaves;
-            acc[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};     // items past n_items never win
-            if (t < n_tiles) {
-                f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[i][0]), bfrag[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[i][1]), bfrag[1], c, 0, 0, 0);
-                // C/D map of 16x16: column (pillar) = lane & 15, row (item) = 4 * (lane >> 4) + reg
-                if (16 * t + 16 > n_items) {
+        for (int i0 = 0; i0 < kMaxTiles; i0 += kMaxTiles) {
+            uint4 a[kMaxTiles][2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * t + 4 * q + r >= n_items) c[r] = -INFINITY;
+            for (int ii = 0; ii < kMaxTiles; ++ii) {
+                const int t = wid + (i0 + ii) * kWaves;                      // wave-uniform
+                if (t < n_tiles) {
+                    a[ii][0] = bank_bf[(size_t)t * 128 + lane];
+                    a[ii][1] = bank_bf[(size_t)t * 128 + 64 + lane];
                 }
-                acc[i] = c;
-                lmax = vmaxr(vmaxr(lmax, vmaxr(c[0], c[1])), vmaxr(c[2], c[3]));
+            }
+#pragma unroll
+            for (int ii = 0; ii < kMaxTiles; ++ii) {
+                const int i = i0 + ii, t = wid + i * kWaves;
+#pragma unroll
+                for (int st = 0; st < kSets; ++st) {
+                    acc[st][i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};     // items past n_items never win
+                    if (t < n_tiles) {
+                        f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[ii][0]), bfrag[st][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a[ii][1]), bfrag[st][1], c, 0, 0, 0);
+                        // C/D map of 16x16: column (pillar) = lane & 15, row (item) = 4 * (lane >> 4) + reg
+                        if (16 * t + 16 > n_items) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (16 * t + 4 * q + r >= n_items) c[r] = -INFINITY;
+                        }
+                        acc[st][i] = c;
+                        lmax[st] = vmaxr(vmaxr(lmax[st], vmaxr(c[0], c[1])), vmaxr(c[2], c[3]));
+                    }
+                }
             }
         }
-        s_pm[l15 * 64 + wid * 4 + q] = lmax;
+#pragma unroll
+        for (int st = 0; st < kSets; ++st) s_pm[(16 * st + l15) * 64 + wid * 4 + q] = lmax[st];
     }
     RO_STAMP(2);
     __syncthreads();
     RO_STAMP(3);
 
-    // ---- step 2: wave w -> threshold of pillar w ----
+    // ---- step 2: wave w -> thresholds of pillars w, w + 16 ----
     const float wm = wmax[lane];
-    float fc = 0.f;
-    bool exact_all = false;     // this wave's pillar is outside the fp16 range: no pre-filter
-    if (wid < np) {
-        fc = s_f[wid * kC + lane];                      // lane = channel
-        const float wsum = hvpr_reduce_sum<64>(wm), wtop = hvpr_reduce<64>(wm, op_maxr());
-        // 2 eps_p: the bound on |A - L| of this pillar, doubled (see the header); infinite outside the fp16 range
-        const float fa = fabsf(fc);
-        float eps2 = 2.f * (hvpr_reduce_sum<64>(fmaf(kRelErr * wm, fa, kAbsErr * fa)) + kAbsErr * wsum + 1e-30f);
-        if (!(hvpr_reduce<64>(fa, op_maxr()) <= kHalfMax) || !(wtop <= kHalfMax)) eps2 = INFINITY;
-        exact_all = !(eps2 < INFINITY);
-        // tau <= k-th largest of the 64 lane maxima (its 16 leading bits): a lower bound of the k-th largest A
-        const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(s_pm[wid * 64 + lane]), k));
-        // tau = -inf or eps2 = inf / NaN let every live item through; the -inf padding past n_items never passes
-        if (lane == 0) s_tau[wid] = fmaxf(tau - eps2, -3.4028235e38f);
+    const float wsum = hvpr_reduce_sum<64>(wm), wtop = hvpr_reduce<64>(wm, op_maxr());
+    unsigned exact_all = 0u;    // bit st: the wave's pillar of set st is outside the fp16 range: no pre-filter
+#pragma unroll
+    for (int st = 0; st < kSets; ++st) {
+        const int p = 16 * st + wid;
+        if (p < np) {
+            const float fa = fabsf(s_f[p * kC + lane]);                      // lane = channel
+            // 2 eps_p: the bound on |A - L| of this pillar, doubled (see the header); infinite outside the fp16 range
+            float eps2 = 2.f * (hvpr_reduce_sum<64>(fmaf(kRelErr * wm, fa, kAbsErr * fa)) + kAbsErr * wsum + 1e-30f);
+            if (!(hvpr_reduce<64>(fa, op_maxr()) <= kHalfMax) || !(wtop <= kHalfMax)) eps2 = INFINITY;
+            if (!(eps2 < INFINITY)) exact_all |= 1u << st;
+            // tau <= k-th largest of the 64 lane maxima (its 16 leading bits): a lower bound of the k-th largest A
+            const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(s_pm[p * 64 + lane]), k));
+            // tau = -inf or eps2 = inf / NaN let every live item through; the -inf padding past n_items never passes
+            if (lane == 0) s_tau[p] = fmaxf(tau - eps2, -3.4028235e38f);
+        }
     }
     RO_STAMP(4);
     __syncthreads();
     RO_STAMP(5);
 
-    // ---- step 3: every wave: which of its 32 values per lane reach the threshold of the lane's pillar ----
-    {
-        const float tl = s_tau[l15];
+    // ---- step 3: every wave: which of its 32 values per lane and set reach the threshold of the lane's pillar ----
+#pragma unroll
+    for (int st = 0; st < kSets; ++st) {
+        const int pl = 16 * st + l15;
+        const float tl = s_tau[pl];
         unsigned below = 0u;    // bit 31 - (4 i + r): A < threshold (the sign of the difference; -inf padding stays below)
 #pragma unroll
         for (int i = 0; i < kMaxTiles; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) below = __builtin_amdgcn_alignbit(below, __float_as_uint(acc[i][r] - tl), 31);
-        unsigned hits = l15 < np ? ~below : 0u;
+            for (int r = 0; r < 4; ++r) below = __builtin_amdgcn_alignbit(below, __float_as_uint(acc[st][i][r] - tl), 31);
+        unsigned hits = pl < np ? ~below : 0u;
         const int mine = __popc(hits);
         // position inside the (pillar, wave) segment: the lanes of the lower quarters first
         const int c1 = __shfl_up(mine, 16, 64), c2 = __shfl_up(mine, 32, 64), c3 = __shfl_up(mine, 48, 64);
         int pos = (q >= 1 ? c1 : 0) + (q >= 2 ? c2 : 0) + (q >= 3 ? c3 : 0);
-        if (q == 3) s_cnt[l15 * kWaves + wid] = pos + mine;
-        int *seg = s_cand + (l15 * kWaves + wid) * kSeg;
+        if (q == 3) s_cnt[pl * kWaves + wid] = pos + mine;
+        int *seg = s_cand + (pl * kWaves + wid) * kSeg;
         while (__ballot(hits != 0u) != 0ull) {
             if (hits != 0u) {
                 const int b = __clz((int)hits);           // 4 i + r, ascending item order
@@ -189,10 +208,11 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
     __syncthreads();
     RO_STAMP(7);
 
-    // ---- step 4: one wave per pillar ----
-    if (wid >= np) return;
-    {
-        const int p = wid;
+    // ---- step 4: one wave per pillar, the wave's pillar of every set in turn ----
+#pragma unroll
+    for (int st = 0; st < kSets; ++st) {      // (unrolled: as a loop the body spills 170 registers)
+        const int p = 16 * st + wid;
+        if (p >= np) break;
         int *list = s_list + wid * 128;
         // candidate list of the pillar: the 16 wave segments back to back
         int cw = lane < kWaves ? s_cnt[p * kWaves + lane] : 0;
@@ -203,7 +223,7 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         pf += __builtin_amdgcn_update_dpp(0, pf, 0x114, 0xf, 0xf, true);
         pf += __builtin_amdgcn_update_dpp(0, pf, 0x118, 0xf, 0xf, true);
         int cnt = __builtin_amdgcn_readlane(pf, 15);
-        if (over || exact_all) cnt = 65;
+        if (over || ((exact_all >> st) & 1u)) cnt = 65;
         if (cnt <= 64) {
             const int w2 = lane >> 2, s2 = lane & 3;      // lane (wave segment, slot)
             const int cw2 = __shfl(cw, w2, 64), base2 = __shfl(pf - cw, w2, 64);

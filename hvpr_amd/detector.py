@@ -345,8 +345,8 @@ class MixAnchor_Memory(_VoxelizingDetector):
     def _can_fuse_encode(self, batch_dict):
         """The fused a1..a4 entry point covers the hvpr.yaml shapes: raw (N,5) points in, PillarVFE_Scale 10->16, 32->64 with the
         5->16->32 scale stream, a 64-wide memory bank, nz == 1, <= 32 points per voxel.  Anything else takes the module
-        chain (three C-ABI calls) — same kernels' arithmetic, same results.  HVPR_ENCODE=modular forces the chain."""
-        if self.training or "voxels" in batch_dict or os.environ.get("HVPR_ENCODE", "fused") != "fused":
+        chain (three C-ABI calls) — same kernels' arithmetic, same results."""
+        if self.training or "voxels" in batch_dict:
             return False
         v, m = getattr(self, "vfe", None), getattr(self, "map_to_bev_module", None)
         if not isinstance(v, vfe.PillarVFE_Scale) or not isinstance(m, map_to_bev.PointPillarScatter_Agg_Memory_1_scale):
@@ -533,7 +533,7 @@ class PipelinedForward:
         assert not model.training and hasattr(model, "stage_encode")
         if depth is None:
             fp32 = getattr(model.backbone_2d, "conv_precision", "fp32") == "fp32" and hasattr(model.backbone_2d, "split_buffers")
-            depth = int(os.environ.get("HVPR_PIPE_DEPTH", "4")) if fp32 else 3
+            depth = 4 if fp32 else 3
         assert depth in (3, 4)
         self.model, self.step, self.depth = model, 0, depth
         self.B = example_batch["batch_size"]

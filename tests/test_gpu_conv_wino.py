@@ -83,11 +83,11 @@ def test_wino_wgrad_matches_float64(N, H, W, cin, cout):
     y = F.conv2d(x.double().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
     (y * dz.double()).sum().backward()
     dw = conv_train.conv_wgrad(x, dz, 9, 1, cout, cin)
-    os.environ["HVPR_TRAIN_WGRAD"] = "direct"
+    os.environ["HVPR_CONV_ALGO"] = "direct"           # the direct weight-gradient kernel on the same tensors
     try:
         dwd = conv_train.conv_wgrad(x, dz, 9, 1, cout, cin)
     finally:
-        del os.environ["HVPR_TRAIN_WGRAD"]
+        del os.environ["HVPR_CONV_ALGO"]
     s = float(w.grad.abs().max())
     ew, ed = float((dw.double() - w.grad).abs().max()) / s, float((dwd.double() - w.grad).abs().max()) / s
     print(f"winograd wgrad {ew:.2e}  direct {ed:.2e}")

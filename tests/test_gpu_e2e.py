@@ -135,8 +135,9 @@ def _snapshot(rec):
 
 @pytest.mark.parametrize("per_batch", [1, 2])
 def test_graph_replay_and_frame_pipeline_equal_the_serial_forward(model_and_params, per_batch):
-    """One hipGraph per frame (GraphedForward) and the three-stage frame pipeline (PipelinedForward: encode of frame k,
-    convolutions of frame k-1, top-k + NMS of frame k-2 in one replay) return exactly what the eager forward returns."""
+    """One hipGraph per frame (GraphedForward) and the frame pipeline (PipelinedForward, four stages by default: encode of
+    frame k | trunk + branches 0, 1 of frame k-1 | last branch + head + decode of frame k-2 | top-k + NMS of frame k-3 in one
+    replay) return exactly what the eager forward returns."""
     cfg, model, params = model_and_params
     frames = [synthetic.hvpr_frame(30 + i) for i in range(5 * per_batch)]
     batches = [_batch(frames[i * per_batch:(i + 1) * per_batch]) for i in range(5)]
