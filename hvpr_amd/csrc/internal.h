@@ -22,6 +22,8 @@ struct VoxWs {
     int4 *arena_rec;   // [N]  fused encode path: {point index, voxel rank or -1 (voxel dropped by the cap), voxel point count, cell}
                        //      per arena position — a pillar wave reads a window of the arena and needs nothing else
     int *arena_total;  // [1]  number of arena positions in use (= in-range points), written by K2
+    float *vfe_aux;    // [64] fused encode path: the pillar VFE's padded-slot column (hvpr_vfe_padded_slot below), computed by an
+                       //      extra workgroup of K3 so that the pillar kernel's prologue does not have to
     int *frame_base;   // [B+1] rank of the first voxel of each frame (uncapped)
     unsigned long long *tile_state;   // [tiles]
     int *ticket;       // [1]
@@ -39,6 +41,7 @@ static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell) 
     w.arena_pt = c.take<float4>(n);
     w.arena_rec = c.take<int4>(n);
     w.arena_total = c.take<int>(1);
+    w.vfe_aux = c.take<float>(64);
     w.frame_base = c.take<int>(batch + 1);
     w.tile_state = c.take<unsigned long long>(hvpr_cdiv(n > 0 ? n : 1, kScanTile));
     w.ticket = c.take<int>(1);
@@ -104,6 +107,26 @@ __device__ __forceinline__ void hvpr_canvas_clear(const ClearJob &c, int blk, in
     }
 }
 
+// The pillar VFE's padded slot (pillar_vfe.py:205-208 masks the INPUT: a padded slot still yields ReLU(folded bias) in layer 0
+// and goes through layer 1): its layer-1 column Z1 = W1a . ReLU(b0), computed ON THE MATRIX CORES with the operand layout of
+// the pillar kernel (vfe.hip), so that it rounds exactly like a real column with zero input.  One wave; z1[64] by channel.
+//   aw[mb][t]  = w1[(32 mb + lane % 32) * 32 + 8 (t / 4) + 4 (lane / 32) + t % 4]      (w1: 64 x 32 row-major, BatchNorm folded)
+//   b0h[t]     = b0[8 (t / 4) + 4 (lane / 32) + t % 4]
+typedef float hvpr_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void hvpr_vfe_padded_slot(const float (&aw)[2][8], const float (&b0h)[8], float *z1) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, slot = lane & 31;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        hvpr_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[mb][t], fmaxf(0.f + b0h[t], 0.f), acc, 0, 0, 0);
+        if (slot == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(float4 *)&z1[32 * mb + 8 * g + 4 * h] = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+    }
+}
+
 struct VoxelizeArgs {
     const float *points;
     int n_points, point_stride, xyz_col, n_feat;
@@ -121,8 +144,9 @@ struct VfeWeights {
 // K1-K3 of the voxelizer (cell keys, rank scan, arena fill) + voxel_offsets.  for_encode: K3 also copies each point (4
 // floats) next to its index in the arena, and does not return the cell_first map to idle — the caller's next kernel reads
 // the occupancy from it and resets it (hvpr_i_vfe_gather does both).
+// vfe_w1 / vfe_b0 (fused path, optional): an extra workgroup of K3 leaves the VFE's padded-slot column in w.vfe_aux.
 HVPR_INTERNAL int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode,
-                                     hipStream_t s);
+                                     hipStream_t s, const float *vfe_w1 = nullptr, const float *vfe_b0 = nullptr);
 // K4 fused into the pillar VFE: selects each voxel's points straight from the arena, writes voxels (optional) / coords /
 // num_points, the pillar and scale features and the pillar + scale cells of the NHWC canvases; extra workgroups of the same
 // launch clear every canvas cell that belongs to no pillar and return cell_first to idle (pair with for_encode above).

@@ -140,10 +140,11 @@ __device__ __forceinline__ int bitonic_asc(int v, int lane, int width) {
 __device__ __forceinline__ f32x16 zero16() { return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
-// Stage the weights through LDS once per workgroup (every wave needs them in a gathered per-lane layout) and compute the padded
-// slot's layer-1 column.  `stage` is the workgroup's scratch (>= 3104 floats, reused by the passes afterwards), `zt` this wave's
-// 160-float table: Z1 by channel, the scale stream's output bias, a row of -inf.  Contains the workgroup barriers.
-__device__ __forceinline__ void load_weights(const VfeParams &v, float *stage, float *zt, Wreg &W) {
+// Stage the weights through LDS once per workgroup (every wave needs them in a gathered per-lane layout) and set up `zt`, this
+// wave's 160-float table: the padded slot's layer-1 column Z1 by channel (taken from z1_pre when the index kernels left it in
+// the workspace, else computed here), the scale stream's output bias, a row of -inf.  `stage`: the workgroup's staging area
+// (3104 floats).  Contains one workgroup barrier.
+__device__ __forceinline__ void load_weights(const VfeParams &v, float *stage, float *zt, Wreg &W, const float *z1_pre) {
     const int lane = threadIdx.x & 63, h = lane >> 5, slot = lane & 31;
     float *s_w1 = stage, *s_ws1 = stage + C1 * 36, *s_w0 = s_ws1 + CS1 * 20;
     for (int i = threadIdx.x; i < C1 * 32 / 4; i += 256) *(float4 *)&s_w1[(i >> 3) * 36 + (i & 7) * 4] = ((const float4 *)v.w1)[i];
@@ -184,18 +185,8 @@ __device__ __forceinline__ void load_weights(const VfeParams &v, float *stage, f
     }
     W.b1c = v.b1[lane];
     W.z0c = fmaxf(0.f + v.b0[lane & 15], 0.f);
-    __syncthreads();   // the staging area is free from here on
-    // the padded slot's layer-1 column, rounded exactly like a real column with zero input
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        f32x16 acc = zero16();
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.aw[mb][t], fmaxf(0.f + W.b0h[t], 0.f), acc, 0, 0, 0);
-        if (slot == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *(float4 *)&zt[32 * mb + 8 * g + 4 * h] = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-        }
-    }
+    if (z1_pre) zt[lane] = z1_pre[lane];
+    else hvpr_vfe_padded_slot(W.aw, W.b0h, zt);
     if (lane < CS1) zt[C1 + lane] = v.bs1[lane];
     zt[96 + lane] = -INFINITY;
 }
@@ -226,6 +217,26 @@ __device__ __forceinline__ float row_carry_and(float x, int mask) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false) & mask);
 }
 __device__ __forceinline__ float fand(float x, int mask) { return __int_as_float(__float_as_int(x) & mask); }
+// the same two moves on a double (both halves), for the pillar sums
+template <int D>
+__device__ __forceinline__ double row_up_and_d(double x, int mask) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x110 + D, 0xf, 0xf, true) & mask;
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x110 + D, 0xf, 0xf, true) & mask;
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double row_carry_and_d(double x, int mask) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x142, 0xa, 0xf, false) & mask;
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x142, 0xa, 0xf, false) & mask;
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// Pillar sums that do not depend on the ORDER of the points (the arena is unordered inside a voxel): every coordinate is taken
+// to a fixed-point grid as an integer-valued double, 2^k units per metre with k from the pillar's own position — all its points
+// lie within the cell, |v| < bound, and 32 * bound * 2^k <= 2^52 — so the (up to 32) terms add EXACTLY in any order; values keep
+// every bit above 2^-k m (k = 41 at 47 m, more near the origin).  k of a bound: bound < 2^e, k = 47 - e.
+__device__ __forceinline__ int sum_scale(float bound) { return 47 - ((int)((__float_as_uint(bound) >> 23) & 0xffu) - 126); }
+__device__ __forceinline__ double to_grid(float v, int k) { return trunc(ldexp((double)v, k)); }
 
 // One pass: 32 point columns (both 32-lane halves hold the same columns, lane = (col, h)) that belong to whole pillars.
 //   pt, live     the column's point; live = it is a real point of a pillar of this pass (others carry zeros)
@@ -245,32 +256,26 @@ __device__ __forceinline__ void vfe_pass(const Wreg &W, WaveLds &L, const float 
     const bool isend = (endmask >> col) & 1u;
     const float ninf = -INFINITY;
     // all ones where column col - d belongs to the same pillar
-    const int g1 = col - 1 >= seg0 ? -1 : 0, g2 = col - 2 >= seg0 ? -1 : 0, g4 = col - 4 >= seg0 ? -1 : 0, g8 = col - 8 >= seg0 ? -1 : 0,
-              g16 = col - 16 >= seg0 ? -1 : 0;
+    const int g1 = col - 1 >= seg0 ? -1 : 0, g2 = col - 2 >= seg0 ? -1 : 0, g4 = col - 4 >= seg0 ? -1 : 0, g8 = col - 8 >= seg0 ? -1 : 0;
 
     // ---- decoration (pillar_vfe.py:187-208) -----------------------------------------------------------------------------
-    // pillar sums by a Kogge-Stone scan that stops at the pillar's first column: the summation tree depends on the point order
-    // inside the pillar only, not on where the pillar sits in the wave
-    float sx = pt.x, sy = pt.y, sz = pt.z;   // columns that are not live carry zeros (padded slots are zero, pillar_vfe.py:187)
-    {
-        float tx, ty, tz;
-        tx = __shfl_up(sx, 1, 32); ty = __shfl_up(sy, 1, 32); tz = __shfl_up(sz, 1, 32);
-        sx += fand(tx, g1); sy += fand(ty, g1); sz += fand(tz, g1);
-        tx = __shfl_up(sx, 2, 32); ty = __shfl_up(sy, 2, 32); tz = __shfl_up(sz, 2, 32);
-        sx += fand(tx, g2); sy += fand(ty, g2); sz += fand(tz, g2);
-        tx = __shfl_up(sx, 4, 32); ty = __shfl_up(sy, 4, 32); tz = __shfl_up(sz, 4, 32);
-        sx += fand(tx, g4); sy += fand(ty, g4); sz += fand(tz, g4);
-        tx = __shfl_up(sx, 8, 32); ty = __shfl_up(sy, 8, 32); tz = __shfl_up(sz, 8, 32);
-        sx += fand(tx, g8); sy += fand(ty, g8); sz += fand(tz, g8);
-        tx = __shfl_up(sx, 16, 32); ty = __shfl_up(sy, 16, 32); tz = __shfl_up(sz, 16, 32);
-        sx += fand(tx, g16); sy += fand(ty, g16); sz += fand(tz, g16);
-    }
-    const int last = seg0 + (n > 0 ? n - 1 : 0);   // the pillar's sum is the scan value at its last live point
+    // pillar sums: exact fixed-point terms (above), segmented inclusive scan along the columns (DPP inside the 16-lane rows + one
+    // carry across the row border); the pillar's LAST column ends up with the sum over the pillar
+    const float cx = (float)cd.w * v.vsx + v.offx, cy = (float)cd.z * v.vsy + v.offy, cz = (float)cd.y * v.vsz + v.offz;   // cell centre
+    const int kx = sum_scale(fabsf(cx) + v.vsx), ky = sum_scale(fabsf(cy) + v.vsy), kz = sum_scale(fabsf(cz) + v.vsz);
+    const int gx = (col >= 16 && seg0 < 16) ? -1 : 0;
+    double sx = to_grid(pt.x, kx), sy = to_grid(pt.y, ky), sz = to_grid(pt.z, kz);   // columns that are not live carry zeros (pillar_vfe.py:187)
+    sx += row_up_and_d<1>(sx, g1); sy += row_up_and_d<1>(sy, g1); sz += row_up_and_d<1>(sz, g1);
+    sx += row_up_and_d<2>(sx, g2); sy += row_up_and_d<2>(sy, g2); sz += row_up_and_d<2>(sz, g2);
+    sx += row_up_and_d<4>(sx, g4); sy += row_up_and_d<4>(sy, g4); sz += row_up_and_d<4>(sz, g4);
+    sx += row_up_and_d<8>(sx, g8); sy += row_up_and_d<8>(sy, g8); sz += row_up_and_d<8>(sz, g8);
+    sx += row_carry_and_d(sx, gx); sy += row_carry_and_d(sy, gx); sz += row_carry_and_d(sz, gx);
+    const int endcol = col + __ffs((int)((endmask >> col) | 0x80000000u)) - 1;     // last column of this column's pillar
     const float fn = (float)n;
-    const float mx = __shfl(sx, last, 32) / fn, my = __shfl(sy, last, 32) / fn, mz = __shfl(sz, last, 32) / fn;
+    const float mx = __shfl((float)ldexp(sx, -kx), endcol, 32) / fn, my = __shfl((float)ldexp(sy, -ky), endcol, 32) / fn,
+                mz = __shfl((float)ldexp(sz, -kz), endcol, 32) / fn;
     // B operand of layer 0: lane (col, h) supplies input 2 t + h to MFMA t.  The mask is applied to the INPUT (:205-208): a
     // padded slot still yields ReLU(folded bias) and takes part in both maxes
-    const float cx = (float)cd.w * v.vsx + v.offx, cy = (float)cd.z * v.vsy + v.offy, cz = (float)cd.y * v.vsz + v.offz;
     float fb0 = h ? pt.y : pt.x, fb1 = h ? pt.w : pt.z, fb2 = h ? pt.y - my : pt.x - mx, fb3 = h ? pt.x - cx : pt.z - mz,
           fb4 = h ? pt.z - cz : pt.y - cy;
     if (!live) { fb0 = 0.f; fb1 = 0.f; fb2 = 0.f; fb3 = 0.f; fb4 = 0.f; }
@@ -306,7 +311,7 @@ __device__ __forceinline__ void vfe_pass(const Wreg &W, WaveLds &L, const float 
     // row border); the pillar's last column ends up with the max over the pillar and leaves it as row q of the pillar table
     {
         // layer-0 outputs are >= 0 (ReLU), so 0 is the neutral element of this scan: a masked-off or missing neighbour reads 0
-        const int gx = (col >= 16 && seg0 < 16) ? -1 : 0, im = inmax ? -1 : 0, hm = hz ? -1 : 0;
+        const int im = inmax ? -1 : 0, hm = hz ? -1 : 0;
         float xr[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -378,11 +383,14 @@ __device__ __forceinline__ void vfe_pass(const Wreg &W, WaveLds &L, const float 
     }
     VFE_STAMP(7);
 
-    // ---- per point: floor by the padded slot's column (at the pillar's first column: the max over the pillar sees it), add
+    // ---- per point: floor by the padded slot's column (at ONE column of the pillar: the max over the pillar sees it), add
     // the pillar's constant; rows back to LDS.  Columns outside the maxes read a row of -inf as their constant
     {
         const float *crow = inmax ? &L.a[q * kPA] : &zt[96];
-        const float *zrow = (hz && proc && col == seg0) ? zt : &zt[96];   // the pillar's first column is always in the maxes
+        // (at the pillar's first column that takes part in the maxes: under the V1 cap a pillar's dropped points sit anywhere)
+        const unsigned inmask = (unsigned)(__ballot(inmax) & 0xffffffffull);
+        const bool floor_here = hz && proc && inmax && ((inmask >> seg0) << seg0 & ((1u << col) - 1u)) == 0u;
+        const float *zrow = floor_here ? zt : &zt[96];
         float4 cv[2][4], zv[2][4];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -443,15 +451,16 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
     const long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     __shared__ __attribute__((aligned(16))) WaveLds s_wave[4];
+    __shared__ __attribute__((aligned(16))) float s_stage[C1 * 36 + CS1 * 20 + C0 * CIN];
     __shared__ __attribute__((aligned(16))) float s_zt[4][160];
     __shared__ int s_sel[4][32];
+    __shared__ __attribute__((aligned(16))) float4 s_selp[4][32];
     __shared__ int s_voff[kMaxB + 1], s_fbase[kMaxB + 1], s_cut[kMaxB];
 #ifdef HVPR_EXP_TIMING
     long long tstamp[10];
     tstamp[0] = __builtin_readcyclecounter();
-    int t_passes = 0;
+    int t_passes = 0, t_sorted = 0;
 #endif
-    static_assert(sizeof(s_wave) >= (C1 * 36 + CS1 * 20 + C0 * CIN) * sizeof(float), "weight staging area");
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31;
     // One frame is a single round of windows with most SIMDs idle, and the launch lasts as long as its slowest wave: a wave
     // whose window needs a second pass (a voxel with more points than slots, a pillar that did not fit) takes twice as long as
@@ -491,7 +500,7 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
         if (rc < g.w.frame_base[1]) cut1 = g.w.vox_rec[rc].w;
     }
     Wreg W;
-    load_weights(v, (float *)s_wave, s_zt[wid], W);   // barriers inside: the frame tables are visible afterwards
+    load_weights(v, s_stage, s_zt[wid], W, g.w.vfe_aux);   // a barrier inside: the frame tables are visible afterwards
     WaveLds &L = s_wave[wid];
     VFE_STAMP(1);
     const int cells_per_frame = g.nx * g.ny;
@@ -545,11 +554,18 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                     }
                 }
                 int vsel = kIdle;
+                float4 psel = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (cnt <= 512) {
-                    // radix select: T = the P-th smallest index (indices are distinct), bit by bit with ballots
+                    // radix select: T = the P-th smallest index (indices are distinct), bit by bit with ballots.  The points come
+                    // along with their records (one round trip); the selected (index, point) pairs are compacted through LDS
                     int vals[8];
+                    float4 pv[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) vals[r] = (r * 64 + lane < cnt) ? g.w.arena_rec[a0 + r * 64 + lane].x : kIdle;
+                    for (int r = 0; r < 8; ++r) {
+                        const bool in = r * 64 + lane < cnt;
+                        vals[r] = in ? g.w.arena_rec[a0 + r * 64 + lane].x : kIdle;
+                        pv[r] = in ? g.w.arena_pt[a0 + r * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                     unsigned T = 0u;
                     for (int bit = g.idx_bits - 1; bit >= 0; --bit) {
                         const unsigned test = T | ((1u << bit) - 1u);
@@ -563,16 +579,30 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                     for (int r = 0; r < 8; ++r) {
                         const bool sel = (unsigned)vals[r] <= T;
                         const unsigned long long m = __ballot(sel);
-                        if (sel) s_sel[wid][fill + __popcll(m & ((1ull << lane) - 1ull))] = vals[r];
+                        if (sel) {
+                            const int at = fill + __popcll(m & ((1ull << lane) - 1ull));
+                            s_sel[wid][at] = vals[r];
+                            s_selp[wid][at] = pv[r];
+                        }
                         fill += __popcll(m);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     vsel = slot < P ? ((volatile int *)s_sel[wid])[slot] : kIdle;
+                    int at = slot;
+                    if (g.voxels_out) {       // the optional `voxels` output lists the points by ascending index
+                        const int key = bitonic_asc(vsel == kIdle ? kIdle : (vsel << 5) | slot, slot, 32);
+                        vsel = key == kIdle ? kIdle : key >> 5;
+                        at = key & 31;
+                    }
+                    if (slot < P) {
+                        const volatile float *pp = (const volatile float *)&s_selp[wid][at];
+                        psel = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                    }
                     __builtin_amdgcn_wave_barrier();
                 } else {
-                    // very dense cell: 64-lane bitonic selection with chunked merging
+                    // very dense cell: 64-lane bitonic selection with chunked merging, then the points from the point array
                     int u = lane < cnt ? g.w.arena_rec[a0 + lane].x : kIdle;
                     u = bitonic_asc(u, lane, 64);
                     const int chunk = 64 - P;
@@ -583,19 +613,19 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                         }
                         u = bitonic_asc(u, lane, 64);
                     }
-                    vsel = __shfl(u, slot, 64);
+                    vsel = __shfl(u, slot, 64);       // ascending
+                    if (slot < P && vsel != kIdle) {
+                        const float *src = g.pts + (size_t)vsel * g.stride + g.xyz_col;
+                        psel = make_float4(src[0], src[1], src[2], src[3]);
+                    }
                 }
-                vsel = bitonic_asc(vsel, slot, 32);
                 live = slot < P && vsel < cutoff;     // vsel == kIdle is never < cutoff
                 n = __popcll(__ballot(live) & 0xffffffffull);
-                if (live) {
-                    const float *src = g.pts + (size_t)vsel * g.stride + g.xyz_col;
-                    pt = make_float4(src[0], src[1], src[2], src[3]);
-                }
+                if (live) pt = psel;
                 proc = true;
                 seg0 = 0;
                 startsproc = 1u;
-                endmask = 1u << (n > 0 ? n - 1 : 0);
+                endmask = 1u << (P - 1);              // all P columns are the pillar's; the ones past the cap's cutoff stay out of the maxes
             } else {
                 // ---- packed pass: columns = arena positions base + s .. base + s + 31, whole pillars only ----------------------
                 const int src = s + col;
@@ -620,18 +650,21 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                     todo &= ~((__ballot(proc && col == seg0) & 0xffffffffull) << s);
                     continue;
                 }
-                // The points of a pillar go by ascending index.  K3 hands out a voxel's arena slots from the top, so when the
-                // points arrived in index order — the usual case, workgroups are dispatched in order — every segment is already
-                // DESCENDING and reading it backwards is all it takes; otherwise a sorting network on (segment, index, source
-                // column) keys orders all segments at once (segments keep their columns)
+                // Inside a pillar the arena holds the points in arrival order.  Nothing of the VFE depends on it (the sums above
+                // are exact, the maxes commute); only the optional `voxels` output lists a pillar's points by ascending index.
+                // K3 hands out a voxel's slots from the top, so a segment that arrived in index order is DESCENDING and only has
+                // to be read backwards; otherwise a sorting network on (segment, index, source column) keys orders all segments
+                // at once (segments keep their columns)
                 int from = col;
-                const int before = __shfl_up(idx0, 1, 32);
-                if (__ballot(proc && col > seg0 && before <= idx0) == 0ull) {
-                    if (proc) from = 2 * seg0 + cn - 1 - col;
-                } else {
-                    unsigned key = ((unsigned)seg0 << (g.idx_bits + 5)) | (((unsigned)idx0 & idxmask) << 5) | (unsigned)col;
-                    key = bitonic32_asc(key, col);
-                    from = (int)(key & 31u);
+                if (g.voxels_out) {
+                    const int before = __shfl_up(idx0, 1, 32);
+                    if (__ballot(proc && col > seg0 && before <= idx0) == 0ull) {
+                        if (proc) from = 2 * seg0 + cn - 1 - col;
+                    } else {
+                        unsigned key = ((unsigned)seg0 << (g.idx_bits + 5)) | (((unsigned)idx0 & idxmask) << 5) | (unsigned)col;
+                        key = bitonic32_asc(key, col);
+                        from = (int)(key & 31u);
+                    }
                 }
                 const int idx = __shfl(idx0, from, 32);
                 from += s;
@@ -686,8 +719,8 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
 #ifdef HVPR_EXP_TIMING
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if ((wblk % 37) == 0 && threadIdx.x == 0)
-        printf("vfe-abs work blk %d role %d passes %d: %lld .. %lld (x10 ns), prologue %lld cycles\n", wblk, role, t_passes, rt0,
-               (long long)__builtin_amdgcn_s_memrealtime(), tstamp[1] - tstamp[0]);
+        printf("vfe-abs work blk %d role %d passes %d (sorted %d): %lld .. %lld (x10 ns), prologue %lld | to first pass %lld | front %lld decor %lld l0 %lld xmax %lld pillar %lld combine %lld final %lld cycles\n", wblk, role, t_passes, t_sorted, rt0,
+               (long long)__builtin_amdgcn_s_memrealtime(), tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4], tstamp[6] - tstamp[5], tstamp[7] - tstamp[6], tstamp[8] - tstamp[7], tstamp[9] - tstamp[8]);
 #endif
 }
 
@@ -696,13 +729,14 @@ __global__ void __launch_bounds__(256, 2) k_vfe_rows(const float4 *__restrict__ 
                                                      const int4 *__restrict__ coords, int M, int P, const int *__restrict__ m_device,
                                                      VfeParams v) {
     __shared__ __attribute__((aligned(16))) WaveLds s_wave[4];
+    __shared__ __attribute__((aligned(16))) float s_stage[C1 * 36 + CS1 * 20 + C0 * CIN];
     __shared__ __attribute__((aligned(16))) float s_zt[4][160];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int n_waves = (gridDim.x * blockDim.x) >> 6;
     if (m_device) M = min(M, *m_device);
     Wreg W;
-    load_weights(v, (float *)s_wave, s_zt[wid], W);
+    load_weights(v, s_stage, s_zt[wid], W, nullptr);
     WaveLds &L = s_wave[wid];
     for (int p = wave; p < M; p += n_waves) {
         int n = num_points[p];

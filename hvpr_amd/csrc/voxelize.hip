@@ -161,7 +161,22 @@ __global__ void __launch_bounds__(kScanThreads) k2_scan(int n, const int *__rest
 
 __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ foff, int batch, int max_voxels, VoxWs w,
                                                int *__restrict__ voxel_offsets, int for_encode,
-                                               const float *__restrict__ pts, int stride, int xyz_col) {
+                                               const float *__restrict__ pts, int stride, int xyz_col,
+                                               const float *__restrict__ vfe_w1, const float *__restrict__ vfe_b0) {
+    if (vfe_w1 && blockIdx.x == gridDim.x - 1) {   // the extra workgroup: the pillar VFE's padded-slot column (internal.h)
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x, h = lane >> 5, slot = lane & 31;
+            float aw[2][8], b0h[8];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) aw[mb][t] = vfe_w1[(32 * mb + slot) * 32 + 8 * (t >> 2) + 4 * h + (t & 3)];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) b0h[t] = vfe_b0[8 * (t >> 2) + 4 * h + (t & 3)];
+            hvpr_vfe_padded_slot(aw, b0h, w.vfe_aux);
+        }
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         int acc = 0;
@@ -269,15 +284,17 @@ __global__ void __launch_bounds__(256) k4_gather(const float *__restrict__ pts, 
 
 }  // namespace
 
-int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode, hipStream_t s) {
+int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode, hipStream_t s,
+                       const float *vfe_w1, const float *vfe_b0) {
     if (for_encode && a.n_feat != 4) return HVPR_ERR_UNSUPPORTED;
     const int tiles = hvpr_cdiv(a.n_points, kScanTile);
     const int pblocks = hvpr_cdiv(a.n_points, 256);
     hipLaunchKernelGGL(k1_keys, dim3(pblocks), dim3(256), 0, s, a.points, a.n_points, a.point_stride, a.xyz_col, a.frame_offsets,
                        a.batch, a.lo_x, a.lo_y, a.lo_z, a.vs_x, a.vs_y, a.vs_z, a.nx, a.ny, a.nz, w, tiles);
     hipLaunchKernelGGL(k2_scan, dim3(tiles), dim3(kScanThreads), 0, s, a.n_points, a.frame_offsets, a.batch, w);
-    hipLaunchKernelGGL(k3_fill, dim3(pblocks), dim3(256), 0, s, a.n_points, a.frame_offsets, a.batch, a.max_voxels, w,
-                       voxel_offsets, for_encode ? 1 : 0, a.points, a.point_stride, a.xyz_col);
+    if (!for_encode) vfe_w1 = nullptr;
+    hipLaunchKernelGGL(k3_fill, dim3(pblocks + (vfe_w1 ? 1 : 0)), dim3(256), 0, s, a.n_points, a.frame_offsets, a.batch, a.max_voxels, w,
+                       voxel_offsets, for_encode ? 1 : 0, a.points, a.point_stride, a.xyz_col, vfe_w1, vfe_b0);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }

@@ -334,6 +334,10 @@ class MixAnchor_Memory(_VoxelizingDetector):
     def __init__(self, model_cfg, num_class, dataset):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
         self.module_list = self.build_networks()
+        # The fused eval forward does not need the padded `voxels` (ΣM, 32, 4) tensor and `pillar_mask` the reference's data
+        # loader / VFE leave in batch_dict (nothing downstream reads them: data_processor.py:43-75 -> pillar_vfe.py:184-221 are
+        # one entry point here).  Set to True to have hvpr_encode_fwd_f32 materialise them as well (tests do).
+        self.export_voxels = bool(model_cfg.get("EXPORT_VOXELS", False))
 
     def get_training_loss(self):
         """detectors/pointpillar.py:59-68 with the arity decision of SURVEY.md T2: loss = rpn + rpn_point + mem."""
@@ -365,8 +369,8 @@ class MixAnchor_Memory(_VoxelizingDetector):
         r = kernels.encode_fwd(pts, self._frame_offsets(batch_dict), B, vg.point_cloud_range, vg.voxel_size, vg.grid_size,
                                vg.max_num_points, vg.max_voxels, vg._workspace(B, pts.shape[0]),
                                self.vfe._fold.get(pts.device, self.vfe._build_folded), self.vfe.offsets,
-                               m.memory.packed_bank(), m.k, xyz_col=1, cap_mode=vg.cap_mode,
-                               out=batch_dict.get("_out_spatial"), state=batch_dict.get("_canvas_state"))
+                               m.memory.packed_bank(), m.k, xyz_col=1, cap_mode=vg.cap_mode, want_voxels=self.export_voxels,
+                               want_mask=self.export_voxels, out=batch_dict.get("_out_spatial"), state=batch_dict.get("_canvas_state"))
         vo = r["voxel_offsets"]
         batch_dict.update(voxels=r["voxels"], voxel_coords=r["coords"], voxel_num_points=r["num_points"], voxel_offsets=vo,
                           voxel_count_device=vo[B:B + 1], pillar_features=r["pillar_features"],

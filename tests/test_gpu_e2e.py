@@ -29,6 +29,7 @@ def model_and_params():
     ds = detector.SyntheticDataset(cfg)
     model = detector.build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
     params = synthetic_weights.load_synthetic(model, seed=0, cls_bias=-2.0)
+    model.export_voxels = True          # the padded voxels / pillar_mask are optional outputs of the fused encode; checked below
     return cfg, model.to(DEV).eval(), params
 
 
@@ -213,6 +214,7 @@ def test_config5_dense_scene_encode_group_batch4():
         if p.NAME == "transform_points_to_voxels":
             p.VOXEL_SIZE, p.MAX_POINTS_PER_VOXEL, p.MAX_NUMBER_OF_VOXELS = [0.2, 0.2, 8.0], 20, {"train": 60000, "test": 60000}
     model = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg))
+    model.export_voxels = True
     params = synthetic_weights.load_synthetic(model, seed=9, cls_bias=-2.0)
     model = model.to(DEV).eval()
     B = 4

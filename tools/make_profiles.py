@@ -5,6 +5,7 @@ summaries under profiles/.   usage: python tools/make_profiles.py <run dir under
   profiles/<r>_kernel_stats_serial.csv         the same with HVPR_BEV_STREAMS=1: every kernel on one stream, durations do not overlap
   profiles/<r>_kernel_stats_pipeline.csv       same of the default `bench.py` (frame pipeline; also holds the latency-mode and probe replays)
   profiles/<r>_kernel_stats_group_b16.csv      the VFE+scatter group alone at hvpr_car batch 16 (tools/bench_group.py --only16)
+  profiles/<r>_kernel_stats_group_dense.csv    ... on the dense scene, BASELINE.json configs[4] (--only-dense);  ..._group_b1.csv: hvpr_car batch 1 (--car1)
   profiles/<r>_pmc_sq_group_b16.csv            SQ counters per kernel of that run (two --pmc passes), averaged per dispatch
   profiles/<r>_pmc_hbm_traffic.csv             per-kernel FETCH_SIZE / WRITE_SIZE (two separate --pmc passes), per frame, serial graph
   profiles/<r>_train_step_kernels.txt          one steady-state training step, kernels by total time
@@ -19,8 +20,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RAW = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r03a")
-R = sys.argv[2] if len(sys.argv) > 2 else "r03"
+RAW = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r04a")
+R = sys.argv[2] if len(sys.argv) > 2 else "r04"
 OUT = os.path.join(ROOT, "profiles")
 
 
@@ -37,6 +38,8 @@ cp("stats_single/bench_kernel_stats.csv", f"{R}_kernel_stats_single_graph.csv")
 cp("stats_serial/bench_kernel_stats.csv", f"{R}_kernel_stats_serial.csv")
 cp("stats/bench_kernel_stats.csv", f"{R}_kernel_stats_pipeline.csv")
 cp("stats_group16/g_kernel_stats.csv", f"{R}_kernel_stats_group_b16.csv")
+cp("stats_group_dense/g_kernel_stats.csv", f"{R}_kernel_stats_group_dense.csv")
+cp("stats_group1/g_kernel_stats.csv", f"{R}_kernel_stats_group_b1.csv")
 cp("train_step_kernels.txt", f"{R}_train_step_kernels.txt")
 
 

@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 runs behind profiles/ (run on the GPU box from the repo root: `gpurun -- bash tools/run_profiles.sh r03a`, then
-# `python tools/make_profiles.py r03a r03` here).  Kernel statistics and the PMC passes are separate runs (a --pmc run carries no
+# rocprofv3 runs behind profiles/ (run on the GPU box from the repo root: `gpurun -- bash tools/run_profiles.sh r04a`, then
+# `python tools/make_profiles.py r04a r04` here).  Kernel statistics and the PMC passes are separate runs (a --pmc run carries no
 # other trace domain).  Only the summaries leave the box: per-dispatch traces are deleted.
 set -u
-O=gpurun_out/${1:-r03a}
+O=gpurun_out/${1:-r04a}
 export TMPDIR=/tmp
 mkdir -p $O
 T="timeout 280"
@@ -21,6 +21,8 @@ unset HVPR_BEV_STREAMS
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py $B --steps 50 --warmup 5 > $O/stats.log 2>&1
 # the VFE+scatter group at batch 16: what bounds k_vfe and k_memory_readout (SQ counters, two passes of <= 8 SQ slots)
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_group16 -o g -- python3 tools/bench_group.py --only16 > $O/stats_group16.log 2>&1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_group_dense -o g -- python3 tools/bench_group.py --only-dense > $O/stats_group_dense.log 2>&1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_group1 -o g -- python3 tools/bench_group.py --car1 > $O/stats_group1.log 2>&1
 $T rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_sq1 -o s -- python3 tools/bench_group.py --only16 > $O/pmc_sq1.log 2>&1
 $T rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2 -o s -- python3 tools/bench_group.py --only16 > $O/pmc_sq2.log 2>&1
 # the training step (BASELINE.json configs[2]): one steady-state step = the kernels between the last two optimiser launches
