@@ -41,7 +41,7 @@ static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell) 
     w.arena_pt = c.take<float4>(n);
     w.arena_rec = c.take<int4>(n);
     w.arena_total = c.take<int>(1);
-    w.vfe_aux = c.take<float>(64);
+    w.vfe_aux = c.take<float>(128);   // [64 .. 127]: scratch word of the L2 warmers
     w.frame_base = c.take<int>(batch + 1);
     w.tile_state = c.take<unsigned long long>(hvpr_cdiv(n > 0 ? n : 1, kScanTile));
     w.ticket = c.take<int>(1);
@@ -145,8 +145,12 @@ struct VfeWeights {
 // floats) next to its index in the arena, and does not return the cell_first map to idle — the caller's next kernel reads
 // the occupancy from it and resets it (hvpr_i_vfe_gather does both).
 // vfe_w1 / vfe_b0 (fused path, optional): an extra workgroup of K3 leaves the VFE's padded-slot column in w.vfe_aux.
+// warm / warm_bytes (fused path, optional): 256 more workgroups of K3 — 32 per XCD, a 32nd of the arrays each — read them once, so that the memory
+// bank (768 KB with its packed copy) sits in every XCD's L2 when the read-out two launches later asks for it; inside a frame the
+// convolution stage (3.9 GB through the L2s) has evicted it since the previous frame (read-out 14.6 us in the frame, 12.5 us warm).
 HVPR_INTERNAL int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode,
-                                     hipStream_t s, const float *vfe_w1 = nullptr, const float *vfe_b0 = nullptr);
+                                     hipStream_t s, const float *vfe_w1 = nullptr, const float *vfe_b0 = nullptr,
+                                     const void *warm0 = nullptr, size_t warm0_bytes = 0, const void *warm1 = nullptr, size_t warm1_bytes = 0);
 // K4 fused into the pillar VFE: selects each voxel's points straight from the arena, writes voxels (optional) / coords /
 // num_points, the pillar and scale features and the pillar + scale cells of the NHWC canvases; extra workgroups of the same
 // launch clear every canvas cell that belongs to no pillar and return cell_first to idle (pair with for_encode above).
