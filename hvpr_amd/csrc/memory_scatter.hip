@@ -214,6 +214,9 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         const int p = 16 * st + wid;
         if (p >= np) break;
         int *list = s_list + wid * 128;
+        // (requested here, needed at the very end: off the chain)
+        int4 cpos = make_int4(-1, 0, -1, -1);
+        if (cell_map || canvas) cpos = coords[p0 + p];
         // candidate list of the pillar: the 16 wave segments back to back
         int cw = lane < kWaves ? s_cnt[p * kWaves + lane] : 0;
         const bool over = __ballot(cw > kSeg) != 0ull;
@@ -348,7 +351,7 @@ __global__ void __launch_bounds__(kThreads) k_memory_readout(const float *__rest
         if (topk_idx && sel) topk_idx[(size_t)(p0 + p) * k + rank] = my_idx;
         long long cell = -1;           // fused a3+a4: this pillar's BEV cell (pointpillar_scatter.py:192, nz == 1)
         if (cell_map || canvas) {
-            const int4 c = coords[p0 + p];
+            const int4 c = cpos;
             if ((unsigned)c.x < (unsigned)batch && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx)
                 cell = ((long long)c.x * ny + c.z) * nx + c.w;
             if (cell_map && lane == 0 && cell >= 0) cell_map[cell] = p0 + p;   // gather-form scatter: k_cell_map's job
