@@ -68,6 +68,7 @@ SIGNATURES = {
     "hvpr_memory_train_bwd_f32": (_I, [_P, _P, _c.c_longlong, _P, _I, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "hvpr_point_pillar_topk_f32": (_I, [_P, _I, _P, _P, _I, _I, _P, _P]),
     "hvpr_scatter_add_rows_f32": (_I, [_P, _P, _c.c_longlong, _I, _I, _P, _P]),
+    "hvpr_segment_sum_rows_f32": (_I, [_P, _c.c_longlong, _I, _I, _P, _P, _P, _c.c_longlong, _P, _c.c_longlong, _P]),
     "hvpr_fused_adam_truewd_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _F, _F, _F, _F, _F, _I, _P, _P]),
     "hvpr_split_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),
     "hvpr_unsplit_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),

@@ -189,6 +189,48 @@ extern "C" int hvpr_three_interpolate_grad_f32(const float *grad_out, const int3
     return HVPR_OK;
 }
 
+// dst[d][c] = sum over the edges of destination d, in the ORDER they are listed, of w[e] * src[row[e]][off + c]: the atomic-free,
+// run-to-run reproducible form of the scattering gradients (one sequential fp32 accumulation per output element)
+__global__ void __launch_bounds__(256) k_segment_sum_rows(const float *__restrict__ src, long long src_stride, int src_off, int C,
+                                                          const int *__restrict__ edge_row, const float *__restrict__ edge_w,
+                                                          const int *__restrict__ rowptr, long long n_dst, float *__restrict__ dst,
+                                                          long long dst_stride) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_dst * C) return;
+    const long long d = t / C;
+    const int c = (int)(t - d * C);
+    const int e0 = rowptr[d], e1 = rowptr[d + 1];
+    float acc = 0.f;
+    int e = e0;
+    for (; e + 8 <= e1; e += 8) {      // eight loads in flight, added in edge order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float x = src[(size_t)(edge_row ? edge_row[e + u] : e + u) * src_stride + src_off + c];
+            v[u] = edge_w ? x * edge_w[e + u] : x;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; e < e1; ++e) {
+        const float x = src[(size_t)(edge_row ? edge_row[e] : e) * src_stride + src_off + c];
+        acc += edge_w ? x * edge_w[e] : x;
+    }
+    dst[(size_t)d * dst_stride + c] = acc;
+}
+
+extern "C" int hvpr_segment_sum_rows_f32(const float *src, long long src_stride, int src_off, int C, const int32_t *edge_row,
+                                         const float *edge_w, const int32_t *rowptr, long long n_dst, float *dst, long long dst_stride,
+                                         hvpr_stream_t stream) {
+    if (C < 1 || src_off < 0 || src_stride < src_off + C || dst_stride < C || n_dst < 0) return HVPR_ERR_INVALID_ARG;
+    if (n_dst == 0) return HVPR_OK;
+    if (!src || !rowptr || !dst) return HVPR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_segment_sum_rows, dim3(hvpr_cdiv(n_dst * C, 256)), dim3(256), 0, (hipStream_t)stream, src, src_stride, src_off, C,
+                       edge_row, edge_w, rowptr, n_dst, dst, dst_stride);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
 extern "C" int hvpr_scatter_add_rows_f32(const float *src, const int32_t *idx, long long m, int row_floats, int n_dst, float *dst,
                                          hvpr_stream_t stream) {
     if (m < 0 || row_floats < 1 || n_dst < 0) return HVPR_ERR_INVALID_ARG;

@@ -133,6 +133,56 @@ def memory_readout_fwd(f, bank, k, m_device=None, want_idx=False):
     return (out, idx) if want_idx else out
 
 
+_SEG_CHUNK = 32      # edges per first-level sum of segment_sum_rows
+
+
+def edges_by_destination(dst, n_dst):
+    """The edges e -> dst[e] of a scatter, grouped by destination for hvpr_segment_sum_rows_f32.  Returns (order, chunk_ptr, dest_ptr):
+    order i32 lists the edge ids destination by destination, inside a destination by ascending edge id (a STABLE sort: the summation
+    order is a fixed function of the index tensor, so the scattering gradients are reproducible bit for bit, which float atomics are
+    not).  A destination's run of edges is cut into chunks of _SEG_CHUNK: chunk_ptr i32 [n_chunks_max + 1] are the chunk boundaries
+    inside `order`, dest_ptr i32 [n_dst + 1] the chunks of each destination — a point picked by 2000 pillars becomes 63 short sums on
+    63 waves and one sum of 63 partials instead of one 2000-term loop on one wave.  Everything stays on the device: the chunk count
+    is bounded by E / _SEG_CHUNK + min(n_dst, E), the unused tail of chunk_ptr is empty chunks.  Destinations outside [0, n_dst)
+    are dropped (they sort to the two ends)."""
+    dst = dst.reshape(-1).to(torch.int64)
+    dev = dst.device
+    E = dst.numel()
+    n_max = E // _SEG_CHUNK + min(n_dst, E) + 1
+    if E == 0:
+        z = torch.zeros(1, dtype=torch.int32, device=dev)
+        return torch.zeros(0, dtype=torch.int32, device=dev), z.expand(n_max + 1).contiguous(), z.expand(n_dst + 1).contiguous()
+    order = torch.argsort(dst, stable=True)
+    sdst = dst[order].contiguous()
+    rowptr = torch.searchsorted(sdst, torch.arange(n_dst + 1, dtype=torch.int64, device=dev))   # edges of d: rowptr[d] .. rowptr[d+1]
+    end_live = rowptr[n_dst:]                                                   # (1,)
+    pos = torch.arange(E, dtype=torch.int64, device=dev)
+    live = (sdst >= 0) & (sdst < n_dst)
+    first = rowptr[sdst.clamp(0, n_dst - 1)]                                    # first edge of this edge's destination
+    head = live & (((pos - first) % _SEG_CHUNK) == 0)                           # this edge opens a chunk
+    csum = torch.cumsum(head.to(torch.int64), 0)
+    cid, total = csum - 1, csum[-1:]                                            # chunk of every live edge; number of chunks
+    chunk_ptr = end_live.expand(n_max + 1).clone()                              # chunks past the last one: empty, at the end
+    chunk_ptr.scatter_(0, torch.where(head, cid, torch.full_like(cid, n_max)), torch.where(head, pos, end_live.expand(E)))
+    # chunks of destination d: from the chunk its first edge opens (for an empty d: the next destination's) to the next one's
+    dest_ptr = torch.where(rowptr < end_live, cid[rowptr.clamp(max=E - 1)], total.expand(n_dst + 1))
+    return order.to(torch.int32), chunk_ptr.to(torch.int32), dest_ptr.to(torch.int32)
+
+
+def segment_sum_rows(src, src_off, C, edge_row, edge_w, chunk_ptr, dest_ptr, n_dst):
+    """dst (n_dst, C): dst[d] = sum over d's edges, in the order given, of edge_w[e] * src[edge_row[e], off : off + C] — two passes of
+    hvpr_segment_sum_rows_f32: per chunk of <= _SEG_CHUNK edges, then per destination over its chunks (fixed order: reproducible)."""
+    n_chunks = chunk_ptr.numel() - 1
+    part = torch.empty((n_chunks, C), dtype=torch.float32, device=src.device)
+    check(lib().hvpr_segment_sum_rows_f32(_ptr(src, torch.float32, "src"), src.shape[-1], int(src_off), int(C), _ptr(edge_row, torch.int32, "edge_row"),
+                                          _ptr(edge_w, torch.float32, "edge_w"), _ptr(chunk_ptr, torch.int32, "chunk_ptr"), int(n_chunks),
+                                          part.data_ptr(), int(C), _stream()), "hvpr_segment_sum_rows_f32")
+    dst = torch.empty((n_dst, C), dtype=torch.float32, device=src.device)
+    check(lib().hvpr_segment_sum_rows_f32(part.data_ptr(), int(C), 0, int(C), None, None, _ptr(dest_ptr, torch.int32, "dest_ptr"), int(n_dst),
+                                          dst.data_ptr(), int(C), _stream()), "hvpr_segment_sum_rows_f32")
+    return dst
+
+
 def scatter_workspace(batch, nx, ny, device):
     """Idle cell map (-1 everywhere); every call returns it to idle."""
     n = lib().hvpr_scatter_workspace_bytes(batch, nx, ny) // 4

@@ -101,8 +101,9 @@ class _MemoryTrain(torch.autograd.Function):
 
 class _GatherRows(torch.autograd.Function):
     """rows[idx] for a (N, C) feature matrix and an integer index tensor of any shape — `points[idx]` of get_score
-    (pointpillar_scatter.py:76): hvpr_gather_rows_f32 forward, hvpr_scatter_add_rows_f32 backward (torch's index backward sorts
-    the 1.2 M indices of a batch first: 26 ms of a training step)."""
+    (pointpillar_scatter.py:76): hvpr_gather_rows_f32 forward; backward = hvpr_segment_sum_rows_f32 over the picks sorted by point
+    (one stable argsort of the frame's picks; torch's own index backward took 26 ms of a training step, and float atomics,
+    hvpr_scatter_add_rows_f32, are not reproducible run to run)."""
 
     @staticmethod
     def forward(ctx, rows, idx):
@@ -120,9 +121,9 @@ class _GatherRows(torch.autograd.Function):
         (flat,) = ctx.saved_tensors
         grad = grad.contiguous()
         c = grad.shape[-1]
-        g = torch.empty((ctx.n, c), dtype=torch.float32, device=grad.device)
-        kernels.check(kernels.lib().hvpr_scatter_add_rows_f32(kernels._ptr(grad, torch.float32, "grad"), flat.data_ptr(), flat.numel(), c, ctx.n,
-                                                              g.data_ptr(), kernels._stream()), "hvpr_scatter_add_rows_f32")
+        # a point may be picked by many pillars: its gradient is summed pick by pick in ascending order (no float atomics)
+        order, chunk_ptr, dest_ptr = kernels.edges_by_destination(flat.to(torch.int64), ctx.n)
+        g = kernels.segment_sum_rows(grad.reshape(-1, c), 0, c, order, None, chunk_ptr, dest_ptr, ctx.n)
         return g, None
 
 

@@ -128,14 +128,25 @@ def _cpad(c):
     return (c + 7) // 8 * 8
 
 
+@torch.no_grad()
+def group_edges(idx, n_per_batch):
+    """(order, chunk_ptr, dest_ptr) of kernels.edges_by_destination for an index tensor idx (B, ...) into n_per_batch rows per sample: the
+    edges of the backward of a gather, grouped by the row they scatter to.  Depends on idx only, so the index plan of a batch
+    (PointNet2MSG.index_plan, computed ahead on a side stream) carries it and the backward does not have to sort."""
+    B = idx.shape[0]
+    dst = idx.reshape(B, -1).to(torch.int64) + torch.arange(B, device=idx.device, dtype=torch.int64).view(B, 1) * n_per_batch
+    return kernels.edges_by_destination(dst, B * n_per_batch)
+
+
 class _GroupRows(torch.autograd.Function):
     """QueryAndGroup (use_xyz) in ROW layout: xyz (B,N,3), features (B,N,C) or None, new_xyz (B,np,3), idx (B,np,ns) i32 ->
     (B*np*ns, cpad) rows [xyz[idx] - new_xyz | features[idx] | 0]; backward scatter-adds the feature columns (hvpr_group_rows_*)."""
 
     @staticmethod
-    def forward(ctx, xyz, features, new_xyz, idx, cpad):
+    def forward(ctx, xyz, features, new_xyz, idx, cpad, csr=None):
         B, N, _ = xyz.shape
         _, np_, ns = idx.shape
+        ctx.csr = csr
         C = 0 if features is None else features.shape[-1]
         xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
         features = None if features is None else features.contiguous()
@@ -152,12 +163,13 @@ class _GroupRows(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, C, np_, ns, cpad = ctx.dims
         if C == 0 or not ctx.needs_input_grad[1]:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         grad = grad.contiguous()
-        gf = torch.empty((B, N, C), dtype=torch.float32, device=grad.device)
-        check(lib().hvpr_group_rows_grad_f32(kernels._ptr(grad, torch.float32, "grad_out"), idx.data_ptr(), B, N, C, np_, ns, cpad, gf.data_ptr(),
-                                             kernels._stream()), "hvpr_group_rows_grad_f32")
-        return None, gf, None, None, None
+        # a point belongs to many groups: its gradient is the sum over the (group, sample) rows that picked it, taken row by row in
+        # ascending row order (kernels.edges_by_destination): no float atomics, the same bits every run
+        order, chunk_ptr, dest_ptr = ctx.csr if ctx.csr is not None else group_edges(idx, N)
+        gf = kernels.segment_sum_rows(grad, 3, C, order, None, chunk_ptr, dest_ptr, B * N).view(B, N, C)
+        return None, gf, None, None, None, None
 
 
 class _MaxSamples(torch.autograd.Function):
@@ -193,7 +205,8 @@ class _FpRows(torch.autograd.Function):
     [three_interpolate(known) | skip | 0]  (hvpr_fp_rows_*; the weights carry no gradient, as in the reference's op)."""
 
     @staticmethod
-    def forward(ctx, known, idx, weight, skip, cpad):
+    def forward(ctx, known, idx, weight, skip, cpad, csr=None):
+        ctx.csr = csr
         known, weight = known.contiguous(), weight.contiguous()
         skip = None if skip is None else skip.contiguous()
         B, m, C1 = known.shape
@@ -212,11 +225,14 @@ class _FpRows(torch.autograd.Function):
         idx, weight = ctx.saved_tensors
         B, m, n, C1, C2, cpad = ctx.dims
         grad = grad.contiguous()
-        gk = torch.empty((B, m, C1), dtype=torch.float32, device=grad.device)
-        gs = torch.empty((B, n, C2), dtype=torch.float32, device=grad.device) if (C2 > 0 and ctx.needs_input_grad[3]) else None
-        check(lib().hvpr_fp_rows_grad_f32(kernels._ptr(grad, torch.float32, "grad_out"), idx.data_ptr(), weight.data_ptr(), B, m, n, C1, C2, cpad,
-                                          gk.data_ptr(), kernels._ptr(gs), kernels._stream()), "hvpr_fp_rows_grad_f32")
-        return gk, None, None, gs, None
+        # a known point feeds many unknown ones: edge (row, k) carries weight[row, k] times the row's gradient to known point idx[row, k];
+        # summed per known point in ascending edge order (no float atomics)
+        order, chunk_ptr, dest_ptr = ctx.csr if ctx.csr is not None else group_edges(idx, m)
+        edge_row = torch.div(order, 3, rounding_mode="floor").to(torch.int32)
+        edge_w = weight.reshape(-1)[order.long()].contiguous()
+        gk = kernels.segment_sum_rows(grad, 0, C1, edge_row, edge_w, chunk_ptr, dest_ptr, B * m).view(B, m, C1)
+        gs = grad[:, C1:C1 + C2].reshape(B, n, C2).contiguous() if (C2 > 0 and ctx.needs_input_grad[3]) else None
+        return gk, None, None, gs, None, None
 
 
 def _rows_image(x):
@@ -292,19 +308,21 @@ class PointnetSAModuleMSG(nn.Module):
             self.mlps.append(_shared_mlp(spec))
 
     def indices(self, xyz):
-        """The index half of forward — it depends on the coordinates only: (FPS idx, new_xyz, [ball-query idx per scale])."""
+        """The index half of forward — it depends on the coordinates only: (FPS idx, new_xyz, [ball-query idx per scale], [the
+        edges of each scale's backward grouped by point, group_edges])."""
         idx = furthest_point_sample(xyz, self.npoint)
         new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
-        return idx, new_xyz, [ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+        balls = [ball_query(g.radius, g.nsample, xyz, new_xyz) for g in self.groupers]
+        return idx, new_xyz, balls, [group_edges(b, xyz.shape[1]) for b in balls]
 
     def forward_rows(self, xyz, features=None, pre=None):
         """xyz (B,N,3), features (B,N,C) rows or None -> new_xyz (B,npoint,3), features (B,npoint,C') rows."""
-        idx, new_xyz, balls = pre if pre is not None else self.indices(xyz)
+        idx, new_xyz, balls, csrs = pre if pre is not None else self.indices(xyz)
         B = xyz.shape[0]
         C = 0 if features is None else features.shape[-1]
         outs = []
-        for grouper, mlp, bidx in zip(self.groupers, self.mlps, balls):
-            x = _GroupRows.apply(xyz, features, new_xyz, bidx, _cpad(3 + C))          # (B*npoint*nsample, cpad)
+        for grouper, mlp, bidx, csr in zip(self.groupers, self.mlps, balls, csrs):
+            x = _GroupRows.apply(xyz, features, new_xyz, bidx, _cpad(3 + C), csr)     # (B*npoint*nsample, cpad)
             outs.append(_MaxSamples.apply(shared_mlp_rows(mlp, x), grouper.nsample))  # (B*npoint, C')
         return new_xyz, torch.cat(outs, dim=1).view(B, self.npoint, -1)
 
@@ -313,6 +331,12 @@ class PointnetSAModuleMSG(nn.Module):
         rows = None if features is None else features.transpose(1, 2).contiguous()
         new_xyz, out = self.forward_rows(xyz, rows, pre=pre)
         return new_xyz, out.transpose(1, 2).contiguous()
+
+
+def three_nn_plan(unknown, known):
+    """(dist, idx) of three_nn + the edges of the interpolation's backward grouped by known point."""
+    dist, idx = three_nn(unknown, known)
+    return dist, idx, group_edges(idx, known.shape[1])
 
 
 class PointnetFPModule(nn.Module):
@@ -324,12 +348,12 @@ class PointnetFPModule(nn.Module):
 
     def forward_rows(self, unknown, known, unknow_feats, known_feats, pre=None):
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,n,C2) rows or None, known_feats (B,m,C1) rows -> (B,n,C') rows."""
-        dist, idx = pre if pre is not None else three_nn(unknown, known)
+        dist, idx, csr = pre if pre is not None else three_nn_plan(unknown, known)
         w = 1.0 / (dist + 1e-8)
         w = w / w.sum(dim=2, keepdim=True)
         B, n = idx.shape[0], idx.shape[1]
         c = known_feats.shape[-1] + (0 if unknow_feats is None else unknow_feats.shape[-1])
-        x = _FpRows.apply(known_feats, _i32(idx), w.detach(), unknow_feats, _cpad(c))
+        x = _FpRows.apply(known_feats, _i32(idx), w.detach(), unknow_feats, _cpad(c), csr)
         return shared_mlp_rows(self.mlp, x).view(B, n, -1)
 
     def forward(self, unknown, known, unknow_feats, known_feats, pre=None):
@@ -376,8 +400,8 @@ class PointNet2MSG(nn.Module):
     @torch.no_grad()
     def index_plan(self, points, batch_size):
         """Every index tensor of the forward — furthest-point samples, ball-query groups, three nearest neighbours — from the
-        point coordinates alone (none of them depends on a weight): {"sa": [(fps idx, new_xyz, [ball idx])], "fp": {i: (dist,
-        idx)}}.  A training loop can compute the plan of the NEXT batch on a side stream while the current step runs
+        point coordinates alone (none of them depends on a weight): {"sa": [(fps idx, new_xyz, [ball idx], [backward edges])],
+        "fp": {i: (dist, idx, backward edges)}}.  A training loop can compute the plan of the NEXT batch on a side stream while the current step runs
         (detector.prefetch_point_indices); forward() takes it from batch_dict["_pn2_plan"]."""
         xyz = points[:, 1:4].contiguous().view(batch_size, -1, 3)
         l_xyz, sa_plan = [xyz], []
@@ -385,7 +409,7 @@ class PointNet2MSG(nn.Module):
             pre = sa.indices(l_xyz[-1])
             sa_plan.append(pre)
             l_xyz.append(pre[1])
-        fp_plan = {i: three_nn(l_xyz[i - 1], l_xyz[i]) for i in range(-1, -(len(self.FP_modules) + 1), -1)}
+        fp_plan = {i: three_nn_plan(l_xyz[i - 1], l_xyz[i]) for i in range(-1, -(len(self.FP_modules) + 1), -1)}
         return {"sa": sa_plan, "fp": fp_plan}
 
     def forward(self, batch_dict):

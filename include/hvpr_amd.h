@@ -347,6 +347,17 @@ int hvpr_point_pillar_topk_f32(const float *pillars, int M, const float *points,
 int hvpr_scatter_add_rows_f32(const float *src, const int32_t *idx, long long m, int row_floats, int n_dst, float *dst,
                               hvpr_stream_t stream);
 
+/* a9 / a10 (training)  The scattering gradients WITHOUT atomics (a point belongs to many groups — backward of QueryAndGroup,
+ * pointnet2_backbone.py:27-34; a known point feeds many unknown ones — backward of three_interpolate, :40-47; backward of the row
+ * gather `points[idx]`, pointpillar_scatter.py:76): dst[d][c] = sum, over the edges e = rowptr[d] .. rowptr[d+1]-1 of destination d
+ * and IN THAT ORDER, of edge_w[e] * src[edge_row[e] * src_stride + src_off + c], c < C (edge_w may be null: weights 1; edge_row
+ * may be null: edge e reads row e).  One
+ * sequential fp32 sum per output element: two runs give the same bits.  The caller sorts the edges by destination (stable) once;
+ * dst [n_dst, dst_stride] is overwritten. */
+int hvpr_segment_sum_rows_f32(const float *src, long long src_stride, int src_off, int C, const int32_t *edge_row,
+                              const float *edge_w, const int32_t *rowptr, long long n_dst, float *dst, long long dst_stride,
+                              hvpr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a10 (training)  MemAE memory addressing with hard shrinkage, MemoryUnit_Agg.forward training branch,
  *     map_to_bev/memory_module.py:31-48 (+ hard_shrink_relu :85-87), without materialising the (R, n_items) attention:

@@ -350,3 +350,56 @@ def test_row_kernels_without_features_and_without_skip():
     (gkn,) = torch.autograd.grad(rows, known, torch.ones_like(rows))
     (gw,) = torch.autograd.grad(want, known, torch.ones_like(want))
     torch.testing.assert_close(gkn, gw, rtol=1e-4, atol=1e-5)
+
+
+def test_scattering_gradients_are_reproducible_and_match_float64():
+    """The three gradients that scatter (QueryAndGroup rows, three-interpolate rows, the row gather of get_score) are sums per
+    destination in a fixed order (hvpr_segment_sum_rows_f32 over edges sorted by destination, stable) — no float atomics: two
+    backward passes give the SAME BITS, and the values match a float64 index_add."""
+    from hvpr_amd import kernels, map_to_bev
+    g = torch.Generator().manual_seed(5)
+    B, N, C, np_, ns = 2, 300, 24, 64, 16
+    xyz = torch.rand(B, N, 3, generator=g).to(DEV)
+    new_xyz = xyz[:, :np_].contiguous()
+    idx = torch.randint(0, 40, (B, np_, ns), generator=g, dtype=torch.int32).to(DEV)       # heavy duplication: 40 hot points
+    gout = torch.randn(B * np_ * ns, 32, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        feat = torch.randn(B, N, C, generator=torch.Generator().manual_seed(6)).to(DEV).requires_grad_(True)
+        rows = pointnet2._GroupRows.apply(xyz, feat, new_xyz, idx, 32)
+        (rows * gout).sum().backward()
+        outs.append(feat.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(B * N, C, dtype=torch.float64, device=DEV)
+    dst = (idx.long().view(B, -1) + torch.arange(B, device=DEV).view(B, 1) * N).view(-1)
+    ref.index_add_(0, dst, gout[:, 3:3 + C].double())
+    torch.testing.assert_close(outs[0].double().view(B * N, C), ref, rtol=1e-5, atol=1e-5)
+    # three-interpolate rows
+    m, n, C1 = 50, 400, 16
+    known0 = torch.randn(B, m, C1, generator=g).to(DEV)
+    idx3 = torch.randint(0, 12, (B, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    w3 = torch.rand(B, n, 3, generator=g).to(DEV)
+    gout = torch.randn(B * n, 16, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        known = known0.clone().requires_grad_(True)
+        rows = pointnet2._FpRows.apply(known, idx3, w3, None, 16)
+        (rows * gout).sum().backward()
+        outs.append(known.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(B * m, C1, dtype=torch.float64, device=DEV)
+    dst = (idx3.long().view(B, -1) + torch.arange(B, device=DEV).view(B, 1) * m).view(-1)
+    ref.index_add_(0, dst, (gout.double().view(B * n, 1, 16) * w3.double().view(B * n, 3, 1)).view(-1, 16))
+    torch.testing.assert_close(outs[0].double().view(B * m, C1), ref, rtol=1e-5, atol=1e-5)
+    # row gather
+    rows0 = torch.randn(500, 64, generator=g).to(DEV)
+    pick = torch.randint(0, 30, (200, 20), generator=g).to(DEV)
+    gout = torch.randn(200, 20, 64, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        r = rows0.clone().requires_grad_(True)
+        (map_to_bev._GatherRows.apply(r, pick) * gout).sum().backward()
+        outs.append(r.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(500, 64, dtype=torch.float64, device=DEV).index_add_(0, pick.view(-1), gout.double().view(-1, 64))
+    torch.testing.assert_close(outs[0].double(), ref, rtol=1e-5, atol=1e-5)

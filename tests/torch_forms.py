@@ -120,7 +120,7 @@ def head_train(self, data_dict):
 def sa_forward_rows(self, xyz, features=None, pre=None):
     """PointnetSAModuleMSG (pointnet2_backbone.py:27-34) with torch gathers, torch 1x1 Conv2d + BatchNorm2d + ReLU and torch max;
     the index tensors (FPS, ball query) come from `pre` or the module's own index kernels."""
-    idx, new_xyz, balls = pre if pre is not None else self.indices(xyz)
+    idx, new_xyz, balls = (pre if pre is not None else self.indices(xyz))[:3]
     B = xyz.shape[0]
     ar = torch.arange(B, device=xyz.device)[:, None, None]
     outs = []
@@ -137,7 +137,7 @@ def sa_forward_rows(self, xyz, features=None, pre=None):
 def fp_forward_rows(self, unknown, known, unknow_feats, known_feats, pre=None):
     """PointnetFPModule (pointnet2_backbone.py:40-47, 86-89) with torch gathers and the torch shared MLP."""
     from hvpr_amd import pointnet2
-    dist, idx = pre if pre is not None else pointnet2.three_nn(unknown, known)
+    dist, idx = (pre if pre is not None else pointnet2.three_nn(unknown, known))[:2]
     w = 1.0 / (dist + 1e-8)
     w = w / w.sum(dim=2, keepdim=True)
     B = idx.shape[0]
