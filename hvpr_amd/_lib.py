@@ -63,6 +63,8 @@ SIGNATURES = {
     "hvpr_bn_stats_nhwc_f32": (_I, [_P, _c.c_longlong, _I, _F, _P, _P, _P, _P, _Z, _P]),
     "hvpr_bn_relu_fwd_nhwc_f32": (_I, [_P, _c.c_longlong, _I, _P, _P, _I, _P, _P, _P, _P]),
     "hvpr_bn_relu_bwd_nhwc_f32": (_I, [_P, _P, _c.c_longlong, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "hvpr_bn_relu_bwd_sums_nhwc_f32": (_I, [_P, _P, _c.c_longlong, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "hvpr_bn_relu_bwd_apply_nhwc_f32": (_I, [_P, _P, _c.c_longlong, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _c.c_double, _P]),
     "hvpr_memory_train_workspace_bytes": (_Z, [_I]),
     "hvpr_memory_train_fwd_f32": (_I, [_P, _c.c_longlong, _P, _I, _F, _P, _P, _P, _Z, _P]),
     "hvpr_memory_train_bwd_f32": (_I, [_P, _P, _c.c_longlong, _P, _I, _F, _P, _P, _P, _P, _P, _Z, _P]),

@@ -21,6 +21,51 @@ from ._lib import check, lib
 
 _ws_cache = {}
 
+# ---------------------------------------------------------------------------------------------- SyncBatchNorm
+# tools/train.py:119-120 turns every BatchNorm into torch.nn.SyncBatchNorm when --sync_bn is given (off by default).  The
+# BatchNorms of this path do not run torch's kernels, so convert_sync_batchnorm would not synchronise anything; instead the
+# statistics of bn_relu / sfm_step below — every BatchNorm2d of the two-stream backbone and head, the point stream's shared MLPs
+# and the VFE scale stream — are all-reduced over a process group when one is set here: per-channel (sum x, sum x^2, count) in the
+# forward, (sum dy, sum dy * xhat) in the backward, in float64, one all-reduce each (RCCL on the GPU; gloo runs the same code).
+# Not covered: the two BatchNorm1d inside the fused PFN kernels (csrc/vfe_train.hip) and SpatialAttention's one-channel
+# BatchNorm (csrc/gate_train.hip) keep per-rank statistics.
+_sync = {"group": None}
+
+
+def set_sync_batchnorm(group=True):
+    """group: a torch.distributed process group, True = the default group, None / False = off (per-rank statistics)."""
+    _sync["group"] = None if not group else group
+
+
+def _sync_group():
+    g = _sync["group"]
+    if g is None or not torch.distributed.is_available() or not torch.distributed.is_initialized():
+        return None
+    return None if g is True else g, True
+
+
+def sync_moments(sum_x, sum_x2, count, eps, group=None):
+    """Global batch statistics from per-rank sums: all-reduce of [sum x | sum x^2 | count] in float64 -> (mean, biased variance,
+    1 / sqrt(var + eps)) as float32 and the global count as a float64 scalar tensor.  Pure torch: CPU tensors with gloo, GPU
+    tensors with RCCL."""
+    C = sum_x.numel()
+    packed = torch.cat([sum_x.double().view(-1), sum_x2.double().view(-1), torch.tensor([float(count)], dtype=torch.float64, device=sum_x.device)])
+    torch.distributed.all_reduce(packed, group=group)
+    n = packed[2 * C]
+    mean = packed[:C] / n
+    var = (packed[C:2 * C] / n - mean * mean).clamp_min(0.0)
+    return mean.float(), var.float(), torch.rsqrt(var + float(eps)).float(), n
+
+
+def sync_backward_sums(dgamma, dbeta, count, group=None):
+    """(sum dy * xhat, sum dy) of the global batch, already divided by the global count (float32), from the per-rank sums."""
+    C = dgamma.numel()
+    packed = torch.cat([dgamma.double().view(-1), dbeta.double().view(-1)])
+    torch.distributed.all_reduce(packed, group=group)
+    packed = packed / count
+    return packed[:C].float().contiguous(), packed[C:].float().contiguous()
+
+
 
 def _workspace(nbytes, device):
     """One grow-only scratch buffer per device: every kernel that takes it consumes it before the next one is enqueued on the
@@ -57,7 +102,39 @@ def bn_statistics(z, eps, partials=None):
         ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), dev)
         check(lib().hvpr_bn_stats_nhwc_f32(kernels._ptr(z, torch.float32, "z"), P, C, float(eps), mean.data_ptr(), var.data_ptr(),
                                            invstd.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_stats_nhwc_f32")
-    return mean, var, invstd
+    sg = _sync_group()
+    if sg is None:
+        return mean, var, invstd, P
+    if partials is not None and partials.numel() > 0:
+        sums = partials.double().sum(0)
+        s1, s2 = sums[0], sums[1]
+    else:
+        s1 = mean.double() * P
+        s2 = (var.double() + mean.double() ** 2) * P
+    return sync_moments(s1, s2, P, eps, sg[0])
+
+
+def _bn_backward(dy, z, P, C, scale, shift, mean, invstd, relu, gate, dgate, count):
+    """dz, d gamma, d beta of the train-mode BatchNorm (+ ReLU, + SFM gate) — one kernel pair per rank, or, with SyncBatchNorm,
+    the two halves with the all-reduce of the two sums between them (count: the global count of the forward)."""
+    dz = torch.empty_like(z)
+    dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
+    ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), z.device)
+    sg = _sync_group()
+    if sg is None or not torch.is_tensor(count):
+        check(lib().hvpr_bn_relu_bwd_nhwc_f32(kernels._ptr(dy, torch.float32, "dy"), z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(),
+                                              mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0, kernels._ptr(gate), kernels._ptr(dgate),
+                                              dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              kernels._stream()), "hvpr_bn_relu_bwd_nhwc_f32")
+        return dz, dgamma, dbeta
+    check(lib().hvpr_bn_relu_bwd_sums_nhwc_f32(kernels._ptr(dy, torch.float32, "dy"), z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(),
+                                               mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0, kernels._ptr(gate), dgamma.data_ptr(),
+                                               dbeta.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_bn_relu_bwd_sums_nhwc_f32")
+    dg_t, db_t = sync_backward_sums(dgamma, dbeta, count, sg[0])          # over the global batch, divided by its count
+    check(lib().hvpr_bn_relu_bwd_apply_nhwc_f32(dy.data_ptr(), z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                                invstd.data_ptr(), 1 if relu else 0, kernels._ptr(gate), kernels._ptr(dgate), dz.data_ptr(),
+                                                dg_t.data_ptr(), db_t.data_ptr(), 1.0, kernels._stream()), "hvpr_bn_relu_bwd_apply_nhwc_f32")
+    return dz, dgamma, dbeta          # parameter gradients: this rank's sums (DistributedDataParallel averages them)
 
 
 def conv_fwd_raw(x, weight, stride=1, adjoint=False, stats=False):
@@ -177,7 +254,7 @@ class _BNReLU(torch.autograd.Function):
         C = z.shape[-1]
         P = z.numel() // C
         dev = z.device
-        mean, var, invstd = bn_statistics(z, eps, partials)
+        mean, var, invstd, count = bn_statistics(z, eps, partials)
         scale = (gamma.detach() * invstd).contiguous()
         shift = (beta.detach() - mean * scale).contiguous()
         y = torch.empty_like(z)
@@ -188,24 +265,19 @@ class _BNReLU(torch.autograd.Function):
                                               kernels._ptr(gate, torch.float32, "gate"), kernels._ptr(resid, torch.float32, "resid"),
                                               y.data_ptr(), kernels._stream()), "hvpr_bn_relu_fwd_nhwc_f32")
         ctx.save_for_backward(z, scale, shift, mean, invstd, gate)
-        ctx.relu = relu
-        ctx.mark_non_differentiable(mean, var)
-        return y, mean, var
+        ctx.relu, ctx.count = relu, count
+        cnt = count if torch.is_tensor(count) else mean.new_tensor(float(count), dtype=torch.float64)
+        ctx.mark_non_differentiable(mean, var, cnt)
+        return y, mean, var, cnt
 
     @staticmethod
-    def backward(ctx, dy, _dm, _dv):
+    def backward(ctx, dy, _dm, _dv, _dc):
         z, scale, shift, mean, invstd, gate = ctx.saved_tensors
         dy = dy.contiguous()
         C = z.shape[-1]
         P = z.numel() // C
-        dz = torch.empty_like(z)
-        dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
         dgate = torch.empty_like(gate) if gate is not None else None
-        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), z.device)
-        check(lib().hvpr_bn_relu_bwd_nhwc_f32(kernels._ptr(dy, torch.float32, "dy"), z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(),
-                                              mean.data_ptr(), invstd.data_ptr(), 1 if ctx.relu else 0, kernels._ptr(gate), kernels._ptr(dgate),
-                                              dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
-                                              kernels._stream()), "hvpr_bn_relu_bwd_nhwc_f32")
+        dz, dgamma, dbeta = _bn_backward(dy, z, P, C, scale, shift, mean, invstd, ctx.relu, gate, dgate, ctx.count)
         return dz, dgamma, dbeta, None, None, dgate, (dy if gate is not None else None), None
 
 
@@ -231,7 +303,7 @@ class _SfmStep(torch.autograd.Function):
         C = z.shape[-1]
         P = z.numel() // C
         dev = z.device
-        mean, var, invstd = bn_statistics(z, eps, partials)
+        mean, var, invstd, count = bn_statistics(z, eps, partials)
         scale = (gamma.detach() * invstd).contiguous()
         shift = (beta.detach() - mean * scale).contiguous()
         gate = gate.detach().contiguous()
@@ -240,23 +312,19 @@ class _SfmStep(torch.autograd.Function):
         check(lib().hvpr_bn_relu_fwd_nhwc_f32(z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(), 1, gate.data_ptr(), x.data_ptr(),
                                               y.data_ptr(), kernels._stream()), "hvpr_bn_relu_fwd_nhwc_f32")
         ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gate)
-        ctx.mark_non_differentiable(mean, var)
-        return y, mean, var
+        ctx.count = count
+        cnt = count if torch.is_tensor(count) else mean.new_tensor(float(count), dtype=torch.float64)
+        ctx.mark_non_differentiable(mean, var, cnt)
+        return y, mean, var, cnt
 
     @staticmethod
-    def backward(ctx, dy, _dm, _dv):
+    def backward(ctx, dy, _dm, _dv, _dc):
         x, weight, z, scale, shift, mean, invstd, gate = ctx.saved_tensors
         dy = dy.contiguous()
         C = z.shape[-1]
         P = z.numel() // C
-        dz = torch.empty_like(z)
-        dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
         dgate = torch.empty_like(gate)
-        ws = _workspace(lib().hvpr_bn_workspace_bytes(P, C), z.device)
-        check(lib().hvpr_bn_relu_bwd_nhwc_f32(kernels._ptr(dy, torch.float32, "dy"), z.data_ptr(), P, C, scale.data_ptr(), shift.data_ptr(),
-                                              mean.data_ptr(), invstd.data_ptr(), 1, gate.data_ptr(), dgate.data_ptr(), dz.data_ptr(),
-                                              dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()),
-              "hvpr_bn_relu_bwd_nhwc_f32")
+        dz, dgamma, dbeta = _bn_backward(dy, z, P, C, scale, shift, mean, invstd, True, gate, dgate, ctx.count)
         cout, cin = weight.shape[0], weight.shape[1]
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -272,18 +340,23 @@ class _SfmStep(torch.autograd.Function):
 
 def sfm_step(x, weight, bn, gate):
     """gate * relu(bn(conv3x3(x))) + x with train-mode `bn` (running statistics updated like nn.BatchNorm2d), one autograd node."""
-    y, mean, var = _SfmStep.apply(x, weight, bn.weight, bn.bias, bn.eps, gate)
-    _update_running(bn, mean, var, x.numel() // x.shape[-1])
+    y, mean, var, count = _SfmStep.apply(x, weight, bn.weight, bn.bias, bn.eps, gate)
+    _update_running(bn, mean, var, count if _sync_group() is not None else x.numel() // x.shape[-1])
     return y
 
 
 def _update_running(bn, mean, var, n):
+    """n: the number of values per channel the statistics were taken over — a python number, or (SyncBatchNorm: the global count) a
+    scalar tensor; the unbiased-variance factor n / (n - 1) is then formed on the device."""
     if bn.track_running_stats:
         with torch.no_grad():
             bn.num_batches_tracked += 1
             m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
+            if torch.is_tensor(n):
+                bn.running_var.mul_(1 - m).add_(var * (n / (n - 1).clamp_min(1.0)).to(var.dtype) * m)
+            else:
+                bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
 
 
 def conv(x, weight, stride=1, stats=False):
@@ -300,14 +373,8 @@ def deconv(x, weight):
 def bn_relu(z, bn, relu=True, gate=None, resid=None, partials=None):
     """Train-mode nn.BatchNorm2d `bn` (its weight / bias / eps / momentum / running buffers) + optional ReLU on NHWC `z`; with
     gate (N,H,W,1) and resid (N,H,W,C): gate * relu(bn(z)) + resid, differentiable in all of them."""
-    y, mean, var = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu, gate, resid, partials)
-    if bn.track_running_stats:
-        with torch.no_grad():
-            n = z.numel() // z.shape[-1]
-            bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
+    y, mean, var, count = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu, gate, resid, partials)
+    _update_running(bn, mean, var, count if _sync_group() is not None else z.numel() // z.shape[-1])
     return y
 
 

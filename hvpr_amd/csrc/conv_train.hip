@@ -426,25 +426,49 @@ extern "C" int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, con
     return HVPR_OK;
 }
 
-extern "C" int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
-                                         const float *mean, const float *invstd, int relu, const float *gate, float *dgate, float *dz,
-                                         float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
-    if (!dy || !z || !scale || !shift || !mean || !invstd || !dz || !dgamma || !dbeta || !workspace || P < 1) return HVPR_ERR_INVALID_ARG;
-    if ((gate == nullptr) != (dgate == nullptr)) return HVPR_ERR_INVALID_ARG;
+// The backward in its two halves, so that a caller can put an all-reduce between them (SyncBatchNorm: the sums and the count are
+// those of the GLOBAL batch, tools/train.py:119-120): sums = local d beta / d gamma; apply = dz from whatever sums it is given.
+extern "C" int hvpr_bn_relu_bwd_sums_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
+                                              const float *mean, const float *invstd, int relu, const float *gate, float *dgamma,
+                                              float *dbeta, void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
+    if (!dy || !z || !scale || !shift || !mean || !invstd || !dgamma || !dbeta || !workspace || P < 1) return HVPR_ERR_INVALID_ARG;
     if (C < 4 || C % 4 != 0 || C > 1024) return HVPR_ERR_UNSUPPORTED;
     if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
     const int blocks = bn_blocks(P);
     hipStream_t s = (hipStream_t)stream;
-    if (dgate) hipLaunchKernelGGL(k_zero_p, dim3(hvpr_cdiv(P, 256) > 8192 ? 8192 : hvpr_cdiv(P, 256)), dim3(256), 0, s, dgate, P);
     hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, s, z, dy, P, C, scale, shift, mean, invstd, relu, gate, (float *)workspace);
     // s1 -> dbeta, s2 -> dgamma  (d beta = sum dy_m, d gamma = sum dy_m * xhat)
     hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, 0.f, 1, dbeta,
                        dgamma, (float *)nullptr);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_bn_relu_bwd_apply_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
+                                               const float *mean, const float *invstd, int relu, const float *gate, float *dgate, float *dz,
+                                               const float *dgamma_total, const float *dbeta_total, double inv_count, hvpr_stream_t stream) {
+    if (!dy || !z || !scale || !shift || !mean || !invstd || !dz || !dgamma_total || !dbeta_total || P < 1 || !(inv_count > 0.0))
+        return HVPR_ERR_INVALID_ARG;
+    if ((gate == nullptr) != (dgate == nullptr)) return HVPR_ERR_INVALID_ARG;
+    if (C < 4 || C % 4 != 0 || C > 1024) return HVPR_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (dgate) hipLaunchKernelGGL(k_zero_p, dim3(hvpr_cdiv(P, 256) > 8192 ? 8192 : hvpr_cdiv(P, 256)), dim3(256), 0, s, dgate, P);
     const long long n4 = P * (C / 4);
     long long g = (n4 + 255) / 256;
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, s, (const float4 *)dy, (const float4 *)z, n4, C / 4, scale, shift, mean,
-                       invstd, dbeta, dgamma, (float)(1.0 / (double)P), relu, gate, dgate, (float4 *)dz);
+                       invstd, dbeta_total, dgamma_total, (float)inv_count, relu, gate, dgate, (float4 *)dz);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
+}
+
+extern "C" int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
+                                         const float *mean, const float *invstd, int relu, const float *gate, float *dgate, float *dz,
+                                         float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
+    if (!dz || (gate == nullptr) != (dgate == nullptr)) return HVPR_ERR_INVALID_ARG;
+    const int st = hvpr_bn_relu_bwd_sums_nhwc_f32(dy, z, P, C, scale, shift, mean, invstd, relu, gate, dgamma, dbeta, workspace,
+                                                  workspace_bytes, stream);
+    if (st != HVPR_OK) return st;
+    return hvpr_bn_relu_bwd_apply_nhwc_f32(dy, z, P, C, scale, shift, mean, invstd, relu, gate, dgate, dz, dgamma, dbeta, 1.0 / (double)P,
+                                           stream);
 }

@@ -128,6 +128,16 @@ def finalize():
         dist.destroy_process_group()
 
 
+def convert_sync_batchnorm(model, process_group=None):
+    """The counterpart of `torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` (reference tools/train.py:119-120, --sync_bn) for
+    this path: its BatchNorms run the library's own kernels, so there is no module to swap — the batch statistics of
+    conv_train.bn_relu / sfm_step (backbone, head, point-stream MLPs, VFE scale stream) are all-reduced over `process_group`
+    (default group when None) from now on.  Returns the model unchanged; call before wrap_ddp."""
+    from . import conv_train
+    conv_train.set_sync_batchnorm(process_group if process_group is not None else True)
+    return model
+
+
 def wrap_ddp(model, device):
     """Data-parallel training wrapper (reference: tools/train.py:143-145): one process per GPU, gradient all-reduce over
     RCCL ("nccl" backend) overlapped with backward in ~25 MB buckets; the ~62 MB of fp32 gradients take ~0.7 ms on the

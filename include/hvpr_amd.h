@@ -409,6 +409,16 @@ int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *s
 int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
                               const float *mean, const float *invstd, int relu, const float *gate, float *dgate, float *dz, float *dgamma,
                               float *dbeta, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+/* The same backward in its two halves, for SyncBatchNorm (tools/train.py:119-120 converts every BatchNorm when --sync_bn is given):
+ * _sums leaves the LOCAL d gamma = sum dy_m * xhat and d beta = sum dy_m (dy_m = dy through the ReLU / gate); the caller all-reduces
+ * them over the ranks; _apply computes dz (and dgate) from the sums and 1 / count of the GLOBAL batch.  hvpr_bn_relu_bwd_nhwc_f32 is
+ * _sums followed by _apply with the local sums and 1 / P. */
+int hvpr_bn_relu_bwd_sums_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
+                                   const float *mean, const float *invstd, int relu, const float *gate, float *dgamma, float *dbeta,
+                                   void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+int hvpr_bn_relu_bwd_apply_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
+                                    const float *mean, const float *invstd, int relu, const float *gate, float *dgate, float *dz,
+                                    const float *dgamma_total, const float *dbeta_total, double inv_count, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a14 (training)  Optimiser step over ONE flat fp32 parameter buffer (and matching flat gradient / moment buffers, all

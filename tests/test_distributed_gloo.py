@@ -268,3 +268,61 @@ def test_bench_refuses_more_ranks_than_gpus():
     for script in ("bench.py", os.path.join("tools", "bench_train.py")):
         p = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout), (script, p.stderr[-500:])
+
+
+# ------------------------------------------------------------------------------------------------ SyncBatchNorm (tools/train.py:119-120)
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from hvpr_amd import conv_train, distributed
+    distributed.init("gloo")
+    g = torch.Generator().manual_seed(3)
+    x_full = torch.randn(2, 6, 5, 8, generator=g) * 2.0 + 0.7            # (N, H, W, C): rank r owns sample r
+    wout = torch.randn(2, 6, 5, 8, generator=g)
+    gamma, beta, eps = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g), 1e-3
+    x = x_full[rank:rank + 1].reshape(-1, 8)
+    # what conv_train.bn_statistics / _bn_backward do around the kernels, with the kernels' sums written in torch
+    mean, var, invstd, n = conv_train.sync_moments(x.sum(0), (x * x).sum(0), x.shape[0], eps)
+    xhat = (x - mean) * invstd
+    y = torch.relu(xhat * gamma + beta)
+    dy = wout[rank:rank + 1].reshape(-1, 8) * (y > 0)
+    dgamma_l, dbeta_l = (dy * xhat).sum(0), dy.sum(0)
+    dg_t, db_t = conv_train.sync_backward_sums(dgamma_l, dbeta_l, n)
+    dz = gamma * invstd * (dy - db_t - xhat * dg_t)
+    distributed.finalize()
+    q.put((rank, y.numpy(), dz.numpy(), dgamma_l.numpy(), dbeta_l.numpy(), mean.numpy(), var.numpy(), float(n)))
+
+
+def test_sync_batchnorm_two_ranks_batch1_equal_one_process_batch2():
+    """SyncBatchNorm over the own BatchNorm kernels: the collective half (conv_train.sync_moments / sync_backward_sums — float64
+    all-reduces of (sum x, sum x^2, count) and (sum dy xhat, sum dy)) on two gloo ranks with one sample each, against train-mode
+    BatchNorm + ReLU over both samples in one process (float64 autograd): output, input gradient, and the SUM of the ranks' weight /
+    bias gradients.  (The kernels on either side of the all-reduces are covered on the GPU: tests/test_gpu_conv_train.py and the
+    one-rank RCCL test in tests/test_gpu_distributed.py.)"""
+    import torch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(3)
+    x_full = (torch.randn(2, 6, 5, 8, generator=g) * 2.0 + 0.7).double().requires_grad_(True)
+    wout = torch.randn(2, 6, 5, 8, generator=g).double()
+    gamma = (torch.rand(8, generator=g) + 0.5).double().requires_grad_(True)
+    beta = torch.randn(8, generator=g).double().requires_grad_(True)
+    y = torch.relu(torch.nn.functional.batch_norm(x_full.permute(0, 3, 1, 2), None, None, gamma, beta, True, 0.0, 1e-3)).permute(0, 2, 3, 1)
+    (y * wout).sum().backward()
+    for r in range(2):
+        _, yr, dzr, _, _, mean, var, n = [torch.from_numpy(t) if hasattr(t, "dtype") else t for t in got[r]]
+        assert n == 60.0
+        torch.testing.assert_close(yr.double().view(1, 6, 5, 8), y[r:r + 1].detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dzr.double().view(1, 6, 5, 8), x_full.grad[r:r + 1], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(mean.double(), x_full.detach().reshape(-1, 8).mean(0), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(var.double(), x_full.detach().reshape(-1, 8).var(0, unbiased=False), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(torch.from_numpy(got[0][3] + got[1][3]).double(), gamma.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch.from_numpy(got[0][4] + got[1][4]).double(), beta.grad, rtol=1e-4, atol=1e-5)

@@ -49,3 +49,21 @@ def test_bench_train_step_ddp_line_over_one_rank_rccl(tmp_path):
     assert 55.0 < r["allreduce_MB"] < 70.0                      # ~15.5 M fp32 gradients
     assert r["ms_per_step"] > 0 and r["frames_per_s_global"] > 0
     assert all(np.isfinite(r["loss_first_last"]))
+
+
+def test_sync_batchnorm_path_on_one_rank_rccl(tmp_path):
+    """SyncBatchNorm (reference tools/train.py:119-120) over the own BatchNorm kernels: conv -> bn_relu (statistics from the Winograd
+    kernel's per-tile sums) -> fused SFM step, forward + backward, with the statistics all-reduced over a one-rank RCCL group against
+    the per-rank path.  At world size 1 the two compute the same numbers by different routes (float64 torch sums + split backward
+    vs the finalize kernel + fused backward): agreement to fp32 round-off.  The N > 1 arithmetic of the all-reduces is covered on
+    CPU/gloo (test_sync_batchnorm_two_ranks_batch1_equal_one_process_batch2)."""
+    from hvpr_amd import distributed
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_syncbn_worker.py")
+    out = tmp_path / "syncbn.json"
+    rc = distributed.launch_local(1, [worker, str(out)], timeout=600)
+    assert rc == 0
+    r = json.load(open(out))
+    print(r)
+    assert r["backend"] == "nccl" and r["world"] == 1
+    for k, v in r["rel"].items():
+        assert v <= 2e-6, (k, v)
