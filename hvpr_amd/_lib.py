@@ -13,11 +13,13 @@ _P = _c.c_void_p
 _I = _c.c_int
 _F = _c.c_float
 _Z = _c.c_size_t
+ALLREDUCE_FN = _c.CFUNCTYPE(_I, _P, _I, _P, _P)      # hvpr_allreduce_fn: (double *buf, int n, hvpr_stream_t stream, void *ctx) -> int
 
 # name -> (restype, argtypes); mirrors include/hvpr_amd.h one to one (checked by tests/test_capi_symbols.py)
 SIGNATURES = {
     "hvpr_abi_version": (_I, []),
     "hvpr_status_string": (_c.c_char_p, [_I]),
+    "hvpr_set_batchnorm_allreduce": (None, [_P, _P]),
     "hvpr_voxelize_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "hvpr_voxelize_workspace_reset": (_I, [_P, _Z, _I, _I, _I, _I, _I, _P]),
     "hvpr_voxelize_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I,

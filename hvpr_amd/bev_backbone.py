@@ -224,7 +224,7 @@ class BaseBEVBackbone_Scale(nn.Module):
             statistics receive the `uses` identical updates in closed form."""
             sp = self.attention.spatial
             g, mean, var = ct.spatial_gate_train(y, sp.conv.weight, sp.conv.bias, sp.norm.weight, sp.norm.bias, sp.norm.eps)
-            ct.update_running_repeated(sp.norm, mean, var, y.numel() // y.shape[-1], uses)
+            ct.update_running_repeated(sp.norm, mean, var, ct.global_count(y.numel() // y.shape[-1], y.device), uses)
             return g                                                                       # (N,H,W,1)
 
         x, xp = nhwc(data_dict["spatial_features"]), nhwc(data_dict["spatial_features_point"])

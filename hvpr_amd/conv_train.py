@@ -27,14 +27,52 @@ _ws_cache = {}
 # statistics of bn_relu / sfm_step below — every BatchNorm2d of the two-stream backbone and head, the point stream's shared MLPs
 # and the VFE scale stream — are all-reduced over a process group when one is set here: per-channel (sum x, sum x^2, count) in the
 # forward, (sum dy, sum dy * xhat) in the backward, in float64, one all-reduce each (RCCL on the GPU; gloo runs the same code).
-# Not covered: the two BatchNorm1d inside the fused PFN kernels (csrc/vfe_train.hip) and SpatialAttention's one-channel
-# BatchNorm (csrc/gate_train.hip) keep per-rank statistics.
-_sync = {"group": None}
+# The two BatchNorm1d inside the fused PFN kernels (csrc/vfe_train.hip) and SpatialAttention's one-channel BatchNorm
+# (csrc/gate_train.hip) live inside single C-ABI calls; they reach the same all-reduce through the library's hook
+# (hvpr_set_batchnorm_allreduce, include/hvpr_amd.h), which set_sync_batchnorm installs and removes together with the group.
+_sync = {"group": None, "hook": None}
+
+
+class _DeviceDoubles:
+    """`n` float64 words at device address `ptr` for torch.as_tensor (the array interface torch reads device pointers through)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def device_doubles(ptr, n):
+    return torch.as_tensor(_DeviceDoubles(ptr, n), device="cuda")
+
+
+def _hook_allreduce(buf, n, stream, ctx):
+    # called by the library between two of its launches, on the thread that made the call; the kernels before it were enqueued on
+    # torch's current stream (kernels._stream()), which is also what the collective orders itself against
+    try:
+        g = _sync["group"]
+        if g is None or not torch.distributed.is_initialized():
+            return 0
+        torch.distributed.all_reduce(device_doubles(buf, n), group=None if g is True else g)
+        _sync["hook_calls"] = _sync.get("hook_calls", 0) + 1
+        return 0
+    except Exception:        # an exception must not cross the C frame: the entry point reports HVPR_ERR_LAUNCH
+        import traceback
+        traceback.print_exc()
+        return 1
 
 
 def set_sync_batchnorm(group=True):
     """group: a torch.distributed process group, True = the default group, None / False = off (per-rank statistics)."""
+    from ._lib import ALLREDUCE_FN
     _sync["group"] = None if not group else group
+    if _sync["group"] is None:
+        if _sync["hook"] is not None:            # (the library is loaded: it was needed to set the hook)
+            lib().hvpr_set_batchnorm_allreduce(None, None)
+            _sync["hook"] = None
+        return
+    if torch.cuda.is_available():                # the hooked entry points are GPU kernels; a CPU (gloo) run never reaches them
+        if _sync["hook"] is None:
+            _sync["hook"] = ALLREDUCE_FN(_hook_allreduce)     # kept alive here for as long as the library holds the pointer
+        lib().hvpr_set_batchnorm_allreduce(_sync["hook"], None)
 
 
 def _sync_group():
@@ -42,6 +80,17 @@ def _sync_group():
     if g is None or not torch.distributed.is_available() or not torch.distributed.is_initialized():
         return None
     return None if g is True else g, True
+
+
+def global_count(n, device):
+    """The number of values a BatchNorm's statistics are taken over: `n` (python number) without SyncBatchNorm, else its sum over
+    the ranks as a float64 scalar tensor (the unbiased-variance factor of the running statistics uses the global count)."""
+    sg = _sync_group()
+    if sg is None:
+        return n
+    t = torch.tensor([float(n)], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, group=sg[0])
+    return t[0]
 
 
 def sync_moments(sum_x, sum_x2, count, eps, group=None):
@@ -441,4 +490,7 @@ def update_running_repeated(bn, mean, var, n, times):
         keep = (1.0 - bn.momentum) ** times
         bn.num_batches_tracked += times
         bn.running_mean.mul_(keep).add_(mean.view_as(bn.running_mean), alpha=1.0 - keep)
-        bn.running_var.mul_(keep).add_(var.view_as(bn.running_var), alpha=(1.0 - keep) * n / max(n - 1, 1))
+        if torch.is_tensor(n):
+            bn.running_var.mul_(keep).add_(var.view_as(bn.running_var) * (n / (n - 1).clamp_min(1.0)).to(var.dtype) * (1.0 - keep))
+        else:
+            bn.running_var.mul_(keep).add_(var.view_as(bn.running_var), alpha=(1.0 - keep) * n / max(n - 1, 1))

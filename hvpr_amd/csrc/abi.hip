@@ -13,3 +13,13 @@ extern "C" const char *hvpr_status_string(int status) {
         default: return "unknown status";
     }
 }
+
+// SyncBatchNorm hook (include/hvpr_amd.h): the only state this library keeps between calls
+namespace { hvpr_allreduce_fn g_bn_allreduce = nullptr; void *g_bn_allreduce_ctx = nullptr; }
+
+extern "C" void hvpr_set_batchnorm_allreduce(hvpr_allreduce_fn fn, void *ctx) { g_bn_allreduce = fn; g_bn_allreduce_ctx = ctx; }
+
+int hvpr_i_bn_allreduce(double *buf, int n, hipStream_t s) {
+    if (!g_bn_allreduce) return 0;
+    return g_bn_allreduce(buf, n, (hvpr_stream_t)s, g_bn_allreduce_ctx);
+}

@@ -14,6 +14,9 @@
 
 static inline int hvpr_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// SyncBatchNorm (abi.hip): sums buf[0..n) over the ranks through the caller's hook, ordered on `s`; 0 without a hook / on success
+int hvpr_i_bn_allreduce(double *buf, int n, hipStream_t s);
+
 // 256-byte aligned carve helper for workspaces
 struct hvpr_carver {
     char *base;

@@ -6,10 +6,11 @@
 //
 //   forward   k_gt_pool      pooled[n,y,x] = (max_c y, mean_c y), argmax_c (lowest index on ties)
 //             k_gt_conv      a = conv3x3(pooled) + bias, per-workgroup partial (sum a, sum a^2)
-//             k_gt_stats     mean, biased variance, 1/sqrt(var + eps) of a over N*H*W (double sums, fixed order: deterministic)
+//             k_gt_sums      (count, sum, sum of squares) in double, fixed order: deterministic  [SyncBatchNorm hook here]
+//             k_gt_stats     mean, biased variance, 1/sqrt(var + eps) of a over the batch
 //             k_gt_apply     gate = sigmoid((a - mean) * invstd * gamma + beta)
 //   backward  k_gt_bwd_red   ds = dgate * gate * (1 - gate); partial (sum ds, sum ds * xhat)
-//             k_gt_bwd_fin   dbeta = sum ds, dgamma = sum ds * xhat
+//             k_gt_bwd_fin   dbeta = sum ds, dgamma = sum ds * xhat                              [SyncBatchNorm hook here]
 //             k_gt_bwd_da    da = gamma * invstd * (ds - dbeta / n - xhat * dgamma / n)      (batch statistics differentiated through)
 //             k_gt_bwd_conv  d pooled = conv_transpose(da, w); dy = d mean / C + [c == argmax] d max; partial dW (18), dbias
 //             k_gt_bwd_fin2  dW, dbias
@@ -117,13 +118,20 @@ __device__ __forceinline__ void final_sums(const float *__restrict__ part, int b
     }
 }
 
-__global__ void __launch_bounds__(256) k_gt_stats(const float *__restrict__ part, int blocks, double count, float eps,
-                                                  const float *__restrict__ bias, float *__restrict__ stats) {
+// one workgroup: tot = (count, sum, sum of squares) of the partial rows, in double
+__global__ void __launch_bounds__(256) k_gt_sums(const float *__restrict__ part, int blocks, double count, double *__restrict__ tot) {
     double t[2];
-    final_sums<2>(part, blocks, t);     // sums of (a - bias) and (a - bias)^2
+    final_sums<2>(part, blocks, t);
+    if (threadIdx.x == 0) { tot[0] = count; tot[1] = t[0]; tot[2] = t[1]; }
+}
+
+// tot (after the SyncBatchNorm hook, if any: sums of (a - bias) and (a - bias)^2 over the global batch) -> mean, variance, 1/std
+__global__ void __launch_bounds__(64) k_gt_stats(const double *__restrict__ tot, float eps, const float *__restrict__ bias,
+                                                 float *__restrict__ stats) {
     if (threadIdx.x == 0) {
-        const double ms = t[0] / count;
-        double var = t[1] / count - ms * ms;
+        const double count = tot[0];
+        const double ms = tot[1] / count;
+        double var = tot[2] / count - ms * ms;
         if (var < 0.0) var = 0.0;
         const double m = ms + (double)bias[0];
         stats[0] = (float)m; stats[1] = (float)var; stats[2] = (float)(1.0 / sqrt(var + (double)eps));
@@ -150,22 +158,24 @@ __global__ void __launch_bounds__(256) k_gt_bwd_red(const float *__restrict__ dg
     block_sums<2>(v, part + (size_t)blockIdx.x * 2);
 }
 
-__global__ void __launch_bounds__(256) k_gt_bwd_fin(const float *__restrict__ part, int blocks, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+// dbeta / dgamma of THIS rank (the parameter gradients), and tot = (count, sum ds, sum ds xhat) for the hook
+__global__ void __launch_bounds__(256) k_gt_bwd_fin(const float *__restrict__ part, int blocks, double count, float *__restrict__ dgamma,
+                                                    float *__restrict__ dbeta, double *__restrict__ tot) {
     double t[2];
     final_sums<2>(part, blocks, t);
-    if (threadIdx.x == 0) { dbeta[0] = (float)t[0]; dgamma[0] = (float)t[1]; }
+    if (threadIdx.x == 0) { dbeta[0] = (float)t[0]; dgamma[0] = (float)t[1]; tot[0] = count; tot[1] = t[0]; tot[2] = t[1]; }
 }
 
 __global__ void __launch_bounds__(256) k_gt_bwd_da(const float *__restrict__ dgate, const float *__restrict__ gate, const float *__restrict__ a,
                                                    long long P, const float *__restrict__ stats, const float *__restrict__ gamma,
-                                                   const float *__restrict__ dgamma, const float *__restrict__ dbeta, float inv_n,
-                                                   float *__restrict__ da) {
+                                                   const double *__restrict__ tot, float *__restrict__ da) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
+    const float inv_n = (float)(1.0 / tot[0]), dbeta = (float)tot[1], dgamma = (float)tot[2];      // over the (global) batch
     const float g = gate[p];
     const float ds = dgate[p] * g * (1.f - g);
     const float xh = (a[p] - stats[0]) * stats[2];
-    da[p] = gamma[0] * stats[2] * (ds - dbeta[0] * inv_n - xh * (dgamma[0] * inv_n));
+    da[p] = gamma[0] * stats[2] * (ds - dbeta * inv_n - xh * (dgamma * inv_n));
 }
 
 __global__ void __launch_bounds__(256) k_gt_bwd_conv(const float *__restrict__ da, const float2 *__restrict__ pooled, const int *__restrict__ argmax,
@@ -266,7 +276,10 @@ extern "C" int hvpr_spatial_gate_train_fwd_f32(const float *y, int N, int H, int
     const int n_tiles = (int)(tiles.x * tiles.y * tiles.z);
     hipLaunchKernelGGL(k_gt_pool, dim3(hvpr_cdiv(P, 32)), dim3(256), 0, s, y, P, C, (float2 *)pooled, argmax);
     hipLaunchKernelGGL(k_gt_conv, tiles, dim3(256), 0, s, (const float2 *)pooled, H, W, w18, conv_bias, a, part);
-    hipLaunchKernelGGL(k_gt_stats, dim3(1), dim3(256), 0, s, (const float *)part, n_tiles, (double)P, eps, conv_bias, stats);
+    double *tot = (double *)((char *)workspace + hvpr_spatial_gate_train_workspace_bytes(N, H, W) - 256);
+    hipLaunchKernelGGL(k_gt_sums, dim3(1), dim3(256), 0, s, (const float *)part, n_tiles, (double)P, tot);
+    if (hvpr_i_bn_allreduce(tot, 3, s) != 0) return HVPR_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_gt_stats, dim3(1), dim3(64), 0, s, (const double *)tot, eps, conv_bias, stats);
     hipLaunchKernelGGL(k_gt_apply, dim3(hvpr_cdiv(P, 256)), dim3(256), 0, s, (const float *)a, P, (const float *)stats, gamma, beta, gate);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
@@ -289,9 +302,10 @@ extern "C" int hvpr_spatial_gate_train_bwd_f32(const float *dgate, const float *
     float *da = (float *)((char *)workspace + (((size_t)n_tiles * 19 + 1024 * 2) * sizeof(float) + 255) / 256 * 256);
     const int rb = red_blocks(P);
     hipLaunchKernelGGL(k_gt_bwd_red, dim3(rb), dim3(256), 0, s, dgate, gate, a, P, stats, part);
-    hipLaunchKernelGGL(k_gt_bwd_fin, dim3(1), dim3(256), 0, s, (const float *)part, rb, dgamma, dbeta);
-    hipLaunchKernelGGL(k_gt_bwd_da, dim3(hvpr_cdiv(P, 256)), dim3(256), 0, s, dgate, gate, a, P, stats, gamma, (const float *)dgamma,
-                       (const float *)dbeta, (float)(1.0 / (double)P), da);
+    double *tot = (double *)((char *)workspace + hvpr_spatial_gate_train_workspace_bytes(N, H, W) - 256);
+    hipLaunchKernelGGL(k_gt_bwd_fin, dim3(1), dim3(256), 0, s, (const float *)part, rb, (double)P, dgamma, dbeta, tot);
+    if (hvpr_i_bn_allreduce(tot, 3, s) != 0) return HVPR_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_gt_bwd_da, dim3(hvpr_cdiv(P, 256)), dim3(256), 0, s, dgate, gate, a, P, stats, gamma, (const double *)tot, da);
     hipLaunchKernelGGL(k_gt_bwd_conv, tiles, dim3(256), 0, s, (const float *)da, (const float2 *)pooled, argmax, H, W, C, w18, dy, part);
     hipLaunchKernelGGL(k_gt_bwd_fin2, dim3(1), dim3(256), 0, s, (const float *)part, n_tiles, dw18, dbias);
     HVPR_CHECK_LAUNCH();

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
 
     // ---- step 2: wave w -> thresholds of its pillars w (, w + 8) ----
     const float wm = wmax[lane];
-    const float wsum = hvpr_reduce_sum<64>(wm), wtop = hvpr_reduce<64>(wm, op_maxr());
+    const float wsum = wmax[kC], wtop = wmax[kC + 1];     // sum_c wmax_c, max_c wmax_c (k_wmax_stats)
     unsigned exact_all = 0u;    // bit j: the wave's j-th pillar is outside the fp16 range: no pre-filter
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
@@ -162,8 +162,10 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
         if (p < np) {
             const float fa = fabsf(s_f[p * kC + lane]);                      // lane = channel
             // 2 eps_p: the bound on |A - L| of this pillar, doubled (see the header); infinite outside the fp16 range
-            float eps2 = 2.f * (hvpr_reduce_sum<64>(fmaf(kRelErr * wm, fa, kAbsErr * fa)) + kAbsErr * wsum + 1e-30f);
-            if (!(hvpr_reduce<64>(fa, op_maxr()) <= kHalfMax) || !(wtop <= kHalfMax)) eps2 = INFINITY;
+            float term = fmaf(kRelErr * wm, fa, kAbsErr * fa);
+            if (!(fa <= kHalfMax)) term = INFINITY;                          // (rides the sum: no second reduction)
+            float eps2 = 2.f * (hvpr_reduce_sum<64>(term) + kAbsErr * wsum + 1e-30f);
+            if (!(wtop <= kHalfMax)) eps2 = INFINITY;
             if (!(eps2 < INFINITY)) exact_all |= 1u << j;
             // tau <= k-th largest of the 64 lane maxima (its 16 leading bits): a lower bound of the k-th largest A
             const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(s_pm[p * 64 + lane]), k));
@@ -505,7 +507,7 @@ int launch_readout(const float *f, int M, const int32_t *m_device, const float *
 // bank (n_items, 64) row-major fp32 -> the read-out kernel's streaming copy:
 //   [ceil(n_items / 16) tiles][2 channel halves][64 lanes] x 8 fp16 (round to nearest even; rows past n_items zero): lane
 //   (l15, q) of half h holds channels 32h + 8q .. + 7 of item 16 * tile + l15 — the A operand of v_mfma_f32_16x16x32_f16,
-//   1 KB contiguous per load instruction; followed by wmax[64] fp32 = max_j |bank[j][c]| (the pre-filter's error bound).
+//   1 KB contiguous per load instruction; followed by wmax[64] fp32 = max_j |bank[j][c]| (the pre-filter's error bound), their sum and their maximum.
 __global__ void __launch_bounds__(256) k_bank_pack(const float *__restrict__ bank, int n_items, uint4 *__restrict__ packed, int n_out) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n_out) return;
@@ -546,7 +548,14 @@ __global__ void __launch_bounds__(1024) k_bank_wmax(const float *__restrict__ ba
     }
 }
 
-extern "C" size_t hvpr_memory_bank_packed_floats(int n_items) { return n_items < 1 ? 0 : (size_t)hvpr_cdiv(n_items, 16) * 512 + kC; }
+// wmax[64] = sum_c wmax[c], wmax[65] = max_c wmax[c]: the same for every pillar, so not the read-out's work
+__global__ void __launch_bounds__(64) k_wmax_stats(float *__restrict__ wmax) {
+    const float wm = wmax[threadIdx.x];
+    const float wsum = hvpr_reduce_sum<64>(wm), wtop = hvpr_reduce<64>(wm, op_maxr());
+    if (threadIdx.x == 0) { wmax[kC] = wsum; wmax[kC + 1] = wtop; }
+}
+
+extern "C" size_t hvpr_memory_bank_packed_floats(int n_items) { return n_items < 1 ? 0 : (size_t)hvpr_cdiv(n_items, 16) * 512 + 2 * kC; }
 
 extern "C" int hvpr_memory_bank_pack_f32(const float *bank, int n_items, float *packed, hvpr_stream_t stream) {
     if (!bank || !packed || n_items < 1) return HVPR_ERR_INVALID_ARG;
@@ -556,6 +565,7 @@ extern "C" int hvpr_memory_bank_pack_f32(const float *bank, int n_items, float *
     hipLaunchKernelGGL(k_wmax_zero, dim3(1), dim3(kC), 0, (hipStream_t)stream, wmax);
     const int wg = n_items <= 2048 ? 1 : (n_items < 128 * 128 ? hvpr_cdiv(n_items, 128) : 128);   // >= 8 items per wave slot
     hipLaunchKernelGGL(k_bank_wmax, dim3(wg), dim3(1024), 0, (hipStream_t)stream, bank, n_items, wmax);
+    hipLaunchKernelGGL(k_wmax_stats, dim3(1), dim3(kC), 0, (hipStream_t)stream, wmax);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }

@@ -334,16 +334,28 @@ __global__ void __launch_bounds__(256) k_memtrain_bwd_items(const float *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) { p[r] = 0.f; d[r] = 0.f; }
 #pragma unroll
-            for (int kk = 0; kk < kC / 2; ++kk) {
-                const float wv = s_w[item_l * kXP + 2 * kk + half];
-                p = __builtin_amdgcn_mfma_f32_32x32x2f32(s_x[(rb * 32 + l31) * kXP + 2 * kk + half], wv, p, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(s_dy[(rb * 32 + l31) * kXP + 2 * kk + half], wv, d, 0, 0, 0);
-            }
-            // C/D map: column (item) = l31, row (row of x) = (r & 3) + 8 (r >> 2) + 4 half.   p -> cx, d -> cy
+            for (int kk = 0; kk < kC / 2; ++kk)
+                p = __builtin_amdgcn_mfma_f32_32x32x2f32(s_x[(rb * 32 + l31) * kXP + 2 * kk + half], s_w[item_l * kXP + 2 * kk + half], p, 0, 0, 0);
+            // C/D map: column (item) = l31, row (row of x) = (r & 3) + 8 (r >> 2) + 4 half.   p -> a
+            bool hit = false;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float a = item_ok ? expf(p[r] - s_mx[rr]) * s_iz[rr] : 0.f;
+                p[r] = item_ok ? expf(p[r] - s_mx[rr]) * s_iz[rr] : 0.f;
+                hit |= p[r] > lambd;
+            }
+            // the support {a > lambda} is a handful of items per row, usually the same few: most 32 x 32 tiles have none, and
+            // for those dt = dy W^T and the product CY . dy (cy = t = 0 outside the support) are not needed at all
+            const bool any = __ballot(hit) != 0ull;             // wave-uniform
+            if (any) {
+#pragma unroll
+                for (int kk = 0; kk < kC / 2; ++kk)
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(s_dy[(rb * 32 + l31) * kXP + 2 * kk + half], s_w[item_l * kXP + 2 * kk + half], d, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float a = p[r];
                 float cx = -a * s_c[rr], cy = 0.f;
                 if (a > lambd) {
                     const float in = s_in[rr];
@@ -353,14 +365,20 @@ __global__ void __launch_bounds__(256) k_memtrain_bwd_items(const float *__restr
                 p[r] = cx; d[r] = cy;
             }
             // dw[item][ch] += sum_rows CX[item][row] x[row][ch] + CY[item][row] dy[row][ch]: A[i = item = l31][k = half] = the
-            // coefficient register (rows rho(r), rho(r) + 4), B[k = half][j = ch = l31] = x / dy [row rho(r) + 4 half][ch]
+            // coefficient register (rows rho(r), rho(r) + 4), B[k = half][j = ch = l31] = x / dy [row rho(r) + 4 half][ch].
+            // (Adding the CY products of a tile without support would add exact zeros: skipping them changes no bit.)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    dw[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], s_x[rr * kXP + b * 32 + l31], dw[b], 0, 0, 0);
-                    dw[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[r], s_dy[rr * kXP + b * 32 + l31], dw[b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) dw[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], s_x[rr * kXP + b * 32 + l31], dw[b], 0, 0, 0);
+            }
+            if (any) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) dw[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[r], s_dy[rr * kXP + b * 32 + l31], dw[b], 0, 0, 0);
                 }
             }
         }

@@ -122,13 +122,17 @@ __device__ __forceinline__ void wg_reduce_store(float *s_row, float *__restrict_
     for (int i = threadIdx.x; i < K; i += kThreads) part[(size_t)blockIdx.x * kMaxRow + i] = s_row[i];
 }
 
-// sums[i] = sum over the workgroup rows, in row order, in double
-__global__ void __launch_bounds__(256) k_vfe_reduce_rows(const float *__restrict__ part, int K, double *__restrict__ sums) {
+// sums[i] = sum over the workgroup rows, in row order, in double; sums[-1] = the element count; local[i] = a copy of the first
+// n_local sums (what stays per-rank when the SyncBatchNorm hook replaces the front of `sums` by the sums over all ranks)
+__global__ void __launch_bounds__(256) k_vfe_reduce_rows(const float *__restrict__ part, int K, double count, double *__restrict__ sums,
+                                                         int n_local, double *__restrict__ local) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) sums[-1] = count;
     if (i >= K) return;
     double a = 0.0;
     for (int h = 0; h < kBlocks; ++h) a += (double)part[(size_t)h * kMaxRow + i];
     sums[i] = a;
+    if (i < n_local) local[i] = a;
 }
 
 // MODE 0: statistics of y0.  MODE 1: statistics of y1.  MODE 2: out [M, 64].
@@ -188,11 +192,12 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_fwd(const float4 *__rest
 }
 
 // one workgroup: per-channel mean / biased variance / inv-std of a layer from the partial rows; folded scale / shift
-__global__ void __launch_bounds__(256) k_vfe_fin_stats(const double *__restrict__ sums, int C, double count, float eps,
+__global__ void __launch_bounds__(256) k_vfe_fin_stats(const double *__restrict__ sums, int C, float eps,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta, int layer,
                                                        Scratch *__restrict__ s, float *__restrict__ mean_out, float *__restrict__ var_out) {
     const int c = threadIdx.x;
     if (c >= C) return;
+    const double count = sums[-1];          // (of the global batch after the hook)
     const double a = sums[c], b = sums[C + c];
     const double mu = a / count;
     double var = b / count - mu * mu;
@@ -278,15 +283,19 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd1(const float4 *__res
 }
 
 // one workgroup: finish layer 1 — dbeta1, dgamma1, dW1 and the Q, w of the dense part of g_x1
-__global__ void __launch_bounds__(256) k_vfe_fin_bwd1(const double *__restrict__ sh, double count, const float *__restrict__ w1,
+// (sh[-1] = count, db / dg: of the global batch when the SyncBatchNorm hook ran; gw, s1, S1 and `local` (db, dg): this rank's —
+// the dense term of dW1 multiplies the GLOBAL dbeta / dgamma / N with the moments of the LOCAL slots, the parameter gradients
+// dbeta1 / dgamma1 are the local sums)
+__global__ void __launch_bounds__(256) k_vfe_fin_bwd1(const double *__restrict__ sh, const double *__restrict__ local, const float *__restrict__ w1,
                                                       const float *__restrict__ gamma1, Scratch *__restrict__ s,
                                                       float *__restrict__ dw1, float *__restrict__ dgamma1, float *__restrict__ dbeta1) {
     __shared__ double coef_q[C1], coef_w[C1];
+    const double count = sh[-1];
     const double *db = sh, *dg = sh + C1, *gw = sh + 2 * C1, *s1 = sh + 2 * C1 + C1 * K1, *S1 = s1 + K1;
     if (threadIdx.x < C1) {
         const int c = threadIdx.x;
         const double c1 = (double)gamma1[c] * (double)s->inv1[c];
-        dbeta1[c] = (float)db[c]; dgamma1[c] = (float)dg[c];
+        dbeta1[c] = (float)local[c]; dgamma1[c] = (float)local[C1 + c];
         s->dbeta1[c] = (float)db[c]; s->dgamma1[c] = (float)dg[c];
         coef_q[c] = c1 * (double)s->inv1[c] * dg[c] / count;
         coef_w[c] = c1 * (db[c] - (double)s->mu1[c] * (double)s->inv1[c] * dg[c]) / count;
@@ -410,11 +419,12 @@ __global__ void __launch_bounds__(kThreads) k_vfe_train_bwd0(const float4 *__res
 }
 
 // one workgroup: finish layer 0 — dbeta0, dgamma0, dW0
-__global__ void __launch_bounds__(256) k_vfe_fin_bwd0(const double *__restrict__ sh, double count, const float *__restrict__ w0,
+__global__ void __launch_bounds__(256) k_vfe_fin_bwd0(const double *__restrict__ sh, const double *__restrict__ local, const float *__restrict__ w0,
                                                       const float *__restrict__ gamma0, const Scratch *__restrict__ s,
                                                       float *__restrict__ dw0, float *__restrict__ dgamma0, float *__restrict__ dbeta0) {
+    const double count = sh[-1];
     const double *db = sh, *dg = sh + C0, *gw = sh + 2 * C0, *s0 = gw + C0 * CIN, *S0 = s0 + CIN;
-    if (threadIdx.x < C0) { dbeta0[threadIdx.x] = (float)db[threadIdx.x]; dgamma0[threadIdx.x] = (float)dg[threadIdx.x]; }
+    if (threadIdx.x < C0) { dbeta0[threadIdx.x] = (float)local[threadIdx.x]; dgamma0[threadIdx.x] = (float)local[C0 + threadIdx.x]; }
     if (threadIdx.x < C0 * CIN) {
         const int c = threadIdx.x / CIN, k = threadIdx.x % CIN;
         const double c0 = (double)gamma0[c] * (double)s->inv0[c];
@@ -425,8 +435,8 @@ __global__ void __launch_bounds__(256) k_vfe_fin_bwd0(const double *__restrict__
     }
 }
 
-// workspace: [kBlocks][kMaxRow] partial rows (f32) | [kMaxRow] reduced sums (f64) | Scratch
-constexpr size_t kPartBytes = (size_t)kBlocks * kMaxRow * sizeof(float), kSumBytes = (size_t)kMaxRow * sizeof(double);
+// workspace: [kBlocks][kMaxRow] partial rows (f32) | count, [kMaxRow] reduced sums, [2 * C1] per-rank copy (f64) | Scratch
+constexpr size_t kPartBytes = (size_t)kBlocks * kMaxRow * sizeof(float), kSumBytes = (size_t)(2 + kMaxRow + 2 * C1) * sizeof(double);
 size_t ws_bytes() { return kPartBytes + kSumBytes + sizeof(Scratch) + 256; }
 
 }  // namespace
@@ -438,17 +448,19 @@ static int vfe_train_forward(const float *voxels, const int32_t *num_points, con
                              const float *gamma0, const float *beta0, const float *w1, const float *gamma1, const float *beta1, float eps,
                              Geom g, float *out, float *mean0, float *var0, float *mean1, float *var1, void *workspace, hipStream_t s) {
     float *part = (float *)workspace;
-    double *sums = (double *)((char *)workspace + kPartBytes);
+    double *sums = (double *)((char *)workspace + kPartBytes) + 2;          // sums[-1]: the count
     Scratch *sc = (Scratch *)((char *)workspace + kPartBytes + kSumBytes);
     const double count = (double)M * PS;
     hipLaunchKernelGGL(k_vfe_train_fwd<0>, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords, M, PS, g,
                        w0, w1, sc, part, nullptr);
-    hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kF1, 256)), dim3(256), 0, s, part, kF1, sums);
-    hipLaunchKernelGGL(k_vfe_fin_stats, dim3(1), dim3(256), 0, s, sums, C0, count, eps, gamma0, beta0, 0, sc, mean0, var0);
+    hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kF1, 256)), dim3(256), 0, s, part, kF1, count, sums, 0, nullptr);
+    if (hvpr_i_bn_allreduce(sums - 1, 1 + kF1, s) != 0) return -1;          // SyncBatchNorm: count, sum y0, sum y0^2 over all ranks
+    hipLaunchKernelGGL(k_vfe_fin_stats, dim3(1), dim3(256), 0, s, (const double *)sums, C0, eps, gamma0, beta0, 0, sc, mean0, var0);
     hipLaunchKernelGGL(k_vfe_train_fwd<1>, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords, M, PS, g,
                        w0, w1, sc, part, nullptr);
-    hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kF2, 256)), dim3(256), 0, s, part, kF2, sums);
-    hipLaunchKernelGGL(k_vfe_fin_stats, dim3(1), dim3(256), 0, s, sums, C1, count, eps, gamma1, beta1, 1, sc, mean1, var1);
+    hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kF2, 256)), dim3(256), 0, s, part, kF2, count, sums, 0, nullptr);
+    if (hvpr_i_bn_allreduce(sums - 1, 1 + kF2, s) != 0) return -1;
+    hipLaunchKernelGGL(k_vfe_fin_stats, dim3(1), dim3(256), 0, s, (const double *)sums, C1, eps, gamma1, beta1, 1, sc, mean1, var1);
     if (out)
         hipLaunchKernelGGL(k_vfe_train_fwd<2>, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords, M,
                            PS, g, w0, w1, sc, part, out);
@@ -485,7 +497,7 @@ extern "C" int hvpr_pillar_vfe_bwd_f32(const float *voxels, const int32_t *num_p
     const Geom g = {vs_x, vs_y, vs_z, off_x, off_y, off_z};
     hipStream_t s = (hipStream_t)stream;
     float *part = (float *)workspace;
-    double *sums = (double *)((char *)workspace + kPartBytes);
+    double *sums = (double *)((char *)workspace + kPartBytes) + 2, *local = sums + kMaxRow;
     Scratch *sc = (Scratch *)((char *)workspace + kPartBytes + kSumBytes);
     // the batch statistics are recomputed (two passes) instead of being trusted from a caller: the workspace carries no state
     // between calls, and the dgamma1 / dbeta1 outputs serve as the throw-away mean / variance destinations until they are written
@@ -495,12 +507,14 @@ extern "C" int hvpr_pillar_vfe_bwd_f32(const float *voxels, const int32_t *num_p
     const double count = (double)M * P_;
     hipLaunchKernelGGL(k_vfe_train_bwd1, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords,
                        (long long)M, P_, g, w0, w1, sc, d_pillar_features, part);
-    hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kB1, 256)), dim3(256), 0, s, part, kB1, sums);
-    hipLaunchKernelGGL(k_vfe_fin_bwd1, dim3(1), dim3(256), 0, s, sums, count, w1, gamma1, sc, dw1, dgamma1, dbeta1);
+    hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kB1, 256)), dim3(256), 0, s, part, kB1, count, sums, 2 * C1, local);
+    if (hvpr_i_bn_allreduce(sums - 1, 1 + 2 * C1, s) != 0) return HVPR_ERR_LAUNCH;     // count, dbeta1, dgamma1 over all ranks
+    hipLaunchKernelGGL(k_vfe_fin_bwd1, dim3(1), dim3(256), 0, s, (const double *)sums, (const double *)local, w1, gamma1, sc, dw1, dgamma1, dbeta1);
     hipLaunchKernelGGL(k_vfe_train_bwd0, dim3(kBlocks), dim3(kThreads), 0, s, (const float4 *)voxels, num_points, (const int4 *)coords,
                        (long long)M, P_, g, w0, w1, gamma1, sc, d_pillar_features, part);
-    hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kB2, 256)), dim3(256), 0, s, part, kB2, sums);
-    hipLaunchKernelGGL(k_vfe_fin_bwd0, dim3(1), dim3(256), 0, s, sums, count, w0, gamma0, sc, dw0, dgamma0, dbeta0);
+    hipLaunchKernelGGL(k_vfe_reduce_rows, dim3(hvpr_cdiv(kB2, 256)), dim3(256), 0, s, part, kB2, count, sums, 2 * C0, local);
+    if (hvpr_i_bn_allreduce(sums - 1, 1 + 2 * C0, s) != 0) return HVPR_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_vfe_fin_bwd0, dim3(1), dim3(256), 0, s, (const double *)sums, (const double *)local, w0, gamma0, sc, dw0, dgamma0, dbeta0);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }

@@ -130,9 +130,11 @@ def finalize():
 
 def convert_sync_batchnorm(model, process_group=None):
     """The counterpart of `torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` (reference tools/train.py:119-120, --sync_bn) for
-    this path: its BatchNorms run the library's own kernels, so there is no module to swap — the batch statistics of
-    conv_train.bn_relu / sfm_step (backbone, head, point-stream MLPs, VFE scale stream) are all-reduced over `process_group`
-    (default group when None) from now on.  Returns the model unchanged; call before wrap_ddp."""
+    this path: its BatchNorms run the library's own kernels, so there is no module to swap — from now on the batch statistics of
+    EVERY train-mode BatchNorm of the model are those of the global batch: conv_train.bn_relu / sfm_step (backbone, head,
+    point-stream MLPs, VFE scale stream) all-reduce their per-rank sums over `process_group` (default group when None); the two
+    BatchNorm1d inside the fused PFN kernels and SpatialAttention's BatchNorm reach the same all-reduce through the library's hook
+    (hvpr_set_batchnorm_allreduce).  Returns the model unchanged; call before wrap_ddp."""
     from . import conv_train
     conv_train.set_sync_batchnorm(process_group if process_group is not None else True)
     return model

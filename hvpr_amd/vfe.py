@@ -150,7 +150,10 @@ def _update_running(bn, mean, var, n):
         bn.num_batches_tracked += 1
         mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-        bn.running_var.mul_(1 - mom).add_(var, alpha=mom * n / max(n - 1, 1))
+        if torch.is_tensor(n):              # SyncBatchNorm: the global count, a device scalar
+            bn.running_var.mul_(1 - mom).add_(var * (n / (n - 1).clamp_min(1.0)).to(var.dtype) * mom)
+        else:
+            bn.running_var.mul_(1 - mom).add_(var, alpha=mom * n / max(n - 1, 1))
 
 
 def _train_forward(self, batch_dict, voxels, num, coords):
@@ -182,11 +185,12 @@ def _train_forward(self, batch_dict, voxels, num, coords):
     x, m0, v0, m1, v1 = _PfnTrain.apply(voxels.contiguous(), _as_i32(num).contiguous(), _as_i32(coords).contiguous(),
                                         l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight,
                                         l1.norm.bias, l0.norm.eps, self.voxel_size, self.offsets)
-    _update_running(l0.norm, m0, v0, M * P)
-    _update_running(l1.norm, m1, v1, M * P)
+    from . import conv_train as ct
+    cnt = ct.global_count(M * P, voxels.device)
+    _update_running(l0.norm, m0, v0, cnt)
+    _update_running(l1.norm, m1, v1, cnt)
     # scale stream (pillar_vfe.py:213-216): [n, |mean|, mean] (5 columns, zero-padded to the convolution kernel's 8) through
     # Linear (no bias) + train-mode BatchNorm1d + ReLU twice, as 1x1 convolutions over the M rows on the library's kernels
-    from . import conv_train as ct
     s = torch.cat([n.unsqueeze(1), torch.norm(mean, 2, 2), mean.squeeze(1), mean.new_zeros((M, 3))], dim=-1)
     t = s.view(1, 1, M, 8)
     for seq in self.pfn_scale_layers:

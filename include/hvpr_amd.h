@@ -37,6 +37,19 @@ enum hvpr_status {
 int hvpr_abi_version(void);
 const char *hvpr_status_string(int status);
 
+/* SyncBatchNorm across ranks (reference: tools/train.py:119-120, --sync_bn -> torch.nn.SyncBatchNorm).  The training entry points
+ * that hold a whole BatchNorm inside ONE call — hvpr_pillar_vfe_train_fwd_f32 / hvpr_pillar_vfe_bwd_f32 (two BatchNorm1d) and
+ * hvpr_spatial_gate_train_fwd_f32 / _bwd_f32 (one BatchNorm2d) — hand their per-rank sums to this hook between two of their
+ * launches: fn must replace buf[0..n) (device doubles; buf[0] is the element count, then sum x, sum x^2 forward or sum dy,
+ * sum dy xhat backward) by the sum over all ranks, enqueued so that work submitted to `stream` afterwards sees the result; it
+ * returns 0 on success (anything else makes the entry point return HVPR_ERR_LAUNCH).  With the hook set the statistics, and the
+ * input gradient, are those of the global batch; parameter gradients stay per-rank sums (the data-parallel wrapper reduces them),
+ * as in torch.nn.SyncBatchNorm.  fn == NULL (the default) restores per-rank statistics.  This one pointer pair is the only state
+ * the library keeps between calls; set it before the first training call, from one thread.
+ * (The BatchNorms of hvpr_bn_* take the other route: their sums / apply halves are separate entry points.) */
+typedef int (*hvpr_allreduce_fn)(double *buf, int n, hvpr_stream_t stream, void *ctx);
+void hvpr_set_batchnorm_allreduce(hvpr_allreduce_fn fn, void *ctx);
+
 /* ---------------------------------------------------------------------------------------------
  * a1  Voxelizer.  Replaces spconv.utils.VoxelGenerator[V2].generate as called from
  *     pcdet/datasets/processor/data_processor.py:43-75 (CPU dataloader in the reference).
@@ -122,7 +135,7 @@ int hvpr_pillar_vfe_bwd_f32(const float *voxels, const int32_t *num_points, cons
  *     fp32 from `bank` (logit = butterfly-tree sum of the 64 fp32 products), so the selected ids are the exact fp32 top-k
  *     (value descending, id ascending on ties); the k selected rows are read from `bank` too.
  * ------------------------------------------------------------------------------------------- */
-size_t hvpr_memory_bank_packed_floats(int n_items);   /* size of the packed copy in floats: ceil(n_items/16) * 512 + 64 */
+size_t hvpr_memory_bank_packed_floats(int n_items);   /* size of the packed copy in floats: ceil(n_items/16) * 512 + 128 */
 int hvpr_memory_bank_pack_f32(const float *bank, int n_items, float *packed, hvpr_stream_t stream);
 int hvpr_memory_readout_fwd_f32(const float *f, int M, const int32_t *m_device, const float *bank, const float *bank_packed,
                                 int n_items, int k, float *out, int32_t *topk_idx, hvpr_stream_t stream);

@@ -67,3 +67,6 @@ def test_sync_batchnorm_path_on_one_rank_rccl(tmp_path):
     assert r["backend"] == "nccl" and r["world"] == 1
     for k, v in r["rel"].items():
         assert v <= 2e-6, (k, v)
+    # SpatialAttention's BatchNorm went through the library's hook (hvpr_set_batchnorm_allreduce): one call forward, one backward; the
+    # N > 1 arithmetic of the hooked kernels is covered by the emulated two-rank tests of tests/test_gpu_train_ops.py
+    assert r["hook_calls"] == 2, r["hook_calls"]

@@ -403,3 +403,136 @@ def test_scattering_gradients_are_reproducible_and_match_float64():
     assert torch.equal(outs[0], outs[1])
     ref = torch.zeros(500, 64, dtype=torch.float64, device=DEV).index_add_(0, pick.view(-1), gout.double().view(-1, 64))
     torch.testing.assert_close(outs[0].double(), ref, rtol=1e-5, atol=1e-5)
+
+
+class _TwoRankReplay:
+    """SyncBatchNorm hook for ONE GPU: the two 'ranks' run one after the other, round after round; every hook call records the
+    rank's own buffer and adds what the OTHER rank recorded at the same call index in the previous round.  Call i is right once
+    calls 0..i-1 were, so after (number of hook calls per step) + 1 rounds both ranks see exactly what a lock-step all-reduce
+    would have given them."""
+
+    def __init__(self):
+        from hvpr_amd._lib import ALLREDUCE_FN, lib
+        self.prev, self.cur, self.rank, self.calls = {0: [], 1: []}, {0: [], 1: []}, 0, 0
+        self.fn = ALLREDUCE_FN(self)
+        lib().hvpr_set_batchnorm_allreduce(self.fn, None)
+
+    def __call__(self, buf, n, stream, ctx):
+        from hvpr_amd import conv_train as ct
+        t = ct.device_doubles(buf, n)
+        i = len(self.cur[self.rank])
+        self.cur[self.rank].append(t.clone())
+        other = self.prev[1 - self.rank]
+        if i < len(other):
+            assert other[i].numel() == n
+            t += other[i]
+        self.calls += 1
+        return 0
+
+    def next_round(self):
+        self.prev, self.cur = self.cur, {0: [], 1: []}
+
+    def close(self):
+        from hvpr_amd._lib import lib
+        lib().hvpr_set_batchnorm_allreduce(None, None)
+
+
+def test_sync_batchnorm_hook_pfn_two_emulated_ranks_equal_the_joint_batch():
+    """hvpr_set_batchnorm_allreduce on the fused PFN kernels (two BatchNorm1d inside one call, forward and backward): two ranks
+    with 700 / 301 pillars, emulated on one GPU (_TwoRankReplay), against ONE process holding all 1001 pillars — features equal,
+    parameter gradients add up to the joint ones (what DDP's mean x world size gives), batch means equal."""
+    import copy
+    from hvpr_amd import vfe as V
+    from hvpr_amd.config import hvpr_car_cfg
+    cfg = hvpr_car_cfg()
+    g = torch.Generator().manual_seed(5)
+    M, MA, P = 1001, 700, 32
+    base = V.PillarVFE_Scale(cfg.MODEL.VFE, 4, [0.16, 0.16, 3], [0, -19.84, -2.5, 47.36, 19.84, 0.5]).train()
+    with torch.no_grad():
+        for layer in base.pfn_layers:
+            layer.norm.weight.copy_(torch.rand(layer.norm.weight.shape, generator=g) + 0.5)
+            layer.norm.bias.copy_(torch.randn(layer.norm.bias.shape, generator=g) * 0.3)
+    num = torch.randint(1, 9, (M,), generator=g)
+    num[0] = P
+    coords = torch.stack([torch.zeros(M, dtype=torch.long), torch.zeros(M, dtype=torch.long),
+                          torch.randint(0, 248, (M,), generator=g), torch.randint(0, 296, (M,), generator=g)], dim=1).int()
+    vox = torch.rand(M, P, 4, generator=g) * torch.tensor([47.0, 39.0, 3.0, 1.0]) + torch.tensor([0.0, -19.5, -2.5, 0.0])
+    vox = vox * (torch.arange(P).view(1, -1, 1) < num.view(-1, 1, 1))
+    dfeat = torch.randn(M, 64, generator=g)
+
+    def run(m, sl):
+        m.zero_grad()
+        bd = {"voxels": vox[sl].to(DEV), "voxel_num_points": num[sl].to(DEV).int(), "voxel_coords": coords[sl].to(DEV)}
+        out = m(bd)["pillar_features"]
+        (out * dfeat[sl].to(DEV)).sum().backward()
+        return out.detach()
+
+    joint = copy.deepcopy(base).to(DEV)
+    o_joint = run(joint, slice(0, M))
+    parts = (slice(0, MA), slice(MA, M))
+    hook = _TwoRankReplay()
+    try:
+        for rnd in range(7):                      # 2 hook calls forward + 4 backward (the backward recomputes the statistics)
+            mods = [copy.deepcopy(base).to(DEV) for _ in range(2)]
+            outs = []
+            for r in range(2):
+                hook.rank = r
+                outs.append(run(mods[r], parts[r]))
+            assert len(hook.cur[0]) == 6 and len(hook.cur[1]) == 6
+            hook.next_round()
+    finally:
+        hook.close()
+    scale = float(o_joint.abs().max())
+    assert float((torch.cat(outs) - o_joint).abs().max()) < 2e-6 * scale
+    for (name, pj), (_, pa), (_, pb) in zip(joint.named_parameters(), mods[0].named_parameters(), mods[1].named_parameters()):
+        if "pfn_layers" not in name:
+            continue
+        gj, gs = pj.grad.double(), pa.grad.double() + pb.grad.double()
+        assert float((gs - gj).abs().max()) < 2e-5 * max(float(gj.abs().max()), 1e-6), name
+    for lj, la, lb in zip(joint.pfn_layers, mods[0].pfn_layers, mods[1].pfn_layers):
+        assert torch.equal(la.norm.running_mean, lb.norm.running_mean)
+        assert float((la.norm.running_mean - lj.norm.running_mean).abs().max()) < 1e-7
+    # and per-rank statistics without the hook are NOT the joint ones (the test would pass vacuously otherwise)
+    alone = run(copy.deepcopy(base).to(DEV), parts[0])
+    assert float((alone - o_joint[:MA]).abs().max()) > 1e-4 * scale
+
+
+def test_sync_batchnorm_hook_spatial_gate_two_emulated_ranks_equal_the_joint_batch():
+    """The same for SpatialAttention's one-channel BatchNorm (hvpr_spatial_gate_train_fwd/bwd_f32): frames 0 and 1 on two emulated
+    ranks against both frames in one process — gate and dy equal, parameter gradients add up."""
+    from hvpr_amd import conv_train as ct
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = 2, 40, 48, 32
+    y = torch.relu(torch.randn(N, H, W, C, generator=g) * torch.tensor([1.0, 2.5]).view(2, 1, 1, 1)).to(DEV)
+    w = (torch.randn(1, 2, 3, 3, generator=g) * 0.4).to(DEV)
+    b, gamma, beta = torch.tensor([0.3], device=DEV), torch.tensor([1.3], device=DEV), torch.tensor([-0.2], device=DEV)
+    dg = torch.randn(N, H, W, 1, generator=g).to(DEV)
+
+    def run(sl):
+        leaves = [t.clone().requires_grad_(True) for t in (y[sl], w, b, gamma, beta)]
+        gate, mean, var = ct.spatial_gate_train(*leaves, 1e-3)
+        grads = torch.autograd.grad(gate, leaves, dg[sl])
+        return gate.detach(), mean, var, grads
+
+    gate_j, mean_j, var_j, grads_j = run(slice(0, 2))
+    hook = _TwoRankReplay()
+    try:
+        for rnd in range(3):
+            res = []
+            for r in range(2):
+                hook.rank = r
+                res.append(run(slice(r, r + 1)))
+            hook.next_round()
+    finally:
+        hook.close()
+    assert float((torch.cat([res[0][0], res[1][0]]) - gate_j).abs().max()) < 1e-6
+    for r in range(2):
+        np.testing.assert_allclose(float(res[r][1]), float(mean_j), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(float(res[r][2]), float(var_j), rtol=1e-6)
+    dy = torch.cat([res[0][3][0], res[1][3][0]])
+    assert float((dy - grads_j[0]).abs().max()) < 2e-6 * float(grads_j[0].abs().max())
+    for k, what in ((1, "dw"), (3, "dgamma"), (4, "dbeta")):
+        s = res[0][3][k].double() + res[1][3][k].double()
+        assert float((s - grads_j[k].double()).abs().max()) < 2e-5 * float(grads_j[k].abs().max()), what
+    alone = run(slice(0, 1))
+    assert float((alone[0] - gate_j[:1]).abs().max()) > 1e-3
