@@ -315,7 +315,7 @@ class _BNReLU(torch.autograd.Function):
                                               y.data_ptr(), kernels._stream()), "hvpr_bn_relu_fwd_nhwc_f32")
         ctx.save_for_backward(z, scale, shift, mean, invstd, gate)
         ctx.relu, ctx.count = relu, count
-        cnt = count if torch.is_tensor(count) else mean.new_tensor(float(count), dtype=torch.float64)
+        cnt = count if torch.is_tensor(count) else torch.tensor(float(count), dtype=torch.float64)      # (a HOST tensor: no copy to the device, no sync)
         ctx.mark_non_differentiable(mean, var, cnt)
         return y, mean, var, cnt
 
@@ -362,7 +362,7 @@ class _SfmStep(torch.autograd.Function):
                                               y.data_ptr(), kernels._stream()), "hvpr_bn_relu_fwd_nhwc_f32")
         ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gate)
         ctx.count = count
-        cnt = count if torch.is_tensor(count) else mean.new_tensor(float(count), dtype=torch.float64)
+        cnt = count if torch.is_tensor(count) else torch.tensor(float(count), dtype=torch.float64)      # (a HOST tensor: no copy to the device, no sync)
         ctx.mark_non_differentiable(mean, var, cnt)
         return y, mean, var, cnt
 

@@ -47,6 +47,18 @@ def direction_targets(anchors, reg_targets, dir_offset, num_bins):
     return F.one_hot(bins, num_bins).to(anchors.dtype)
 
 
+_code_w_cache = {}
+
+
+def _code_weights(values, dtype, device):
+    """The code weights as a device tensor, built once per (values, dtype, device): torch.tensor(list, device=...) is a synchronising
+    host copy, and this sits in every training step."""
+    key = (tuple(float(v) for v in values), dtype, device)
+    if key not in _code_w_cache:
+        _code_w_cache[key] = torch.tensor(list(key[0]), dtype=dtype, device=device)
+    return _code_w_cache[key]
+
+
 def rpn_losses(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, num_class, num_anchors_per_loc, cfg_weights,
                dir_offset, num_dir_bins):
     """Losses of ONE prediction stream.  cls/box/dir preds are NHWC head outputs; labels (B,A) i32, reg_targets (B,A,7).
@@ -64,7 +76,7 @@ def rpn_losses(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, nu
     cls_loss = sigmoid_focal_loss(cls_preds.reshape(B, -1, num_class), one_hot, cls_w).sum() / B * cfg_weights["cls_weight"]
 
     bp = box_preds.reshape(B, -1, box_preds.shape[-1] // num_anchors_per_loc)
-    code_w = torch.tensor(cfg_weights["code_weights"], dtype=bp.dtype, device=bp.device)
+    code_w = _code_weights(cfg_weights["code_weights"], bp.dtype, bp.device)
     bp_sin, tg_sin = add_sin_difference(bp, reg_targets)
     loc_loss = weighted_smooth_l1(bp_sin, tg_sin, reg_w, code_w).sum() / B * cfg_weights["loc_weight"]
     parts = {"cls": cls_loss, "loc": loc_loss}

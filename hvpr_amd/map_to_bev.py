@@ -198,6 +198,30 @@ class PointPillarScatter(_ScatterBase):
         return batch_dict
 
 
+def _frame_ranges(cols, B):
+    """For every batch-index column of `cols`: [(lo, hi)] * B if its rows are grouped by frame in ascending order (frame b = rows
+    lo .. hi), else None.  One device -> host read for all columns."""
+    parts = []
+    for c in cols:
+        c = c.long()
+        ok = ((c[1:] >= c[:-1]).sum() == max(c.numel() - 1, 0)) & ((c >= 0) & (c < B)).sum().eq(c.numel())
+        cnt = (c.view(-1, 1) == torch.arange(B, device=c.device).view(1, -1)).sum(dim=0)      # (torch.bincount reads its size on the host)
+        parts += [cnt, ok.view(1).long()]
+    host = torch.cat(parts).tolist()
+    out = []
+    for i in range(len(cols)):
+        cnt, ok = host[i * (B + 1):i * (B + 1) + B], host[i * (B + 1) + B]
+        if not ok:
+            out.append(None)
+            continue
+        lo, r = 0, []
+        for n in cnt:
+            r.append((lo, lo + n))
+            lo += n
+        out.append(r)
+    return out
+
+
 class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
     """Scatter with memory read-out and scale canvas — pointpillar_scatter.py:39-222 (eval branch :169-222)."""
 
@@ -254,10 +278,14 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
         point_f, point_c = batch_dict["point_features"], batch_dict["point_coords"]
         B = _batch_size(batch_dict)
         pos_point, pos_mem = [], []
+        # rows of one frame: a slice when the rows are grouped by frame (what the voxelizer, the point stream and the reference's
+        # collate produce) — ONE host read for all frames and both tensors; a boolean mask per frame is a host sync each, forward
+        # and backward, and a host that cannot run ahead of the device leaves it idle in every launch-bound stretch of the step
+        vr, pr = _frame_ranges([coords[:, 0], point_c[:, 0]], B)
         for b in range(B):
-            m = coords[:, 0] == b
-            pillars = pf[m]
-            agg, positives = self.get_score(point_f[point_c[:, 0] == b], pillars)
+            pillars = pf[vr[b][0]:vr[b][1]] if vr is not None else pf[coords[:, 0] == b]
+            points = point_f[pr[b][0]:pr[b][1]] if pr is not None else point_f[point_c[:, 0] == b]
+            agg, positives = self.get_score(points, pillars)
             pos_point.append(agg)
             pos_mem.append(self.memory(pillars, self.k, positives)["output"])
         pos_point, pos_mem = torch.cat(pos_point, 0), torch.cat(pos_mem, 0)

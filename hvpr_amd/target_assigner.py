@@ -13,7 +13,7 @@ from .common_utils import limit_period
 def nearest_bev_boxes(boxes):
     """(N,7) -> axis-aligned (x1,y1,x2,y2) after snapping the heading to the nearest axis (box_utils.py:297-308)."""
     rot = limit_period(boxes[:, 6], 0.5, np.pi).abs()
-    dims = torch.where(rot[:, None] < np.pi / 4, boxes[:, [3, 4]], boxes[:, [4, 3]])
+    dims = torch.where(rot[:, None] < np.pi / 4, boxes[:, 3:5], boxes[:, 3:5].flip(1))    # (slices: a python index list is a synchronising host copy)
     return torch.cat((boxes[:, 0:2] - dims / 2, boxes[:, 0:2] + dims / 2), dim=1)
 
 
@@ -63,7 +63,7 @@ class AxisAlignedTargetAssigner:
             for cname, anchors in zip(self.anchor_class_names, all_anchors):
                 fms = anchors.shape[:3]
                 a = anchors.reshape(-1, anchors.shape[-1])
-                name_idx = torch.tensor([self.class_names.index(cname)], device=gt.device)
+                name_idx = self.class_names.index(cname)
                 # python-style class_names[c - 1]: class 0 (a padded row inside the valid range) wraps to the last class
                 same = torch.remainder(gcls - 1, len(self.class_names)) == name_idx
                 lab, tgt, w = self._assign_single(a, gt[:, :-1], gcls, valid & same, self.matched[cname], self.unmatched[cname])

@@ -129,8 +129,8 @@ def test_wino_fused_bn_statistics(N, H, W, cin, cout):
     w = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).to(DEV)
     z, partials = conv_train.conv_fwd_raw(x, w, 1, stats=True)
     assert partials is not None and partials.shape[1:] == (2, cout)
-    mean, var, invstd = conv_train.bn_statistics(z, 1e-3, partials)
-    mean2, var2, invstd2 = conv_train.bn_statistics(z, 1e-3)                 # the separate pass over z
+    mean, var, invstd, _ = conv_train.bn_statistics(z, 1e-3, partials)
+    mean2, var2, invstd2, _ = conv_train.bn_statistics(z, 1e-3)               # the separate pass over z
     zd = z.double().reshape(-1, cout)
     np.testing.assert_allclose(mean.cpu().numpy(), zd.mean(0).cpu().numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(var.cpu().numpy(), zd.var(0, unbiased=False).cpu().numpy(), rtol=2e-5, atol=1e-7)
