@@ -528,105 +528,131 @@ __global__ void __launch_bounds__(64) k_nms_sweep(const unsigned long long *__re
 
 // The greedy sweep for n <= 4096 candidates (nb <= 64 mask words per row).  The sweep is serial over the 64-box blocks and
 // needs, per block, the mask rows of the boxes it keeps: read on demand that is one dependent L2 round trip per block
-// (64 x ~3.5 us).  Here one workgroup of 8 waves streams ALL rows through a double-buffered LDS ring, two blocks (128
-// rows x nb words, 64 KB) per phase: waves 1-7 load phase p+1 while wave 0 resolves phase p out of LDS — the resolve
-// never waits for memory.  Same greedy order, same result.
-constexpr int kRingThreads = 512;
-constexpr int kRingBlocks = 2;                       // 64-box blocks per phase
+// (64 x ~3.5 us).  Here one workgroup of 8 waves streams ALL rows through an LDS ring, one block (64 rows x nb words, 32 KB)
+// per phase, and wave 0 resolves phase p out of LDS.  Four of the eight loader waves OWN the phases p = g (mod 2), 16 rows
+// each: they request the rows of their next phase two phases before they are needed and keep them in registers until the
+// ring slot is free — two L2 round trips in flight, the barriers wait for LDS only (rounds 1-3: all loaders fetched phase
+// p + 1 during phase p behind __syncthreads(), whose vmcnt(0) made every phase one round trip long: 71 us; now 59, bound
+// by the ~300 dependent instructions wave 0 spends per block; more loader waves slow that wave down: 13 waves 63 us).  The
+// diagonal words and the candidate ids travel through LDS too (a column read of the ring is a 64-way bank conflict, order[]
+// a dependent global load).  Same greedy order, same result.
+constexpr int kRingThreads = 576;                    // the resolving wave + 8 loaders
+constexpr int kRingOwners = 4;                       // loader waves that share a phase (16 rows each)
+constexpr int kRingDepth = (kRingThreads / 64 - 1) / kRingOwners;     // 2 phases in flight
 constexpr int kRingWords = 64;                       // words per row in LDS (nb <= 64)
+constexpr int kRingPieces = (64 / kRingOwners) * (kRingWords / 2) / 64;   // 16-byte pieces per lane and phase: 8
 
 __global__ void __launch_bounds__(kRingThreads) k_nms_sweep_ring(const unsigned long long *__restrict__ mask, int nb_stride,
                                                                  const int *__restrict__ n_device, int n_max,
                                                                  const int *__restrict__ order, int map_through_order,
                                                                  int max_keep, int *__restrict__ keep, int *__restrict__ keep_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_rows[];   // [2][kRingBlocks * 64][kRingWords]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_rows[];   // [2][64][kRingWords]
     __shared__ int s_done;
+    // per ring slot: the diagonal word of every row (row r of block b, word b: a column of s_rows — 64 lanes on one bank) and the
+    // candidates' ids, so that the resolve reads both without a bank conflict / without a dependent global load
+    __shared__ unsigned long long s_diag[2][64];
+    __shared__ int s_ord[2][64];
     const int n = n_device ? min(*n_device, n_max) : n_max;
     const int nb = (n + 63) / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int phases = (nb + kRingBlocks - 1) / kRingBlocks;
-    constexpr int kPhaseRows = kRingBlocks * 64;
-    // 16-byte pieces: row r of the phase, words 2c, 2c+1
-    auto load_phase = [&](int ph, int first_thread, int n_threads) {
-        unsigned long long *dst = s_rows + (size_t)(ph & 1) * kPhaseRows * kRingWords;
-        constexpr int kPieces = kPhaseRows * (kRingWords / 2);
-        constexpr int kUnroll = (kPieces + (kRingThreads - 64) - 1) / (kRingThreads - 64);   // enough for the 7 loader waves
-        ulonglong2 v[kUnroll];
-        // every load of the phase is issued before the first LDS store: one L2 round trip per phase, not one per piece
+    // a loader lane holds pieces (row 32 * half + 2u + lane / 32, words 2c, 2c + 1 with c = lane % 32), u = 0..15, of its phase
+    ulonglong2 v[kRingPieces];
+    int ord = 0;
+    const bool ord_lane = order && map_through_order && wid != 0 && (wid - 1) % kRingOwners == 0;
+    const int pr = (lane >> 5) + (64 / kRingOwners) * ((wid - 1) % kRingOwners), pc = lane & 31, grp = (wid - 1) / kRingOwners;
+    // global -> registers: 32 UNCONDITIONAL loads back to back, no select on an address or a result (the compiler turns those into
+    // a branch and a wait per load).  What is not wanted is never looked at by the resolve, so it may hold anything: rows past n
+    // (clamped to the last row of the buffer), words left of the diagonal block (the lower triangle; those lanes fetch the
+    // diagonal piece again — same cache line, no extra traffic) and words past nb.
+    const bool even = !(nb_stride & 1);             // 16-byte aligned pieces whose two words both exist
+    auto request = [&](int ph) {
+        const int pcc = max(pc, (ph - 1) >> 1);
+        if (ord_lane) ord = order[min(ph * 64 + lane, n_max - 1)];
+        if (even) {
+            const int col = 2 * min(pcc, (nb_stride >> 1) - 1);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int i = tid - first_thread + u * n_threads;
-            const int r = i / (kRingWords / 2), c = i % (kRingWords / 2);
-            const int row = ph * kPhaseRows + r;
-            v[u] = make_ulonglong2(0ull, 0ull);
-            // words left of the diagonal block are zero (lower triangle) and never looked at again: not fetched — half the
-            // bytes this one workgroup has to pull through its CU
-            if (i < kPieces && row < n && 2 * c < nb_stride && 2 * c + 1 >= (row >> 6)) {
-                const unsigned long long *src = mask + (size_t)row * nb_stride + 2 * c;
-                if (!(nb_stride & 1)) v[u] = *(const ulonglong2 *)src;            // even stride: 16-byte aligned, both words exist
-                else { v[u].x = src[0]; if (2 * c + 1 < nb_stride) v[u].y = src[1]; }
+            for (int u = 0; u < kRingPieces; ++u)
+                v[u] = *(const ulonglong2 *)(mask + (size_t)min(ph * 64 + 2 * u + pr, n_max - 1) * nb_stride + col);
+        } else {
+            const int c0 = min(2 * pcc, nb_stride - 1), c1 = min(2 * pcc + 1, nb_stride - 1);
+#pragma unroll
+            for (int u = 0; u < kRingPieces; ++u) {
+                const size_t base = (size_t)min(ph * 64 + 2 * u + pr, n_max - 1) * nb_stride;
+                v[u].x = mask[base + c0];
+                v[u].y = mask[base + c1];
             }
         }
+    };
+    auto commit = [&](int ph) {         // registers -> ring slot ph & 1
+        unsigned long long *dst = s_rows + (size_t)(ph & 1) * 64 * kRingWords;
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int i = tid - first_thread + u * n_threads;
-            if (i < kPieces) *(ulonglong2 *)(dst + (size_t)(i / (kRingWords / 2)) * kRingWords + 2 * (i % (kRingWords / 2))) = v[u];
+        for (int u = 0; u < kRingPieces; ++u) *(ulonglong2 *)(dst + (size_t)(2 * u + pr) * kRingWords + 2 * pc) = v[u];
+        if (pc == (ph >> 1)) {
+            // (bit masks, not `odd ? v.y : v.x`: the compiler turns that select into a dynamic index and the whole array into scratch)
+            const unsigned long long odd = 0ull - (unsigned long long)(ph & 1);
+#pragma unroll
+            for (int u = 0; u < kRingPieces; ++u) s_diag[ph & 1][2 * u + pr] = (v[u].x & ~odd) | (v[u].y & odd);
         }
+        if (ord_lane) s_ord[ph & 1][lane] = ord;
     };
     if (tid == 0) s_done = 0;
-    load_phase(0, 0, kRingThreads);
-    __syncthreads();
+    if (wid != 0) request(grp);         // phases 0..3
+    if (wid != 0 && grp == 0) { commit(0); request(kRingDepth); }
+    // The barriers of this kernel order LDS traffic only: __syncthreads() would also wait for every outstanding GLOBAL load of the
+    // wave (vmcnt(0)) — exactly the round trip per phase the ring is there to hide.  The loaded registers are guarded by the
+    // compiler's own vmcnt waits at their first use (commit).
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    lds_barrier();
     unsigned long long remv = 0ull;                  // wave 0: lane w owns suppression word w
     int kept = 0;
-    for (int ph = 0; ph < phases; ++ph) {
+    for (int ph = 0; ph < nb; ++ph) {
         if (wid != 0) {
-            if (ph + 1 < phases && !s_done) load_phase(ph + 1, 64, kRingThreads - 64);
+            // the owner of phase ph + 1 hands it over (its slot was read last in phase ph - 1) and requests its next one
+            if ((ph + 1) % kRingDepth == grp && ph + 1 < nb && !s_done) {
+                commit(ph + 1);
+                request(ph + 1 + kRingDepth);
+            }
         } else if (kept < max_keep) {
-            const unsigned long long *rows = s_rows + (size_t)(ph & 1) * kPhaseRows * kRingWords;
-            for (int bb = 0; bb < kRingBlocks && kept < max_keep; ++bb) {
-                const int b = ph * kRingBlocks + bb;
-                if (b >= nb) break;
-                const unsigned long long diag = rows[(size_t)(bb * 64 + lane) * kRingWords + b];   // row `lane` of block b, word b
-                unsigned long long rw;
-                {
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(remv & 0xffffffffull), b);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(remv >> 32), b);
-                    rw = ((unsigned long long)hi << 32) | lo;
-                }
-                const int lim = min(64, n - b * 64);
-                const unsigned long long valid = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
-                unsigned long long kbits = 0ull;
-                unsigned long long avail = ~rw & valid;
-                while (avail && kept < max_keep) {                 // only unsuppressed candidates are visited
-                    const int i = __ffsll((long long)avail) - 1;
-                    kbits |= 1ull << i;
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffull), i);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), i);
-                    rw |= ((unsigned long long)hi << 32) | lo;
-                    ++kept;
-                    avail = ~rw & valid & ~((2ull << i) - 1ull);
-                }
-                const int base = kept - __popcll(kbits);
-                if ((kbits >> lane) & 1ull) {
-                    const int pos = b * 64 + lane;
-                    keep[base + __popcll(kbits & ((1ull << lane) - 1ull))] = (order && map_through_order) ? order[pos] : pos;
-                }
-                // rows of the kept boxes, straight from LDS, four at a time: the reads of a round are issued together (one LDS
-                // latency per round instead of one per kept box — the resolve of a block is what bounds this kernel)
-                for (unsigned long long kb = kbits; kb;) {
-                    unsigned long long t4[4];
+            const unsigned long long *rows = s_rows + (size_t)(ph & 1) * 64 * kRingWords;
+            const int b = ph;
+            const unsigned long long diag = s_diag[ph & 1][lane];                  // row `lane` of block b, word b
+            const int my_id = (order && map_through_order) ? s_ord[ph & 1][lane] : b * 64 + lane;
+            unsigned long long rw;
+            {
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)(remv & 0xffffffffull), b);
+                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(remv >> 32), b);
+                rw = ((unsigned long long)hi << 32) | lo;
+            }
+            const int lim = min(64, n - b * 64);
+            const unsigned long long valid = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
+            unsigned long long kbits = 0ull;
+            unsigned long long avail = ~rw & valid;
+            while (avail && kept < max_keep) {                 // only unsuppressed candidates are visited
+                const int i = __ffsll((long long)avail) - 1;
+                kbits |= 1ull << i;
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffull), i);
+                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), i);
+                rw |= ((unsigned long long)hi << 32) | lo;
+                ++kept;
+                avail = ~rw & valid & ~((2ull << i) - 1ull);
+            }
+            const int base = kept - __popcll(kbits);
+            if ((kbits >> lane) & 1ull) keep[base + __popcll(kbits & ((1ull << lane) - 1ull))] = my_id;
+            // rows of the kept boxes, straight from LDS, four at a time: the reads of a round are issued together (one LDS
+            // latency per round instead of one per kept box)
+            for (unsigned long long kb = kbits; kb;) {
+                unsigned long long t4[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = kb ? __ffsll((long long)kb) - 1 : -1;
-                        kb &= kb - 1ull;
-                        t4[u] = i >= 0 ? rows[(size_t)(bb * 64 + i) * kRingWords + lane] : 0ull;
-                    }
-                    remv |= (t4[0] | t4[1]) | (t4[2] | t4[3]);
+                for (int u = 0; u < 4; ++u) {
+                    const int i = kb ? __ffsll((long long)kb) - 1 : -1;
+                    kb &= kb - 1ull;
+                    t4[u] = i >= 0 ? rows[(size_t)i * kRingWords + lane] : 0ull;
                 }
+                remv |= (t4[0] | t4[1]) | (t4[2] | t4[3]);
             }
             if (kept >= max_keep && lane == 0) s_done = 1;
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (tid == 0) *keep_count = kept;
 }
@@ -684,7 +710,7 @@ extern "C" int hvpr_nms_bev_f32(const float *boxes, int box_stride, const int32_
         hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, s, prepared, n_device, n_max, thresh, mask, nb);
     }
     if (nb <= kRingWords) {
-        const size_t lds = (size_t)2 * kRingBlocks * 64 * kRingWords * sizeof(unsigned long long);
+        const size_t lds = (size_t)2 * 64 * kRingWords * sizeof(unsigned long long);
         static unsigned long long lds_set = 0ull;   // per device
     if (hvpr_ensure_dyn_lds((const void *)k_nms_sweep_ring, (int)lds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
         hipLaunchKernelGGL(k_nms_sweep_ring, dim3(1), dim3(kRingThreads), lds, s, mask, nb, n_device, n_max, order, map_through_order,
