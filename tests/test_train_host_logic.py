@@ -49,3 +49,27 @@ def test_training_modules_refuse_cpu_tensors():
         model.dense_head({"spatial_features_2d": torch.randn(1, 384, 32, 32), "spatial_features_point_2d": torch.randn(1, 384, 32, 32)})
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model.vfe({"voxels": torch.rand(3, 32, 4), "voxel_num_points": torch.tensor([1, 2, 3]), "voxel_coords": torch.zeros(3, 4)})
+
+
+def test_frame_ranges_slices_for_grouped_rows_and_none_otherwise():
+    """map_to_bev._frame_ranges: rows grouped by frame in ascending order (what the voxelizer, the point stream and the reference's
+    collate produce) come back as per-frame (lo, hi) slices from ONE host read — empty frames included; anything else (unsorted,
+    an index outside [0, B)) comes back as None, and the training branch falls back to the reference's boolean masks
+    (pointpillar_scatter.py:101-104)."""
+    import torch
+    from hvpr_amd.map_to_bev import _frame_ranges
+    a = torch.tensor([0, 0, 0, 2, 2, 3], dtype=torch.int32)            # frame 1 empty
+    b = torch.tensor([0, 1, 1, 1, 2, 3, 3], dtype=torch.int64)
+    ra, rb = _frame_ranges([a, b], 4)
+    assert ra == [(0, 3), (3, 3), (3, 5), (5, 6)]
+    assert rb == [(0, 1), (1, 4), (4, 5), (5, 7)]
+    for r, col in ((ra, a), (rb, b)):
+        for f, (lo, hi) in enumerate(r):
+            assert torch.equal(torch.arange(lo, hi), torch.nonzero(col == f).flatten())
+    unsorted = torch.tensor([0, 2, 1, 1], dtype=torch.int32)
+    outside = torch.tensor([0, 1, 4], dtype=torch.int32)
+    negative = torch.tensor([-1, 0, 1], dtype=torch.int32)
+    empty = torch.zeros(0, dtype=torch.int32)
+    ru, ro, rn, re = _frame_ranges([unsorted, outside, negative, empty], 4)
+    assert ru is None and ro is None and rn is None
+    assert re == [(0, 0)] * 4
