@@ -41,8 +41,10 @@ extern "C" int hvpr_encode_fwd_f32(const float *points, int n_points, int point_
     const VoxWs w = hvpr_vox_carve(workspace, ws_max_batch, ws_max_points, ncell);
     const VoxelizeArgs a{points, n_points, point_stride, xyz_col, n_feat, frame_offsets, batch, lo_x, lo_y, lo_z, vs_x, vs_y, vs_z,
                          nx, ny, nz, max_points, max_voxels, cap_mode};
+    // (sizes of the pillar VFE's weights: csrc/vfe.hip — 10 -> 16 -> 64 per point, 5 -> 16 -> 32 for the scale stream)
+    const WarmSmall small{{w0, b0, w1, b1, ws0, bs0, ws1, bs1}, {16 * 10, 16, 64 * 32, 64, 16 * 5, 16, 32 * 16, 32}};
     int st = hvpr_i_voxel_index(a, w, voxel_offsets, true, s, w1, b0, bank_packed, bank_packed ? hvpr_memory_bank_packed_floats(n_items) * 4 : 0,
-                                bank, (size_t)n_items * 64 * 4);
+                                bank, (size_t)n_items * 64 * 4, &small);
     if (st != HVPR_OK) return st;
     const VfeWeights v{vs_x, vs_y, vs_z, off_x, off_y, off_z, w0, b0, w1, b1, ws0, bs0, ws1, bs1};
     st = hvpr_i_vfe_gather(a, w, voxel_offsets, capacity, v, voxels, coords, num_points, pillar_features, pillar_scale_features,

@@ -148,9 +148,12 @@ struct VfeWeights {
 // warm / warm_bytes (fused path, optional): 256 more workgroups of K3 — 32 per XCD, a 32nd of the arrays each — read them once, so that the memory
 // bank (768 KB with its packed copy) sits in every XCD's L2 when the read-out two launches later asks for it; inside a frame the
 // convolution stage (3.9 GB through the L2s) has evicted it since the previous frame (read-out 14.6 us in the frame, 12.5 us warm).
+// warm_small (optional): up to eight small arrays (the pillar VFE's weights: 12 KB in eight tensors) read by ONE of the warmers per XCD.
+struct WarmSmall { const float *p[8]; int n[8]; };
 HVPR_INTERNAL int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode,
                                      hipStream_t s, const float *vfe_w1 = nullptr, const float *vfe_b0 = nullptr,
-                                     const void *warm0 = nullptr, size_t warm0_bytes = 0, const void *warm1 = nullptr, size_t warm1_bytes = 0);
+                                     const void *warm0 = nullptr, size_t warm0_bytes = 0, const void *warm1 = nullptr, size_t warm1_bytes = 0,
+                                     const WarmSmall *warm_small = nullptr);
 // K4 fused into the pillar VFE: selects each voxel's points straight from the arena, writes voxels (optional) / coords /
 // num_points, the pillar and scale features and the pillar + scale cells of the NHWC canvases; extra workgroups of the same
 // launch clear every canvas cell that belongs to no pillar and return cell_first to idle (pair with for_encode above).

@@ -169,12 +169,26 @@ __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ fo
                                                const float *__restrict__ pts, int stride, int xyz_col,
                                                const float *__restrict__ vfe_w1, const float *__restrict__ vfe_b0, int point_blocks,
                                                const float4 *__restrict__ warm0, long long warm0_v4, const float4 *__restrict__ warm1,
-                                               long long warm1_v4, int *__restrict__ sink) {
+                                               long long warm1_v4, WarmSmall small, int *__restrict__ sink) {
     if ((int)blockIdx.x > point_blocks) {          // L2 warmers (internal.h): workgroups are dealt to the XCDs in turn;
         // warmer w = 8 * part + x reads slice `part` (of kWarmParts) of both arrays on the XCD its index lands on, all its loads
         // (six per thread for the 768 KB of the memory bank) in flight at once
         const int part = ((int)blockIdx.x - point_blocks - 1) >> 3;
         float acc = 0.f;
+        // one warmer per XCD also reads the small arrays (the pillar VFE's weights) — requested first, added last, so that their
+        // round trip runs beside the big arrays' (up to 256 * {1, 1, 8, 1, 1, 1, 2, 1} floats: what the pillar VFE has)
+        constexpr int kSmallLoads[8] = {1, 1, 8, 1, 1, 1, 2, 1};
+        float sm[16];
+        if (part == 0) {
+            int q = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int u = 0; u < kSmallLoads[j]; ++u, ++q) {
+                    const int i = threadIdx.x + 256 * u;
+                    sm[q] = i < small.n[j] ? small.p[j][i] : 0.f;
+                }
+        }
 #pragma unroll 1
         for (int which = 0; which < 2; ++which) {
             const float4 *src = which ? warm1 : warm0;
@@ -187,6 +201,10 @@ __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ fo
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += q[u].x + q[u].w;
             }
+        }
+        if (part == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += sm[q];
         }
         if (acc == 1.2345678e-30f) *sink = 1;      // never true in practice: keeps the loads alive
         return;
@@ -314,7 +332,7 @@ __global__ void __launch_bounds__(256) k4_gather(const float *__restrict__ pts, 
 
 int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode, hipStream_t s,
                        const float *vfe_w1, const float *vfe_b0, const void *warm0, size_t warm0_bytes, const void *warm1,
-                       size_t warm1_bytes) {
+                       size_t warm1_bytes, const WarmSmall *warm_small) {
     if (for_encode && a.n_feat != 4) return HVPR_ERR_UNSUPPORTED;
     const int tiles = hvpr_cdiv(a.n_points, kScanTile);
     const int pblocks = hvpr_cdiv(a.n_points, 256);
@@ -329,7 +347,8 @@ int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_off
     const int warmers = (vfe_w1 && (warm0 || warm1)) ? 8 * kWarmParts : 0;       // (the warmers sit behind the padded-slot workgroup)
     hipLaunchKernelGGL(k3_fill, dim3(pblocks + (vfe_w1 ? 1 : 0) + warmers), dim3(256), 0, s, a.n_points, a.frame_offsets, a.batch, a.max_voxels, w,
                        voxel_offsets, for_encode ? 1 : 0, a.points, a.point_stride, a.xyz_col, vfe_w1, vfe_b0, pblocks, (const float4 *)warm0,
-                       (long long)(warm0 ? warm0_bytes / 16 : 0), (const float4 *)warm1, (long long)(warm1 ? warm1_bytes / 16 : 0), (int *)(w.vfe_aux + 64));
+                       (long long)(warm0 ? warm0_bytes / 16 : 0), (const float4 *)warm1, (long long)(warm1 ? warm1_bytes / 16 : 0),
+                       (warm_small && warmers) ? *warm_small : WarmSmall{}, (int *)(w.vfe_aux + 64));
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
