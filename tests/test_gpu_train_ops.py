@@ -536,3 +536,22 @@ def test_sync_batchnorm_hook_spatial_gate_two_emulated_ranks_equal_the_joint_bat
         assert float((s - grads_j[k].double()).abs().max()) < 2e-5 * float(grads_j[k].abs().max()), what
     alone = run(slice(0, 1))
     assert float((alone[0] - gate_j[:1]).abs().max()) > 1e-3
+
+
+def test_sync_batchnorm_hook_failure_is_reported_not_swallowed():
+    """A hook that fails (returns non-zero — e.g. the python side caught an exception from the collective) makes the entry point
+    return HVPR_ERR_LAUNCH, which the wrapper raises; removing the hook restores the per-rank path."""
+    from hvpr_amd import conv_train as ct
+    from hvpr_amd._lib import ALLREDUCE_FN, lib
+    y = torch.rand(1, 8, 8, 8, device=DEV)
+    w = torch.randn(1, 2, 3, 3, device=DEV)
+    one = torch.ones(1, device=DEV)
+    bad = ALLREDUCE_FN(lambda buf, n, stream, ctx: 1)
+    lib().hvpr_set_batchnorm_allreduce(bad, None)
+    try:
+        with pytest.raises(RuntimeError, match="hvpr_spatial_gate_train_fwd_f32"):
+            ct.spatial_gate_train(y, w, one, one, one, 1e-3)
+    finally:
+        lib().hvpr_set_batchnorm_allreduce(None, None)
+    gate, _, _ = ct.spatial_gate_train(y, w, one, one, one, 1e-3)
+    assert bool(torch.isfinite(gate).all())
