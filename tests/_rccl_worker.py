@@ -45,8 +45,10 @@ def make_batch(seed0, B=2):
 batches = [make_batch(400 + 10 * i) for i in range(3)]
 
 
-def run(wrap):
+def run(wrap, sync_bn=False):
     model = copy.deepcopy(base)
+    if sync_bn:          # tools/train.py:119-120 (--sync_bn): every train-mode BatchNorm of the model takes global-batch statistics
+        model = distributed.convert_sync_batchnorm(model)
     m = distributed.wrap_ddp(model, dev) if wrap else model
     opt = optim.build_optimizer(m, cfg.OPTIMIZATION)
     assert isinstance(opt, optim.FusedAdamOneCycle)
@@ -74,10 +76,18 @@ def diff(a, b):
 
 name_p, loss_p, sd_p, flat_p = run(False)
 name_d, loss_d, sd_d, flat_d = run(True)
-name_q, loss_q, sd_q, _ = run(False)              # run-to-run: float atomics (scatter-add gradients) make the steps non-bit-reproducible
+name_q, loss_q, sd_q, _ = run(False)              # run-to-run: every sum of the step has a fixed order, so a rerun is bit-identical
+# the whole detector with SyncBatchNorm inside DDP: at world size 1 the all-reduces are identities, the statistics come out of float64
+# torch sums / the library's hook instead of the finalize kernels — same numbers up to fp32 round-off
+from hvpr_amd import conv_train  # noqa: E402
+name_s, loss_s, sd_s, flat_s = run(True, sync_bn=True)
+hook_calls = conv_train._sync.get("hook_calls", 0)
+conv_train.set_sync_batchnorm(None)
 json.dump({"backend": torch.distributed.get_backend(), "seen": seen, "ddp": name_d, "plain": name_p, "losses_plain": loss_p, "losses_ddp": loss_d,
            "losses_rerun": loss_q, "state_diff_ddp_vs_plain": diff(sd_d, sd_p), "state_diff_rerun_vs_plain": diff(sd_q, sd_p),
            "grads_in_flat_buffer_plain": flat_p, "grads_in_flat_buffer_ddp": flat_d,
+           "losses_sync_bn": loss_s, "state_diff_sync_bn_vs_plain": diff(sd_s, sd_p), "grads_in_flat_buffer_sync_bn": flat_s,
+           "sync_bn_hook_calls": hook_calls,
            "slowest": distributed.max_over_ranks(1.5, dev)}, open(out_path, "w"))
 distributed.barrier(dev)
 distributed.finalize()

@@ -32,6 +32,16 @@ def test_one_rank_rccl_group_real_detector_in_ddp_with_fused_optimizer(tmp_path)
     assert r["losses_rerun"] == r["losses_plain"], r
     assert r["losses_ddp"] == r["losses_plain"], r
     assert r["state_diff_rerun_vs_plain"] == 0.0 and r["state_diff_ddp_vs_plain"] == 0.0, r
+    # the same three steps with distributed.convert_sync_batchnorm(model) (reference --sync_bn) inside DDP: every BatchNorm goes through
+    # its all-reduce route (torch sums for the conv / point BatchNorms, the library's hook for the PFN layers and SpatialAttention:
+    # per step 2 + 4 calls of the PFN kernels and 3 x 2 of the gates) — at world size 1 the same numbers up to fp32 round-off
+    assert r["grads_in_flat_buffer_sync_bn"] and len(r["losses_sync_bn"]) == 3
+    assert r["sync_bn_hook_calls"] == 3 * (6 + 6), r["sync_bn_hook_calls"]
+    for a, b in zip(r["losses_sync_bn"], r["losses_plain"]):
+        assert abs(a - b) <= 2e-4 * abs(b), (r["losses_sync_bn"], r["losses_plain"])
+    # (no bar on the parameters themselves: Adam normalises every gradient, so a parameter whose exact gradient is zero — a convolution
+    # bias in front of a batch-statistics BatchNorm — moves by +-lr on round-off alone; the losses of steps 2 and 3 are the check that
+    # the updated models are the same model)
 
 
 def test_bench_train_step_ddp_line_over_one_rank_rccl(tmp_path):
