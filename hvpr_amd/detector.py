@@ -222,7 +222,9 @@ class Detector3DTemplate(nn.Module):
 
     @staticmethod
     def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
-        """detector3d_template.py:276-318 (no ROI head on this path)."""
+        """detector3d_template.py:276-318 (no ROI head on this path, so the roi_* counters stay 0).  Trailing all-zero gt rows
+        are cut with the reference's `while k > 0`, which never cuts row 0: a frame without ground truth counts one zero box.
+        Two host reads per frame (the gt rows' sums, the recalled counts of all thresholds) instead of one per row / threshold."""
         if "gt_boxes" not in data_dict:
             return recall_dict
         gt = data_dict["gt_boxes"][batch_index]
@@ -231,16 +233,18 @@ class Detector3DTemplate(nn.Module):
             for t in thresh_list:
                 recall_dict["roi_%s" % str(t)] = 0
                 recall_dict["rcnn_%s" % str(t)] = 0
-        k = len(gt) - 1
-        while k > 0 and gt[k].sum() == 0:
+        row_is_zero = (gt.sum(dim=1) == 0).tolist()
+        k = len(row_is_zero) - 1
+        while k > 0 and row_is_zero[k]:
             k -= 1
         gt = gt[:k + 1]
         if gt.shape[0] > 0:
-            iou = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7], gt[:, 0:7]) if box_preds.shape[0] > 0 else \
-                torch.zeros((0, gt.shape[0]), device=gt.device)
-            for t in thresh_list:
-                if iou.shape[0] > 0:
-                    recall_dict["rcnn_%s" % str(t)] += int((iou.max(dim=0)[0] > t).sum().item())
+            if box_preds.shape[0] > 0:
+                best = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7], gt[:, 0:7]).max(dim=0)[0]
+                thr = torch.tensor([float(t) for t in thresh_list], dtype=best.dtype).to(best.device, non_blocking=True)
+                recalled = (best.unsqueeze(0) > thr.unsqueeze(1)).sum(dim=1).tolist()
+                for t, n in zip(thresh_list, recalled):
+                    recall_dict["rcnn_%s" % str(t)] += int(n)
             recall_dict["gt"] += gt.shape[0]
         return recall_dict
 

@@ -461,15 +461,20 @@ def stable_order_desc(scores):
     return np.lexsort((np.arange(s.shape[0]), -s.astype(np.float64))).astype(np.int64)
 
 
+def nms_sorted(sorted_boxes, thresh):
+    """Mask + greedy sweep over boxes ALREADY in score order.  Returns the kept positions, ascending."""
+    sb = np.ascontiguousarray(_f32(sorted_boxes)[:, :7])
+    keep = np.zeros((sb.shape[0],), dtype=np.int64)
+    nk = _lib().hvpr_oracle_nms_sorted(_fp(sb), sb.shape[0], float(thresh),
+                                       keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+    return keep[:nk].copy()
+
+
 def nms_bev(boxes, scores, thresh):
     """nms_gpu restatement: sort desc (stable), bit-mask, sweep.  Returns indices into `boxes`."""
     b = _f32(boxes)[:, :7]
     order = stable_order_desc(scores)
-    sb = np.ascontiguousarray(b[order])
-    keep = np.zeros((sb.shape[0],), dtype=np.int64)
-    nk = _lib().hvpr_oracle_nms_sorted(_fp(sb), sb.shape[0], float(thresh),
-                                       keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
-    return order[keep[:nk]]
+    return order[nms_sorted(b[order], thresh)]
 
 
 def boxes_iou_bev(a, b):
@@ -507,13 +512,70 @@ def class_agnostic_nms(box_scores, box_preds, score_thresh, nms_thresh, pre_maxs
     return sel.astype(np.int64), s[sel]
 
 
-def post_process_frame(cls_logits, boxes, score_thresh, nms_thresh, pre_maxsize, post_maxsize):
-    """One frame of post_processing (class-agnostic branch, :241-259)."""
-    cls = torch.sigmoid(torch.as_tensor(cls_logits, dtype=torch.float32))
+def multi_classes_nms(cls_scores, box_preds, score_thresh, nms_thresh, pre_maxsize, post_maxsize):
+    """model_nms_utils.py:28-65: the class-agnostic chain once per class column, results concatenated in class order.
+    Returns (scores, labels = class index k, boxes, selected anchor ids)."""
+    s = np.asarray(cls_scores, dtype=np.float32)
+    bx = _f32(box_preds)
+    sc, lab, sel = [], [], []
+    for k in range(s.shape[1]):
+        ids, sk = class_agnostic_nms(s[:, k], bx, score_thresh, nms_thresh, pre_maxsize, post_maxsize)
+        sc.append(sk); sel.append(ids); lab.append(np.full((len(ids),), k, np.int64))
+    sel = np.concatenate(sel)
+    return np.concatenate(sc), np.concatenate(lab), bx[sel], sel
+
+
+def post_process_frame(cls_logits, boxes, score_thresh, nms_thresh, pre_maxsize, post_maxsize, normalized=False,
+                       raw_score=False, multi_classes=False):
+    """One frame of post_processing: the class-agnostic branch (:241-259; label = arg-max class + 1, OUTPUT_RAW_SCORE puts the
+    un-normalised maximum out, :254-256) or the MULTI_CLASSES_NMS branch (:214-239; label mapping k -> k + 1)."""
+    src = torch.as_tensor(cls_logits, dtype=torch.float32)
+    cls = src if normalized else torch.sigmoid(src)
+    bx = np.asarray(boxes)
+    if multi_classes:
+        sc, lab, pb, sel = multi_classes_nms(cls.numpy(), bx, score_thresh, nms_thresh, pre_maxsize, post_maxsize)
+        return {"pred_boxes": pb, "pred_scores": sc, "pred_labels": lab + 1, "selected": sel}
     score, label = torch.max(cls, dim=-1)
-    sel, sc = class_agnostic_nms(score.numpy(), np.asarray(boxes), score_thresh, nms_thresh, pre_maxsize, post_maxsize)
-    return {"pred_boxes": np.asarray(boxes)[sel], "pred_scores": sc, "pred_labels": (label.numpy()[sel] + 1),
-            "selected": sel}
+    sel, sc = class_agnostic_nms(score.numpy(), bx, score_thresh, nms_thresh, pre_maxsize, post_maxsize)
+    if raw_score:
+        sc = torch.max(src, dim=-1)[0].numpy()[sel]
+    return {"pred_boxes": bx[sel], "pred_scores": sc, "pred_labels": (label.numpy()[sel] + 1), "selected": sel}
+
+
+def recall_record(box_preds, recall_dict, gt_boxes, thresh_list):
+    """generate_recall_record without an ROI head (detector3d_template.py:276-318): trailing all-zero gt rows are cut — but
+    `while k > 0` never cuts row 0, so a frame without ground truth counts ONE (zero) box —, a gt box is recalled at threshold
+    t when its best 3D IoU over the predictions is > t."""
+    gt = _f32(gt_boxes)
+    if len(recall_dict) == 0:
+        recall_dict = {"gt": 0}
+        for t in thresh_list:
+            recall_dict["roi_%s" % str(t)] = 0
+            recall_dict["rcnn_%s" % str(t)] = 0
+    k = gt.shape[0] - 1
+    while k > 0 and gt[k].sum() == 0:
+        k -= 1
+    gt = gt[:k + 1]
+    if gt.shape[0] > 0:
+        bp = _f32(box_preds)
+        if bp.shape[0] > 0:
+            best = boxes_iou3d(bp[:, :7], gt[:, :7]).max(axis=0)
+            for t in thresh_list:
+                recall_dict["rcnn_%s" % str(t)] += int((best > np.float32(t)).sum())
+        recall_dict["gt"] += gt.shape[0]
+    return recall_dict
+
+
+def post_processing(batch_cls_preds, batch_box_preds, gt_boxes, score_thresh, nms_thresh, pre_maxsize, post_maxsize,
+                    thresh_list, **kw):
+    """post_processing over a batch (detector3d_template.py:168-274): per-frame records + the recall counters."""
+    preds, recall = [], {}
+    for b in range(len(batch_cls_preds)):
+        rec = post_process_frame(batch_cls_preds[b], batch_box_preds[b], score_thresh, nms_thresh, pre_maxsize, post_maxsize, **kw)
+        if gt_boxes is not None:
+            recall = recall_record(rec["pred_boxes"], recall, gt_boxes[b], thresh_list)
+        preds.append(rec)
+    return preds, recall
 
 
 # ----------------------------------------------------------------------------------------

@@ -725,6 +725,193 @@ def g14_axis_aligned_iou(R):
                         nms_boxes=c.numpy(), nms_scores=scores.numpy(), iou_nms=iou_cc.numpy())
 
 
+def load_post_processing(R):
+    """The reference's post-processing wrapper — model_nms_utils.py:6-65 and Detector3DTemplate.post_processing /
+    generate_recall_record (detector3d_template.py:168-318) — imported as they are.  What is ABSENT from the reference is the
+    native module they call, pcdet/ops/iou3d_nms (setup.py:53-62): `nms_gpu` and `boxes_iou3d_gpu` are stood in by thin
+    wrappers over the CPU oracle's C routines, written from the upstream signature (sort descending, optional
+    pre_maxsize cut, mask + sweep, `order[keep]`).  detector3d_template.py's package-relative imports of the module zoo
+    (backbones, heads, transformer ...; none is used by the two methods) are dropped."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import hvpr_oracle as O
+    iou = sys.modules["pcdet.ops.iou3d_nms.iou3d_nms_utils"]
+
+    def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+        order = scores.sort(0, descending=True)[1]
+        if pre_maxsize is not None:
+            order = order[:pre_maxsize]
+        b = np.ascontiguousarray(boxes[order].numpy()[:, :7], dtype=np.float32)
+        keep = O.nms_sorted(b, float(thresh))
+        return order[torch.from_numpy(keep)].contiguous(), None
+
+    def boxes_iou3d_gpu(boxes_a, boxes_b):
+        return torch.from_numpy(O.boxes_iou3d(boxes_a.numpy(), boxes_b.numpy()))
+    iou.nms_gpu, iou.boxes_iou3d_gpu = nms_gpu, boxes_iou3d_gpu
+    _stub("pcdet.models.model_utils", os.path.join(REF, "pcdet/models/model_utils"))
+    _stub("pcdet.models.detectors", os.path.join(REF, "pcdet/models/detectors"))
+    R.model_nms_utils = _load("pcdet.models.model_utils.model_nms_utils", "pcdet/models/model_utils/model_nms_utils.py")
+
+    def drop_zoo(src):
+        lines = src.split("\n")
+        assert lines[5].startswith("from ...ops.iou3d_nms") and lines[9].startswith("from ..model_utils")
+        return "\n".join(l for i, l in enumerate(lines) if not (5 <= i <= 9))
+    R.det_template = _load("pcdet.models.detectors.detector3d_template", "pcdet/models/detectors/detector3d_template.py", drop_zoo)
+    R.det_template.iou3d_nms_utils = iou
+    R.det_template.model_nms_utils = R.model_nms_utils
+    return R
+
+
+def _detection_like(gen, B, N, C, frac_pass, n_centres, logit_lo=-7.0, logit_hi=3.0):
+    """Logits (B, N, C) with well separated distinct values (a shuffled grid: sigmoid on another device cannot reorder them or
+    move one across SCORE_THRESH) and car-sized boxes clustered round a few centres so that NMS has work to do."""
+    boxes = torch.zeros(B, N, 7)
+    cls = torch.empty(B, N, C)
+    thr_logit = float(np.log(0.1 / 0.9))
+    for b in range(B):
+        centres = torch.rand(n_centres, 2, generator=gen) * torch.tensor([44.0, 36.0]) + torch.tensor([1.5, -18.0])
+        boxes[b, :, 0:2] = centres[torch.randint(0, n_centres, (N,), generator=gen)] + torch.randn(N, 2, generator=gen) * 0.7
+        boxes[b, :, 2] = torch.randn(N, generator=gen) * 0.2 - 1.0
+        boxes[b, :, 3:6] = torch.tensor([3.9, 1.6, 1.56]) * (0.8 + 0.4 * torch.rand(N, 3, generator=gen))
+        boxes[b, :, 6] = (torch.rand(N, generator=gen) * 2 - 1) * np.pi
+        n_pass = int(round(N * C * frac_pass[b]))
+        hi = torch.linspace(thr_logit + 0.05, logit_hi, max(n_pass, 1))[:n_pass]
+        lo = torch.linspace(logit_lo, thr_logit - 0.05, N * C - n_pass)
+        v = torch.cat([hi, lo])
+        cls[b] = v[torch.randperm(N * C, generator=gen)].view(N, C)
+    return cls, boxes
+
+
+def _gt_from(boxes_b, picks, shifts, G, labels):
+    """gt_boxes rows (G, 8): copies of predicted boxes moved by `shifts` metres along x; the rest zero rows (collate padding)."""
+    gt = torch.zeros(G, 8)
+    for r, (i, dx, lab) in enumerate(zip(picks, shifts, labels)):
+        gt[r, :7] = boxes_b[i]
+        gt[r, 0] += dx
+        gt[r, 7] = lab
+    return gt
+
+
+def g15_post_processing(R):
+    """Row a8's WRAPPER pinned on the reference's own code: score mask -> top-k -> NMS keep -> index map -> labels -> recall
+    counters, for the class-agnostic branch (one class and three classes, raw-score output), the MULTI_CLASSES_NMS branch, and
+    the two functions of model_nms_utils.py called directly.  Frames: more candidates than NMS_PRE_MAXSIZE, fewer, none at all,
+    more survivors than NMS_POST_MAXSIZE; gt_boxes with trailing zero rows, a zero row in the middle, and all rows zero (the
+    reference's `while k > 0` then keeps ONE zero row as a ground truth: detector3d_template.py:290-293).
+
+    Score ties: torch.topk / torch.sort leave the order of equal scores unspecified (it differs between CPU and GPU builds of
+    torch), so the tie frames are built so that the reference's result does not depend on it as a SET — tied boxes far from
+    everything (all survive), tied boxes under one stronger box (all suppressed), none straddling the NMS_PRE_MAXSIZE cut —
+    and the tests compare after ordering equal scores by ascending id, the tie rule this build defines."""
+    R = load_post_processing(R)
+    gen = torch.Generator().manual_seed(1515)
+    out = {}
+
+    class _DS:
+        class_names = ["Car"]
+
+    def detector(num_class, multi, raw, pre, post, nms_thresh):
+        cfg = EasyDict(POST_PROCESSING=dict(RECALL_THRESH_LIST=[0.3, 0.5, 0.7], SCORE_THRESH=0.1, OUTPUT_RAW_SCORE=raw,
+                                            EVAL_METRIC="kitti",
+                                            NMS_CONFIG=dict(MULTI_CLASSES_NMS=multi, NMS_TYPE="nms_gpu", NMS_THRESH=nms_thresh,
+                                                            NMS_PRE_MAXSIZE=pre, NMS_POST_MAXSIZE=post)))
+        ds = _DS(); ds.class_names = ["Car", "Pedestrian", "Cyclist"][:num_class]
+        return R.det_template.Detector3DTemplate(cfg, num_class, ds), cfg
+
+    def run(tag, cls, boxes, gt, num_class, multi=False, raw=False, normalized=False, pre=512, post=60, nms_thresh=0.1):
+        det, cfg = detector(num_class, multi, raw, pre, post, nms_thresh)
+        B = cls.shape[0]
+        bd = {"batch_size": B, "batch_box_preds": boxes.clone(), "cls_preds_normalized": normalized, "gt_boxes": gt.clone()}
+        if multi:       # the reference's tensor form trips its own assert (label mapping arange(1, num_class) is one short,
+            bd["batch_cls_preds"] = [cls.clone()]           # :219-224); the multi-head LIST form with a full mapping runs
+            bd["multihead_label_mapping"] = [torch.arange(1, num_class + 1)]
+        else:
+            bd["batch_cls_preds"] = cls.clone()
+        preds, recall, _ = det.post_processing(bd)
+        out[tag + ".cls"], out[tag + ".boxes"], out[tag + ".gt_boxes"] = cls.numpy().copy(), boxes.numpy().copy(), gt.numpy().copy()
+        out[tag + ".cfg"] = np.array([num_class, int(multi), int(raw), int(normalized), pre, post], np.int64)
+        out[tag + ".nms_thresh"] = np.float32(nms_thresh)
+        for b, p in enumerate(preds):
+            out[f"{tag}.f{b}.pred_boxes"] = p["pred_boxes"].numpy()
+            out[f"{tag}.f{b}.pred_scores"] = p["pred_scores"].numpy()
+            out[f"{tag}.f{b}.pred_labels"] = p["pred_labels"].numpy().astype(np.int64)
+        keys = sorted(recall)
+        out[tag + ".recall_keys"] = np.array(keys)
+        out[tag + ".recall_values"] = np.array([recall[k] for k in keys], np.int64)
+        # no recalled-count may hang on round-off: every best IoU stays clear of the thresholds
+        for b, p in enumerate(preds):
+            g = gt[b]; k = len(g) - 1
+            while k > 0 and g[k].sum() == 0:
+                k -= 1
+            if p["pred_boxes"].shape[0]:
+                best = R.det_template.iou3d_nms_utils.boxes_iou3d_gpu(p["pred_boxes"][:, :7], g[:k + 1, :7]).max(0)[0]
+                assert all((best - t).abs().min() > 5e-3 for t in (0.3, 0.5, 0.7)), (tag, b, best)
+        # the two functions of model_nms_utils.py, called directly on the same frames
+        ncfg = cfg.POST_PROCESSING.NMS_CONFIG
+        for b in range(B):
+            sc = cls[b] if normalized else torch.sigmoid(cls[b])
+            if multi:
+                s, l, bx = R.model_nms_utils.multi_classes_nms(sc, boxes[b], ncfg, score_thresh=0.1)
+                out[f"{tag}.f{b}.mc_scores"], out[f"{tag}.f{b}.mc_labels"], out[f"{tag}.f{b}.mc_boxes"] = s.numpy(), l.numpy(), bx.numpy()
+            else:
+                sel, ss = R.model_nms_utils.class_agnostic_nms(sc.max(-1)[0], boxes[b], ncfg, score_thresh=0.1)
+                sel = sel if torch.is_tensor(sel) else torch.zeros(0, dtype=torch.long)
+                out[f"{tag}.f{b}.selected"] = sel.numpy().astype(np.int64)
+                out[f"{tag}.f{b}.selected_scores"] = ss.numpy()
+        print("g15", tag, "kept per frame", [len(p["pred_scores"]) for p in preds], dict(recall))
+
+    def plant_ties(cls, boxes, b, n_pass_expected):
+        """Frame b: (i) five boxes with one score, far from everything and from each other -> all survive; (ii) four boxes with
+        one score stacked under a box with a higher score -> all suppressed.  Both groups sit well inside the top-k cut."""
+        N = cls.shape[1]
+        top = torch.sort(cls[b, :, 0], descending=True)[1]
+        assert n_pass_expected > 40
+        loners, under, boss = top[10:15], top[20:24], top[2]
+        cls[b, loners, 0] = float(cls[b, top[10], 0])
+        for j, i in enumerate(loners):
+            boxes[b, i, 0], boxes[b, i, 1] = 100.0 + 12.0 * j, 60.0
+        cls[b, under, 0] = float(cls[b, top[20], 0])
+        boxes[b, boss, 0], boxes[b, boss, 1] = 200.0, -60.0
+        for j, i in enumerate(under):
+            boxes[b, i] = boxes[b, boss].clone()
+            boxes[b, i, 0] += 0.05 * (j + 1)
+        return loners, under
+
+    # --- one class, class-agnostic (hvpr_car): > PRE candidates | < PRE | none | ties + > POST survivors
+    N = 3000
+    cls, boxes = _detection_like(gen, 4, N, 1, [0.5, 0.06, 0.0, 0.3], 40)
+    boxes[3, :, 0:2] = torch.rand(N, 2, generator=gen) * torch.tensor([46.0, 38.0]) + torch.tensor([0.5, -19.0])   # spread: many survivors
+    plant_ties(cls, boxes, 3, 900)
+    order = [torch.sort(cls[b, :, 0], descending=True)[1] for b in range(4)]
+    gt = torch.stack([
+        _gt_from(boxes[0], order[0][[0, 5, 9, 14]].tolist(), [0.1, 0.8, 1.5, 30.0], 6, [1, 1, 1, 1]),
+        _gt_from(boxes[1], order[1][[0, 1, 2, 3, 4, 6]].tolist(), [0.0, 0.3, 0.6, 0.9, 1.3, 2.5], 6, [1] * 6),
+        torch.zeros(6, 8),
+        _gt_from(boxes[3], order[3][[0, 1, 3]].tolist(), [0.2, 0.5, 1.1], 6, [1, 1, 1])])
+    gt[3, 4] = gt[3, 2]; gt[3, 2] = 0            # a zero row in the MIDDLE stays a ground truth; only trailing ones are cut
+    run("car", cls, boxes, gt, 1)
+    run("car_normalized_raw", torch.sigmoid(cls), boxes, gt, 1, raw=True, normalized=True, pre=300, post=25, nms_thresh=0.25)
+
+    # --- the yaml's own sizes (NMS_PRE_MAXSIZE 4096, NMS_POST_MAXSIZE 500, thresh 0.1 as in tools/cfgs/kitti_models/hvpr.yaml)
+    cls, boxes = _detection_like(gen, 1, 7000, 1, [0.7], 400)
+    boxes[0, :, 0:2] = torch.rand(7000, 2, generator=gen) * torch.tensor([46.0, 38.0]) + torch.tensor([0.5, -19.0])
+    o = torch.sort(cls[0, :, 0], descending=True)[1]
+    gt = _gt_from(boxes[0], o[[0, 3, 8]].tolist(), [0.0, 0.4, 1.3], 5, [1, 1, 1])[None]
+    run("car_yaml_sizes", cls, boxes, gt, 1, pre=4096, post=500, nms_thresh=0.1)
+
+    # --- three classes, class-agnostic branch: label = argmax + 1 (:241-247); once with raw scores out (:254-256)
+    cls, boxes = _detection_like(gen, 2, 1500, 3, [0.2, 0.02], 30)
+    o = [torch.sort(cls[b].max(-1)[0], descending=True)[1] for b in range(2)]
+    gt = torch.stack([_gt_from(boxes[0], o[0][[0, 2, 4, 7, 11]].tolist(), [0.0, 0.4, 0.9, 1.4, 2.2], 7, [1, 2, 3, 1, 2]),
+                      _gt_from(boxes[1], o[1][[0, 1]].tolist(), [0.3, 1.0], 7, [3, 1])])
+    run("three_agnostic", cls, boxes, gt, 3, pre=256, post=40)
+    run("three_agnostic_raw", cls, boxes, gt, 3, raw=True, pre=256, post=40)
+
+    # --- three classes, MULTI_CLASSES_NMS branch (:214-239, model_nms_utils.py:28-65); frame 1: one class has no candidate
+    cls[1, :, 1] = cls[1, :, 1].clamp(max=-3.0)
+    run("three_multi", cls, boxes, gt, 3, multi=True, pre=200, post=30, nms_thresh=0.2)
+    np.savez_compressed(os.path.join(OUT, "g15_post_processing.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     R = load_reference()
@@ -741,6 +928,7 @@ if __name__ == "__main__":
     g12_kitti_eval(R)
     g13_voxel_index(R)
     g14_axis_aligned_iou(R)
+    g15_post_processing(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")

@@ -204,3 +204,86 @@ def test_rotated_iou_kernel_against_exact_float64_clipping():
     assert np.abs(d).max() <= 1e-2 and abs(d.mean()) <= 1e-4
     ora = np.array([O.boxes_iou_bev(a[i:i + 1], b[i:i + 1])[0, 0] for i in range(len(a))])
     np.testing.assert_allclose(got, ora, rtol=1e-5, atol=1e-6)
+
+
+def _g15_detector(c):
+    from hvpr_amd import detector
+    from hvpr_amd.config import AttrDict
+    import g15_cases
+    cfg = AttrDict(POST_PROCESSING=dict(RECALL_THRESH_LIST=g15_cases.RECALL_THRESH_LIST, SCORE_THRESH=g15_cases.SCORE_THRESH,
+                                        OUTPUT_RAW_SCORE=c.raw, EVAL_METRIC="kitti",
+                                        NMS_CONFIG=dict(MULTI_CLASSES_NMS=c.multi, NMS_TYPE="nms_gpu", NMS_THRESH=c.nms_thresh,
+                                                        NMS_PRE_MAXSIZE=c.pre, NMS_POST_MAXSIZE=c.post)))
+
+    class DS:
+        class_names = ["Car", "Pedestrian", "Cyclist"][: c.num_class]
+    return detector.Detector3DTemplate(cfg, c.num_class, DS()), cfg, detector
+
+
+def test_post_processing_wrapper_against_reference_fixture_g15(golden_dir):
+    """Row a8's wrapper on the product path against the REFERENCE's own functions (fixture G15 = model_nms_utils.py:6-65 and
+    Detector3DTemplate.post_processing / generate_recall_record, detector3d_template.py:168-318, run in the build container):
+    selected anchor ids, boxes and labels exact, scores to the sigmoid's last bit, recall counters exact — class-agnostic branch
+    (one / three classes, raw-score output, normalised input), MULTI_CLASSES_NMS branch, the two model_nms_utils functions
+    called directly, and the no-read-back form (sync=False)."""
+    import g15_cases
+    for c in g15_cases.load(golden_dir):
+        det, cfg, detector = _g15_detector(c)
+        bd = {"batch_size": c.cls.shape[0], "batch_cls_preds": torch.from_numpy(c.cls).to(DEV),
+              "batch_box_preds": torch.from_numpy(c.boxes).to(DEV), "cls_preds_normalized": c.normalized,
+              "gt_boxes": torch.from_numpy(c.gt_boxes).to(DEV)}
+        preds, recall, _ = det.post_processing(dict(bd))
+        assert recall == c.recall, (c.tag, recall, c.recall)
+        exact_scores = c.normalized or c.raw
+        for b, (p, f) in enumerate(zip(preds, c.frames)):
+            msg = f"{c.tag} f{b}"
+            np.testing.assert_array_equal(p["pred_boxes"].cpu().numpy(), f["pred_boxes"], err_msg=msg)
+            np.testing.assert_array_equal(p["pred_labels"].cpu().numpy(), f["pred_labels"], err_msg=msg)
+            if exact_scores:
+                np.testing.assert_array_equal(p["pred_scores"].cpu().numpy(), f["pred_scores"], err_msg=msg)
+            else:
+                np.testing.assert_allclose(p["pred_scores"].cpu().numpy(), f["pred_scores"], rtol=1e-6, atol=0, err_msg=msg)
+            ncfg = cfg.POST_PROCESSING.NMS_CONFIG
+            sc = bd["batch_cls_preds"][b] if c.normalized else torch.sigmoid(bd["batch_cls_preds"][b])
+            if c.multi:
+                s, l, bx = detector.multi_classes_nms(sc, bd["batch_box_preds"][b], ncfg, score_thresh=g15_cases.SCORE_THRESH)
+                np.testing.assert_allclose(s.cpu().numpy(), f["mc_scores"], rtol=1e-6, atol=0, err_msg=msg)
+                np.testing.assert_array_equal(l.cpu().numpy(), f["mc_labels"], err_msg=msg)
+                np.testing.assert_array_equal(bx.cpu().numpy(), f["mc_boxes"], err_msg=msg)
+            else:
+                np.testing.assert_array_equal(p["selected"].cpu().numpy(), f["selected"], err_msg=msg)
+                sel, ss = detector.class_agnostic_nms(sc.max(-1)[0], bd["batch_box_preds"][b], ncfg, score_thresh=g15_cases.SCORE_THRESH)
+                np.testing.assert_array_equal(sel.cpu().numpy(), f["selected"], err_msg=msg)
+                np.testing.assert_allclose(ss.cpu().numpy(), f["selected_scores"], rtol=1e-6, atol=0, err_msg=msg)
+        if not c.multi:     # the form the frame pipeline uses: padded rows + a device count, no host read
+            preds, recall, _ = det.post_processing(dict(bd), sync=False)
+            assert recall == {}
+            for b, (p, f) in enumerate(zip(preds, c.frames)):
+                n = int(p["pred_count"].item())
+                assert n == len(f["selected"]) and p["selected"].shape[0] == min(c.post, p["selected"].shape[0])
+                np.testing.assert_array_equal(p["selected"][:n].cpu().numpy(), f["selected"])
+                np.testing.assert_array_equal(p["pred_boxes"][:n].cpu().numpy(), f["pred_boxes"])
+                np.testing.assert_array_equal(p["pred_labels"][:n].cpu().numpy(), f["pred_labels"])
+
+
+def test_generate_recall_record_branches():
+    """generate_recall_record (detector3d_template.py:276-318) beyond G15: no gt_boxes key -> the dict is returned untouched;
+    counters accumulate over frames and over calls; no predictions -> only `gt` moves; a prediction equal to a gt box is recalled
+    at every threshold, one 10 m away at none."""
+    from hvpr_amd import detector
+    rng = np.random.default_rng(7)
+    gt = torch.zeros(2, 4, 8, device=DEV)
+    b = torch.from_numpy(_boxes(rng, 3, clustered=False)).to(DEV)
+    gt[0, :3, :7], gt[0, :3, 7] = b, 1.0
+    gt[1, :1, :7], gt[1, :1, 7] = b[:1], 1.0
+    rec = detector.Detector3DTemplate.generate_recall_record
+    assert rec(b, {"x": 1}, 0, {}, [0.3]) == {"x": 1}
+    far = b.clone(); far[:, 0] += 10.0
+    d = rec(b, {}, 0, {"gt_boxes": gt}, [0.3, 0.5, 0.7])
+    assert d == {"gt": 3, "roi_0.3": 0, "rcnn_0.3": 3, "roi_0.5": 0, "rcnn_0.5": 3, "roi_0.7": 0, "rcnn_0.7": 3}
+    d = rec(far, d, 1, {"gt_boxes": gt}, [0.3, 0.5, 0.7])
+    assert d == {"gt": 4, "roi_0.3": 0, "rcnn_0.3": 3, "roi_0.5": 0, "rcnn_0.5": 3, "roi_0.7": 0, "rcnn_0.7": 3}
+    d = rec(b[:0], d, 0, {"gt_boxes": gt}, [0.3, 0.5, 0.7])
+    assert d["gt"] == 7 and d["rcnn_0.3"] == 3
+    d = rec(b[:1], d, 1, {"gt_boxes": torch.zeros(2, 4, 8, device=DEV)}, [0.3, 0.5, 0.7])     # `while k > 0`: one zero box stays
+    assert d["gt"] == 8 and d["rcnn_0.3"] == 3

@@ -237,3 +237,32 @@ def test_rotated_iou_oracle_against_exact_float64_clipping():
     assert np.abs(d).max() <= 1e-2                                  # observed 2.7e-3 (the 1e-2 in-box margin at grazing corners)
     assert abs(d.mean()) <= 1e-4                                    # observed 8.5e-6: no systematic slip
     assert (got[exact == 0] <= 1e-2).all() and (got[exact > 0.05] > 0).all()
+
+
+def test_g15_post_processing_wrapper(golden_dir):
+    """Row a8's wrapper: the oracle's restatement of model_nms_utils.py:6-65 and detector3d_template.py:168-318 (score mask ->
+    top-k -> keep -> index map -> labels -> recall counters) against the reference's own functions (fixture G15: both NMS
+    branches, raw-score output, > / < NMS_PRE_MAXSIZE candidates, none, > NMS_POST_MAXSIZE survivors, score ties, zero gt rows)."""
+    import g15_cases
+    for c in g15_cases.load(golden_dir):
+        preds, recall = O.post_processing(c.cls, c.boxes, c.gt_boxes, g15_cases.SCORE_THRESH, c.nms_thresh, c.pre, c.post,
+                                          g15_cases.RECALL_THRESH_LIST, **c.kwargs())
+        assert recall == c.recall, (c.tag, recall, c.recall)
+        for b, (p, f) in enumerate(zip(preds, c.frames)):
+            np.testing.assert_array_equal(p["pred_boxes"], f["pred_boxes"], err_msg=f"{c.tag} f{b}")
+            np.testing.assert_array_equal(p["pred_scores"], f["pred_scores"], err_msg=f"{c.tag} f{b}")
+            np.testing.assert_array_equal(p["pred_labels"], f["pred_labels"], err_msg=f"{c.tag} f{b}")
+            if c.multi:
+                sc = c.cls[b] if c.normalized else torch.sigmoid(torch.from_numpy(c.cls[b])).numpy()
+                s, l, bx, _ = O.multi_classes_nms(sc, c.boxes[b], g15_cases.SCORE_THRESH, c.nms_thresh, c.pre, c.post)
+                np.testing.assert_array_equal(s, f["mc_scores"]); np.testing.assert_array_equal(l, f["mc_labels"])
+                np.testing.assert_array_equal(bx, f["mc_boxes"])
+            else:
+                np.testing.assert_array_equal(p["selected"], f["selected"], err_msg=f"{c.tag} f{b}")
+    # what the fixture covers, so that a regenerated fixture that lost a case is noticed
+    car = [c for c in g15_cases.load(golden_dir) if c.tag == "car"][0]
+    n_pass = [(torch.sigmoid(torch.from_numpy(car.cls[b, :, 0])) >= 0.1).sum().item() for b in range(4)]
+    assert n_pass[0] > car.pre and 0 < n_pass[1] < car.pre and n_pass[2] == 0
+    assert len(car.frames[0]["selected"]) == car.post and len(car.frames[2]["selected"]) == 0
+    ss = car.frames[3]["selected_scores"]
+    assert (np.diff(ss) == 0).sum() >= 4          # the five tied loners survive
