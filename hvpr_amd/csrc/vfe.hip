@@ -636,8 +636,11 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                 b = g.batch > 1 ? fdiv(cell, g.div_cells) : 0;
                 row = rk;
                 if (g.batch > 1 && rk >= 0) row = b < kMaxB ? s_voff[b] + rk - s_fbase[b] : g.voxel_offsets[b] + rk - g.w.frame_base[b];
-                // whole (the pillar ends inside the pass), owned (it starts inside this wave's window), small, emitted
-                proc = rk >= 0 && cn <= P && seg0 + cn <= 32 && s + seg0 <= kWin && row < g.capacity;
+                // taken by this pass: whole (the pillar ends inside the pass), owned (it starts inside this wave's window), small.
+                // The pass's first pillar always is, so `todo` shrinks with every pass.  Emitted: its output row exists — a
+                // caller's capacity below the voxel count truncates, the pillars past it are taken and dropped
+                const bool own = rk >= 0 && cn <= P && seg0 + cn <= 32 && s + seg0 <= kWin;
+                proc = own && row < g.capacity;
                 if (g.cap_mode == 1 && proc) {
                     if (g.batch == 1) cutoff = cut1;
                     else if (b < kMaxB) cutoff = s_cut[b];
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                     }
                 }
                 if (!mine) {   // the other role's pass: only which pillars it takes
-                    todo &= ~((__ballot(proc && col == seg0) & 0xffffffffull) << s);
+                    todo &= ~((__ballot(own && col == seg0) & 0xffffffffull) << s);
                     continue;
                 }
                 // Inside a pillar the arena holds the points in arrival order.  Nothing of the VFE depends on it (the sums above
@@ -677,7 +680,8 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                 n = __popc(livemask & segmask);
                 startsproc = (unsigned)(__ballot(proc && col == seg0) & 0xffffffffull);
                 endmask = (unsigned)(__ballot(proc && col == seg0 + cn - 1) & 0xffffffffull);
-                todo &= ~((unsigned long long)startsproc << s);
+                todo &= ~((__ballot(own && col == seg0) & 0xffffffffull) << s);
+                if (uni(startsproc) == 0u) continue;   // every pillar of the pass lies past the capacity
             }
             const int cib = proc ? cell - b * cells_per_frame : 0;   // nz == 1: cell = (b * ny + y) * nx + x
             const int cy = fdiv(cib, g.div_nx);

@@ -366,6 +366,41 @@ def test_encode_fused_with_the_voxel_cap(cap_mode):
         assert _encode_both([f, f[::-1].copy()], cap, cap_mode=cap_mode) == 2 * cap
 
 
+@pytest.mark.parametrize("case", ["one_frame", "batch", "large_batch"])
+def test_encode_fused_capacity_below_the_voxel_count_truncates(case):
+    """A C caller whose output buffers hold fewer rows than there are voxels gets the first `capacity` rows and canvases without
+    the dropped pillars (include/hvpr_amd.h: 'capacity'), on every path of k_vfe_gather: one frame (first / later passes on
+    different waves), a small batch, and a batch large enough for the persistent window walk (no role split); with a 1500-point
+    cell (the pass of its own) among the dropped ones.  ADVICE r4: the packed pass used to wait for a dropped pillar for ever."""
+    dense = synthetic.hvpr_frame(5).copy()
+    dense[-3000:, 0] = 10.0 + 0.3 * np.random.default_rng(0).random(3000).astype(np.float32)
+    dense[-3000:, 1] = 0.05
+    frames = {"one_frame": [dense], "batch": [synthetic.hvpr_frame(2)[:5000], np.zeros((0, 4), np.float32), dense[-6000:]],
+              "large_batch": [synthetic.hvpr_frame(7), dense, synthetic.hvpr_frame(8, shuffle=True)]}[case]
+    pts = np.concatenate([np.concatenate([np.full((len(f), 1), b, np.float32), f], 1) for b, f in enumerate(frames)], 0)
+    offs = torch.from_numpy(np.cumsum([0] + [len(f) for f in frames]).astype(np.int32)).to(DEV)
+    B, tp = len(frames), torch.from_numpy(pts).to(DEV)
+    folded = _folded_from(_vfe_params(3))
+    vfe_off = [VS[0] / 2 + RNG[0], VS[1] / 2 + RNG[1], VS[2] / 2 + RNG[2]]
+    W = torch.from_numpy(np.random.default_rng(3).uniform(-0.125, 0.125, (2000, 64)).astype(np.float32)).to(DEV)
+    ws = kernels.VoxelizeWorkspace(B, len(pts), GRID, DEV)
+    full = kernels.encode_fwd(tp, offs, B, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1)
+    torch.cuda.synchronize()
+    m = int(full["voxel_offsets"][B])
+    for cap in (m - 1, m // 2, 7, 1):
+        r = kernels.encode_fwd(tp, offs, B, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1, capacity=cap)
+        torch.cuda.synchronize()
+        for key in ("voxels", "coords", "num_points", "pillar_features", "pillar_scale_features", "pillar_mask", "memory_features"):
+            assert r[key].shape[0] == cap and torch.equal(r[key], full[key][:cap]), (cap, key)
+        sp, sc = full["spatial"].clone(), full["spatial_scale"].clone()
+        c = full["coords"][cap:m].long()
+        sp[c[:, 0], :, c[:, 2], c[:, 3]] = 0
+        sc[c[:, 0], :, c[:, 2], c[:, 3]] = 0
+        assert torch.equal(r["spatial"], sp) and torch.equal(r["spatial_scale"], sc), cap
+    again = kernels.encode_fwd(tp, offs, B, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1)   # workspace idle again
+    assert all(torch.equal(again[k], full[k]) for k in ("coords", "pillar_features", "spatial", "spatial_scale"))
+
+
 def test_encode_fused_dense_scene_config5():
     """SURVEY.md §8d config 5 shape: 512 x 512 grid, 20 points per voxel, 200 k uniform points per frame, the 60 k voxel
     cap hit in both frames (several pillars per wave, batch > 1 row lookup, P < 32)."""
