@@ -27,6 +27,8 @@ struct VoxWs {
     int *frame_base;   // [B+1] rank of the first voxel of each frame (uncapped)
     unsigned long long *tile_state;   // [tiles]
     int *ticket;       // [1]
+    unsigned long long *cell_pack;    // [B*ncell] one-launch index kernel only: {rank, point count, arena offset} of an occupied cell, 20 bits each
+    int *sync;         // [8 + 64] one-launch index kernel: the 8-byte XCD census of barrier 1, the exit counter, barrier 2's flag per owner (idle: 0; the kernel returns them to 0)
 };
 
 static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell) {
@@ -45,12 +47,14 @@ static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell) 
     w.frame_base = c.take<int>(batch + 1);
     w.tile_state = c.take<unsigned long long>(hvpr_cdiv(n > 0 ? n : 1, kScanTile));
     w.ticket = c.take<int>(1);
+    w.cell_pack = c.take<unsigned long long>((size_t)batch * ncell);
+    w.sync = c.take<int>(8 + 64);
     return w;
 }
 
 static inline size_t hvpr_vox_ws_bytes(int batch, int n, long long ncell) {
     VoxWs w = hvpr_vox_carve(nullptr, batch, n, ncell);
-    return (size_t)((char *)(w.ticket) - (char *)nullptr) + 256;
+    return (size_t)((char *)(w.sync) - (char *)nullptr) + 256;
 }
 
 // The dense BEV canvases of the fused encode path are cleared by EXTRA workgroups of the pillar-VFE launch (47 MB at

@@ -1,5 +1,7 @@
 """GPU parity: voxelizer (bit-exact), pillar VFE, memory read-out, scatter — HIP through the C-ABI vs the oracle."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -398,7 +400,10 @@ def test_encode_fused_capacity_below_the_voxel_count_truncates(case):
         sc[c[:, 0], :, c[:, 2], c[:, 3]] = 0
         assert torch.equal(r["spatial"], sp) and torch.equal(r["spatial_scale"], sc), cap
     again = kernels.encode_fwd(tp, offs, B, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1)   # workspace idle again
-    assert all(torch.equal(again[k], full[k]) for k in ("coords", "pillar_features", "spatial", "spatial_scale"))
+    torch.cuda.synchronize()
+    assert torch.equal(again["voxel_offsets"], full["voxel_offsets"])
+    assert all(torch.equal(again[k][:m], full[k][:m]) for k in ("coords", "num_points", "pillar_features", "memory_features"))
+    assert torch.equal(again["spatial"], full["spatial"]) and torch.equal(again["spatial_scale"], full["spatial_scale"])
 
 
 def test_encode_fused_dense_scene_config5():
@@ -475,3 +480,17 @@ def test_encode_fused_stress_shapes(P):
         _encode_both([heavy, base[:100], heavy[::-1].copy()], 500, cap_mode=cap_mode, P=P)
         _encode_both([heavy], 40000, cap_mode=cap_mode, P=P)
     _check_voxelize([heavy, base[:100]], P, 40000)
+
+
+@pytest.mark.parametrize("env", [{"HVPR_INDEX_FUSED": "0"}, {"HVPR_INDEX_AGENT": "1"}], ids=["three_launches", "one_launch_device_scope"])
+def test_encode_other_index_forms_in_a_child_process(env):
+    """The index phase of hvpr_encode_fwd_f32 has two forms — K1 / K2 / K3 as three launches (what more than 32 768 points take;
+    forced here for the small cases too) and the one-launch kernel, whose hand-offs stay in one XCD's L2 when its owners share
+    that XCD and are device-scope otherwise (forced here: the placement-independent path must give the same bits).  The switch
+    is read once per process, hence the child."""
+    if os.environ.get("HVPR_INDEX_CHILD"):
+        pytest.skip("already the child")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "encode_fused_equals or voxel_cap or capacity or stress or persistent"],
+                       env={**os.environ, **env, "HVPR_INDEX_CHILD": "1"}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
