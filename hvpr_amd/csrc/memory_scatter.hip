@@ -73,8 +73,14 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     constexpr int kSeg = 12;                        // candidate slots per (pillar, virtual wave); 1.6 expected, more than kSeg: slow path
     constexpr int kSlots = 4;                       // lanes per segment when the pillar's list is put together
     __shared__ int s_cnt[kPillars * kWaves];                                 // hits of wave w for pillar p: [p][w]
-    __shared__ int s_cand[kPillars * kWaves * kSeg];                         // their item ids: [p][w][slot]
-    __shared__ __attribute__((aligned(16))) int s_list[WAVES * 64 * 2];      // per physical wave: candidate list, then (index, weight) of the selected
+    // their item ids: [p][w][slot]; once every wave is through with them the same 12 KB hold the exact logits of ALL items of one
+    // pillar (the rare exact path at the end)
+    __shared__ union { int cand[kPillars * kWaves * kSeg]; float logit[kItemsPad]; } s_u;
+    int *const s_cand = s_u.cand;
+    __shared__ int s_tot[kPillars], s_flag[kPillars];                        // candidates of a pillar over all waves; 1: no filtered path for it
+    __shared__ int s_list[WAVES * 64];                                       // per physical wave: candidate ids of a round
+    __shared__ __attribute__((aligned(16))) unsigned long long s_key[WAVES * (kPillars / WAVES) * 64];   // per wave and slot: their (order bits of the exact logit, ~id), zero padded
+    __shared__ __attribute__((aligned(8))) int2 s_top[WAVES * 64];           // per physical wave: [slot][rank] (id, logit / weight) of the k selected
     if (m_device) M = min(M, *m_device);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p0 = blockIdx.x * kPillars;
@@ -115,6 +121,9 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     const float wsum = wmax[kC], wtop = wmax[kC + 1];     // sum_c wmax_c, max_c wmax_c (k_wmax_stats)
 #pragma unroll
     for (int j = 0; j < kFeat; ++j) s_f[tid + j * kThreads] = fv[j];
+#pragma unroll
+    for (int h = 0; h < PPW; ++h) s_key[(wid * PPW + h) * 64 + lane] = 0ull;     // step 4's key lists end in zeros
+    if (tid < kPillars) { s_tot[tid] = 0; s_flag[tid] = 0; }
     __syncthreads();
     RO_STAMP(1);
 
@@ -178,7 +187,6 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     RO_STAMP(3);
 
     // ---- step 2: wave w -> thresholds of its pillars w (, w + 8) ----
-    unsigned exact_all = 0u;    // bit j: the wave's j-th pillar is outside the fp16 range: no pre-filter
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int p = wid + WAVES * j;
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
             if (!(fa <= kHalfMax)) term = INFINITY;                          // (rides the sum: no second reduction)
             float eps2 = 2.f * (hvpr_reduce_sum<64>(term) + kAbsErr * wsum + 1e-30f);
             if (!(wtop <= kHalfMax)) eps2 = INFINITY;
-            if (!(eps2 < INFINITY)) exact_all |= 1u << j;
+            if (!(eps2 < INFINITY) && lane == 0) s_flag[p] = 1;      // outside the fp16 range: no pre-filter for this pillar
             // tau <= k-th largest of the 64 lane maxima (its 16 leading bits): a lower bound of the k-th largest A
             const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(s_pm[p * 64 + lane]), k));
             // tau = -inf or eps2 = inf / NaN let every live item through; the -inf padding past n_items never passes
@@ -215,7 +223,11 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
         // position inside the (pillar, virtual wave) segment: the lanes of the lower quarters first
         const int c1 = __shfl_up(mine, 16, 64), c2 = __shfl_up(mine, 32, 64), c3 = __shfl_up(mine, 48, 64);
         int pos = (q >= 1 ? c1 : 0) + (q >= 2 ? c2 : 0) + (q >= 3 ? c3 : 0);
-        if (q == 3) s_cnt[l15 * kWaves + v] = pos + mine;
+        if (q == 3) {
+            s_cnt[l15 * kWaves + v] = pos + mine;
+            atomicAdd(&s_tot[l15], pos + mine);
+            if (pos + mine > kSeg) s_flag[l15] = 1;
+        }
         int *seg = s_cand + (l15 * kWaves + v) * kSeg;
         while (__ballot(hits != 0u) != 0ull) {
             if (hits != 0u) {
@@ -230,192 +242,281 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     __syncthreads();
     RO_STAMP(7);
 
-    // ---- step 4: one wave per pillar (WAVES = 8: the wave's two pillars in turn) ----
+    // ---- step 4: the per-pillar step, ONE instruction stream for the wave's pillars (WAVES = 8: two pillars together) ----
+    // Pillar slot h of the wave is pillar wid + WAVES h.  The candidates of both slots share the wave's 64 candidate lanes (slot 0's
+    // first) and get their exact logits from ONE batch of loads — four lanes per candidate, whose 16 bank-row values each stay in
+    // registers; they are ranked inside their own pillar by counting (lane = candidate walks its pillar's zero-padded key list in
+    // LDS, two keys per read: no per-pillar radix select on the scalar unit); the k best leave (id, logit) by rank in a table, the
+    // softmax runs with lane = (slot, rank), and the weighted sum of the selected rows is taken from the registers of the exact
+    // pass (weight 0 for the unselected) by a vector-halving butterfly over the 16 candidate lanes that share a channel block —
+    // the bank rows are fetched once, a wave's chain has ONE memory round trip whatever PPW is.
+    int *const list = s_list + wid * 64;                                     // candidate ids of the round, joint positions
+    unsigned long long *const keys = s_key + wid * (PPW * 64);               // [slot][64] (order bits of L, ~id), zero padded
+    int2 *const top = s_top + wid * 64;                                      // [slot][rank] -> (id, L bits, then weight bits)
+    const int hrow = lane >> 4, hh = lane >> 5;
+    // candidate counts: row h of the wave (lanes 16 h ..) looks at the 16 virtual-wave segments of slot h
+    const int p_row = wid + WAVES * hrow;
+    const int cw = (hrow < PPW && p_row < np) ? s_cnt[p_row * kWaves + (lane & 15)] : 0;
+    // the pillars of the workgroup without a filtered path: the same word in every wave
+    const unsigned slowm = (unsigned)__ballot(lane < np && (s_flag[lane & 15] != 0 || s_tot[lane & 15] > 64)) & 0xffffu;
+    int pf = cw;                                          // inclusive prefix inside every 16-lane row
+    pf += __builtin_amdgcn_update_dpp(0, pf, 0x111, 0xf, 0xf, true);
+    pf += __builtin_amdgcn_update_dpp(0, pf, 0x112, 0xf, 0xf, true);
+    pf += __builtin_amdgcn_update_dpp(0, pf, 0x114, 0xf, 0xf, true);
+    pf += __builtin_amdgcn_update_dpp(0, pf, 0x118, 0xf, 0xf, true);
+    int cnt_s[2];
+    bool slow_s[2], live_s[2];
+    int4 cpos_s[2];
 #pragma unroll
-    for (int st = 0; st < PPW; ++st) {      // (unrolled: as a loop the body spills 170 registers)
-        const int p = wid + WAVES * st;
-        if (p >= np) break;
-        int *list = s_list + wid * 128;
-        // (requested here, needed at the very end: off the chain)
-        int4 cpos = make_int4(-1, 0, -1, -1);
-        if (cell_map || canvas) cpos = coords[p0 + p];
-        // candidate list of the pillar: the 16 wave segments back to back
-        int cw = lane < kWaves ? s_cnt[p * kWaves + lane] : 0;
-        const bool over = __ballot(cw > kSeg) != 0ull;
-        int pf = cw;                                      // inclusive prefix over lanes 0..15 (one DPP row)
-        pf += __builtin_amdgcn_update_dpp(0, pf, 0x111, 0xf, 0xf, true);
-        pf += __builtin_amdgcn_update_dpp(0, pf, 0x112, 0xf, 0xf, true);
-        pf += __builtin_amdgcn_update_dpp(0, pf, 0x114, 0xf, 0xf, true);
-        pf += __builtin_amdgcn_update_dpp(0, pf, 0x118, 0xf, 0xf, true);
-        int cnt = __builtin_amdgcn_readlane(pf, 15);
-        if (over || ((exact_all >> st) & 1u)) cnt = 65;
-        if (cnt <= 64) {
-            const int w2 = lane / kSlots, s2 = lane % kSlots;      // lane (wave segment, slot)
-            const int cw2 = __shfl(cw, w2, 64), base2 = __shfl(pf - cw, w2, 64);
+    for (int h = 0; h < 2; ++h) {
+        live_s[h] = h < PPW && wid + WAVES * h < np;
+        cnt_s[h] = h < PPW ? __builtin_amdgcn_readlane(pf, 16 * h + 15) : 0;
+        slow_s[h] = live_s[h] && ((slowm >> (wid + WAVES * h)) & 1u);
+        // (the pillar's coordinates: requested here through the scalar unit, looked at only at the very end — off the chain)
+        cpos_s[h] = make_int4(-1, 0, -1, -1);
+        if ((cell_map || canvas) && live_s[h]) cpos_s[h] = coords[__builtin_amdgcn_readfirstlane(p0 + wid + WAVES * h)];
+    }
+    const bool joint = PPW == 2 && live_s[0] && live_s[1] && !slow_s[0] && !slow_s[1] && cnt_s[0] + cnt_s[1] <= 64;
+    // softmax over the k selected exact logits of a round's slots, lane = (slot, rank): two DPP reductions inside the 32-lane
+    // halves; the table then holds (id, weight), ranks past kk item 0 with weight 0
+    auto softmax_ranks = [&](bool both, int sa, int kk_a, int kk_b) {
+        const int r = lane & 31;
+        const bool mine = both || hh == sa;                                // this half's slot belongs to the round
+        const int kk = mine ? (hh == sa ? kk_a : kk_b) : 0;
+        const int2 me = r < kk ? top[hh * 32 + r] : make_int2(0, 0);
+        const float logit = r < kk ? __int_as_float(me.y) : -INFINITY;
+        const float mx = hvpr_reduce<32>(logit, op_maxr());
+        const float e = r < kk ? __expf(logit - mx) : 0.f;
+        const float a = e / hvpr_reduce_sum<32>(e);
+        if (mine) top[hh * 32 + r] = make_int2(me.x, __float_as_int(r < kk ? a : 0.f));
+        if (topk_idx && r < kk) topk_idx[(size_t)(p0 + wid + WAVES * hh) * k + r] = me.x;
+    };
+    RO_STAMP(8);
+#pragma unroll 1
+    for (int round = 0; round < PPW; ++round) {            // ONE copy of the body; the slot's values are picked by scalar selects
+        if (joint && round == 1) break;
+        const int sa = round;                              // first (or only) slot of the round
+        const bool live_a = sa ? live_s[1] : live_s[0], slow_a = sa ? slow_s[1] : slow_s[0];
+        const int na = sa ? cnt_s[1] : cnt_s[0];
+        if (!live_a || slow_a) continue;
+        // (everything below is recomputed per round from this copy of the lane id: hoisted out of the loop, the addresses of
+        // the body are spilled)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const bool both = joint;                           // the round also serves slot 1: its candidates follow slot 0's
+        const int nb = both ? cnt_s[1] : 0, tot = na + nb;
+        const int kk_a = min(k, na), kk_b = both ? min(k, nb) : 0;
+        // the candidate lists: the 16 wave segments of a slot back to back, lane = (segment, slot in the segment)
+        {
+            const int w2 = ln / kSlots, s2 = ln % kSlots;
 #pragma unroll
-            for (int r = 0; r < kSeg / kSlots; ++r)
-                if (s2 + kSlots * r < cw2) list[base2 + s2 + kSlots * r] = s_cand[(p * kWaves + w2) * kSeg + s2 + kSlots * r];
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !both) break;
+                const int h = sa + u, pp = wid + WAVES * h;
+                const int cw2 = __shfl(cw, 16 * h + w2, 64), base2 = (u ? na : 0) + __shfl(pf - cw, 16 * h + w2, 64);
+#pragma unroll
+                for (int r = 0; r < kSeg / kSlots; ++r)
+                    if (s2 + kSlots * r < cw2) list[base2 + s2 + kSlots * r] = s_cand[(pp * kWaves + w2) * kSeg + s2 + kSlots * r];
+            }
         }
-        RO_STAMP(8);
-        // From here lane c < 64 owns candidate c: its item id, its exact logit, whether it is selected, its softmax weight.
-        int my_idx = 0;
-        float L = -INFINITY;
-        bool sel = false;
-        if (cnt <= 64) {
-            my_idx = lane < cnt ? list[lane] : 0;
-            // exact logits, FOUR LANES PER CANDIDATE: lane (c4, qq) reads channels 16 qq .. 16 qq + 15 of candidate 16 g + c4
-            // (a lane per candidate would touch 64 cache lines per load instruction: measured 25 % slower than rounds 1-3),
-            // four fma chains each, the quad is summed by two DPP exchanges, then the sums move to lane = candidate
-            const int c4 = lane >> 2, qq = lane & 3;
-            float4 fq[4];
+        // lane c owns candidate c of the round
+        const bool second = ln >= na;
+        const int my_idx = ln < tot ? list[ln] : 0;
+        // exact logits, FOUR LANES PER CANDIDATE: lane (c4, qq) reads channels 16 qq .. 16 qq + 15 of candidate 16 g + c4 (a lane
+        // per candidate would touch 64 cache lines per load instruction), four fma chains each against the features of the
+        // candidate's OWN pillar, the quad is summed by two DPP exchanges, then the sums move to lane = candidate: a candidate's
+        // logit does not depend on where it sits.  Candidates 0..31 are requested at once, unconditionally; 32..63 only when
+        // there are that many
+        const int c4 = ln >> 2, qq = ln & 3;
+        float4 rv[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fq[i] = *(const float4 *)(s_f + p * kC + 16 * qq + 4 * i);
-            // candidates 0..31 (two groups of 16) are requested at once, unconditionally; 32..63 only when there are that many
-            float4 rv[4][4];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int id = 16 * g + c4 < cnt ? list[16 * g + c4] : 0;
+        for (int g = 0; g < 4; ++g) {
+            if (g < 2 || tot > 32) {      // wave-uniform
+                const int cc = 16 * g + c4;
+                const int id = cc < tot ? list[cc] : 0;
                 const float4 *rowp = (const float4 *)(bank + (size_t)id * kC + 16 * qq);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rv[g][i] = rowp[i];
             }
-            if (cnt > 32) {
+        }
+        float L = -INFINITY;
 #pragma unroll
-                for (int g = 2; g < 4; ++g) {
-                    const int id = 16 * g + c4 < cnt ? list[16 * g + c4] : 0;
-                    const float4 *rowp = (const float4 *)(bank + (size_t)id * kC + 16 * qq);
+        for (int g = 0; g < 4; ++g) {
+            if (g < 2 || tot > 32) {
+                const int pcg = wid + WAVES * (sa + ((both && 16 * g + c4 >= na) ? 1 : 0));
+                const float4 *fp = (const float4 *)(s_f + pcg * kC + 16 * qq);
+                float4 fq = fp[0];
+                float a0 = rv[g][0].x * fq.x, a1 = rv[g][0].y * fq.y, a2 = rv[g][0].z * fq.z, a3 = rv[g][0].w * fq.w;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rv[g][i] = rowp[i];
+                for (int i = 1; i < 4; ++i) {
+                    fq = fp[i];
+                    a0 = fmaf(rv[g][i].x, fq.x, a0); a1 = fmaf(rv[g][i].y, fq.y, a1);
+                    a2 = fmaf(rv[g][i].z, fq.z, a2); a3 = fmaf(rv[g][i].w, fq.w, a3);
                 }
+                float sq = (a0 + a1) + (a2 + a3);
+                sq += hvpr_dpp<0xB1>(sq);    // quad_perm [1,0,3,2]
+                sq += hvpr_dpp<0x4E>(sq);    // quad_perm [2,3,0,1]
+                const float t = __shfl(sq, 4 * (ln & 15), 64);
+                if ((ln >> 4) == g) L = t;
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 2 || cnt > 32) {      // wave-uniform
-                    float a0 = rv[g][0].x * fq[0].x, a1 = rv[g][0].y * fq[0].y, a2 = rv[g][0].z * fq[0].z, a3 = rv[g][0].w * fq[0].w;
-#pragma unroll
-                    for (int i = 1; i < 4; ++i) {
-                        a0 = fmaf(rv[g][i].x, fq[i].x, a0); a1 = fmaf(rv[g][i].y, fq[i].y, a1);
-                        a2 = fmaf(rv[g][i].z, fq[i].z, a2); a3 = fmaf(rv[g][i].w, fq[i].w, a3);
-                    }
-                    float sq = (a0 + a1) + (a2 + a3);
-                    sq += hvpr_dpp<0xB1>(sq);    // quad_perm [1,0,3,2]
-                    sq += hvpr_dpp<0x4E>(sq);    // quad_perm [2,3,0,1]
-                    const float t = __shfl(sq, 4 * (lane & 15), 64);
-                    if ((lane >> 4) == g) L = t;
-                }
-            }
-            if (lane >= cnt) L = -INFINITY;
-            const unsigned long long key = lane < cnt ? (((unsigned long long)ord_bits(L) << 32) | (unsigned)(0xffffffffu - (unsigned)my_idx)) : 0ull;
-            const int kk = min(k, cnt);
-            // select on the 32 value bits; the 32 index bits only matter when equal values straddle the k-th place
-            const unsigned hi = (unsigned)(key >> 32);
-            const unsigned kth_hi = wave_kth_largest_u32(hi, kk);
-            const int n_gt = __popcll(__ballot(hi > kth_hi)), n_eq = __popcll(__ballot(key != 0ull && hi == kth_hi));
-            if (n_gt + n_eq == kk) {
-                sel = key != 0ull && hi >= kth_hi;
-            } else {
-                const unsigned long long kth = wave_kth_largest_u64(key, kk);
-                sel = key != 0ull && key >= kth;
-            }
-        } else {
-            // exact slow path (mass ties, values outside the fp16 range): the exact logit of EVERY item (the same four partial
-            // sums, one lane per item), then k rounds of wave arg-max with (value desc, index asc) order; winner r goes to lane r
-            float v[kItemsPad / 64];
-#pragma unroll 1
-            for (int t = 0; t < kItemsPad / 64; ++t) {
-                const int j = 64 * t + lane;
-                float s = -INFINITY;
+        }
+        // rank inside the pillar by (L desc, id asc): the number of its candidates that come before this one.  Every slot has
+        // its own key list, zero beyond its end (zero is below every key): all lanes walk max(na, nb) entries, two per read
+        const unsigned long long key = ((unsigned long long)ord_bits(L) << 32) | (unsigned)(0xffffffffu - (unsigned)my_idx);
+        unsigned long long *const kp = keys + 64 * (sa + ((both && second) ? 1 : 0));
+        if (ln < tot) kp[ln - (second ? na : 0)] = key;
+        int rank = 0;
+        const int lim = na > nb ? na : nb;                 // (lists are 64 long: walking on to a multiple of 8 reads zeros)
+        for (int j = 0; j < lim; j += 8) {                 // four reads in flight per trip: a lone wave waits for LDS, not for issue
+            const ulonglong2 k0 = *(const ulonglong2 *)(kp + j), k1 = *(const ulonglong2 *)(kp + j + 2);
+            const ulonglong2 k2 = *(const ulonglong2 *)(kp + j + 4), k3 = *(const ulonglong2 *)(kp + j + 6);
+            rank += (k0.x > key ? 1 : 0) + (k0.y > key ? 1 : 0) + (k1.x > key ? 1 : 0) + (k1.y > key ? 1 : 0);
+            rank += (k2.x > key ? 1 : 0) + (k2.y > key ? 1 : 0) + (k3.x > key ? 1 : 0) + (k3.y > key ? 1 : 0);
+        }
+        if (ln < tot && rank < (second ? kk_b : kk_a)) top[(sa + (second ? 1 : 0)) * 32 + rank] = make_int2(my_idx, __float_as_int(L));
+        softmax_ranks(both, sa, kk_a, kk_b);
+    }
+    // ---- the rare pillars that cannot take the filtered path (mass ties, values outside the fp16 range, more than 64 candidates or
+    // more than kSeg in one segment), handled by the WHOLE workgroup one after the other: every wave knows the same set (flags
+    // and totals in LDS since the last barrier), so the barriers below are taken by all waves or by none.  All threads put the
+    // exact logit of EVERY item (four partial sums, one thread per item) into the 12 KB the candidate segments no longer need; the
+    // pillar's own wave then takes k rounds of arg-max with (value desc, index asc) order, winner r to rank r of its table.
+    // (Inline in the common path, this path's 32 registers of logits per lane cost the kernel ~200 B of scratch per lane — and
+    // a read-out that uses scratch at all runs 25 % slower: 171 against 135 us at batch 16.) ----
+    if (slowm != 0u) {
+        __syncthreads();                                   // every wave is through with the candidate segments
+        for (unsigned left = slowm; left != 0u; left &= left - 1u) {
+            const int p = __ffs((int)left) - 1;
+            for (int j = tid; j < kItemsPad; j += kThreads) {
+                float sacc = -INFINITY;
                 if (j < n_items) {
                     const float4 *rowp = (const float4 *)(bank + (size_t)j * kC);
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
                     for (int i = 0; i < kC / 4; ++i) {
-                        const float4 rv = rowp[i];
-                        const float4 fv = *(const float4 *)(s_f + p * kC + 4 * i);
-                        a0 = fmaf(rv.x, fv.x, a0); a1 = fmaf(rv.y, fv.y, a1); a2 = fmaf(rv.z, fv.z, a2); a3 = fmaf(rv.w, fv.w, a3);
+                        const float4 rw = rowp[i];
+                        const float4 fv4 = *(const float4 *)(s_f + p * kC + 4 * i);
+                        a0 = fmaf(rw.x, fv4.x, a0); a1 = fmaf(rw.y, fv4.y, a1); a2 = fmaf(rw.z, fv4.z, a2); a3 = fmaf(rw.w, fv4.w, a3);
                     }
-                    s = (a0 + a1) + (a2 + a3);
+                    sacc = (a0 + a1) + (a2 + a3);
                 }
-                v[t] = s;
+                s_u.logit[j] = sacc;
             }
-            unsigned long long prev = ~0ull, key = 0ull;
-            for (int r = 0; r < k; ++r) {
-                unsigned long long best = 0ull;
+            __syncthreads();
+            if (wid == p % WAVES) {
+                const int sa = p / WAVES;
+                unsigned long long prev = ~0ull;
+                for (int r = 0; r < k; ++r) {
+                    unsigned long long best = 0ull;
+#pragma unroll 4
+                    for (int t = 0; t < kItemsPad / 64; ++t) {
+                        const unsigned long long c = ((unsigned long long)ord_bits(s_u.logit[64 * t + lane]) << 32) |
+                                                     (unsigned)(0xffffffffu - (unsigned)(lane + 64 * t));
+                        if (c < prev && c > best && lane + 64 * t < n_items) best = c;
+                    }
 #pragma unroll
-                for (int t = 0; t < kItemsPad / 64; ++t) {
-                    const unsigned long long c = ((unsigned long long)ord_bits(v[t]) << 32) |
-                                                 (unsigned)(0xffffffffu - (unsigned)(lane + 64 * t));
-                    if (c < prev && c > best && lane + 64 * t < n_items) best = c;
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
+                        const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
+                        const unsigned long long ob = ((unsigned long long)hi << 32) | lo;
+                        best = ob > best ? ob : best;
+                    }
+                    if (lane == 0)
+                        top[sa * 32 + r] = make_int2((int)(0xffffffffu - (unsigned)(best & 0xffffffffull)),
+                                                     __float_as_int(ord_to_float((unsigned)(best >> 32))));
+                    prev = best;
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned lo = __shfl_xor((unsigned)(best & 0xffffffffull), o, 64);
-                    const unsigned hi = __shfl_xor((unsigned)(best >> 32), o, 64);
-                    const unsigned long long ob = ((unsigned long long)hi << 32) | lo;
-                    best = ob > best ? ob : best;
-                }
-                if (lane == r) key = best;
-                prev = best;
+                softmax_ranks(false, sa, k, 0);
             }
-            sel = lane < k && key != 0ull;
-            L = sel ? ord_to_float((unsigned)(key >> 32)) : -INFINITY;
-            my_idx = sel ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffull)) : 0;
+            __syncthreads();                               // the buffer is free for the next such pillar
         }
-        RO_STAMP(9);
-        // softmax over the selected exact logits, in place: two DPP wave reductions (unselected lanes carry -inf / 0)
-        const float logit = sel ? L : -INFINITY;
-        const float mx = hvpr_reduce<64>(logit, op_maxr());
-        const float e = sel ? __expf(logit - mx) : 0.f;
-        const float a = e / hvpr_reduce_sum<64>(e);
-        const unsigned long long selmask = __ballot(sel);
-        const int rank = __popcll(selmask & ((1ull << lane) - 1ull));
-        const int nsel = __popcll(selmask);
-        if (topk_idx && sel) topk_idx[(size_t)(p0 + p) * k + rank] = my_idx;
-        long long cell = -1;           // fused a3+a4: this pillar's BEV cell (pointpillar_scatter.py:192, nz == 1)
-        if (cell_map || canvas) {
-            const int4 c = cpos;
+    }
+    RO_STAMP(9);
+    // ---- weighted sum of the selected rows for all of the wave's slots at once, lane = (slot, channel pair), in rank order (a
+    // fixed function of the pillar: not of its place in the wave or the batch); all loads in flight at once (ranks past k carry
+    // item 0 with weight 0; rows past 16 / 24 are skipped as a block) ----
+    if (PPW == 1) {
+        // one pillar per wave: lane = channel; the (id, weight) pairs sit in lanes 0..31 and reach the loads / fmas through the
+        // scalar unit.  Per channel the same sequence of fmas, in rank order, as the two-pillar form below: the same bits
+        if (live_s[0]) {
+            const int2 mine = top[lane & 31];
+            float rows[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
+            if (k > 16) {
+#pragma unroll
+                for (int r = 16; r < 24; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
+            }
+            if (k > 24) {
+#pragma unroll
+                for (int r = 24; r < 32; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
+            }
+            float o = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
+            if (k > 16) {
+#pragma unroll
+                for (int r = 16; r < 24; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
+            }
+            if (k > 24) {
+#pragma unroll
+                for (int r = 24; r < 32; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
+            }
+            out[(size_t)(p0 + wid) * kC + lane] = o;
+            const int4 c = cpos_s[0];
+            long long cell = -1;
             if ((unsigned)c.x < (unsigned)batch && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx)
                 cell = ((long long)c.x * ny + c.z) * nx + c.w;
-            if (cell_map && lane == 0 && cell >= 0) cell_map[cell] = p0 + p;   // gather-form scatter: k_cell_map's job
+            if (cell_map && lane == 0 && cell >= 0) cell_map[cell] = p0 + wid;
+            if (canvas && cell >= 0) canvas[(size_t)cell * canvas_channels + canvas_offset + lane] = o;
         }
-        // the selected (index, weight) pairs move to the first lanes, then lane = channel: weighted sum of their rows
-        if (sel) { list[2 * rank] = my_idx; list[2 * rank + 1] = __float_as_int(a); }
-        const int2 mine = lane < nsel ? *(const int2 *)(list + 2 * lane) : make_int2(0, 0);
-        // (lanes past nsel carry item 0 with weight 0: the loads go out unconditionally, all in flight at once; rows past k
-        // are skipped as a block)
-        float rows[32];
+    } else
+    {
+        const bool half_live = hh < PPW && wid + WAVES * hh < np;
+        const int cp2 = 2 * (lane & 31);
+        const int2 *tp = top + hh * 32;
+        float2 rows[32];
+        if (half_live) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
-        if (nsel > 16) {
+            for (int r = 0; r < 16; ++r) rows[r] = *(const float2 *)(bank + (size_t)tp[r].x * kC + cp2);
+            if (k > 16) {
 #pragma unroll
-            for (int r = 16; r < 24; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
+                for (int r = 16; r < 24; ++r) rows[r] = *(const float2 *)(bank + (size_t)tp[r].x * kC + cp2);
+            }
+            if (k > 24) {
+#pragma unroll
+                for (int r = 24; r < 32; ++r) rows[r] = *(const float2 *)(bank + (size_t)tp[r].x * kC + cp2);
+            }
+            float ox = 0.f, oy = 0.f;     // (the weights are read again from the table: they would cost 32 registers next to the rows)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float a = __int_as_float(tp[r].y); ox = fmaf(a, rows[r].x, ox); oy = fmaf(a, rows[r].y, oy); }
+            if (k > 16) {
+#pragma unroll
+                for (int r = 16; r < 24; ++r) { const float a = __int_as_float(tp[r].y); ox = fmaf(a, rows[r].x, ox); oy = fmaf(a, rows[r].y, oy); }
+            }
+            if (k > 24) {
+#pragma unroll
+                for (int r = 24; r < 32; ++r) { const float a = __int_as_float(tp[r].y); ox = fmaf(a, rows[r].x, ox); oy = fmaf(a, rows[r].y, oy); }
+            }
+            const int pp = wid + WAVES * hh;
+            *(float2 *)(out + (size_t)(p0 + pp) * kC + cp2) = make_float2(ox, oy);
+            // fused encode path: the memory channels of this pillar's cell, straight into the pre-cleared NHWC canvas
+            // fused a3+a4: this slot's BEV cell (pointpillar_scatter.py:192, nz == 1)
+            const int4 c = hh ? cpos_s[1] : cpos_s[0];
+            long long cell = -1;
+            if ((unsigned)c.x < (unsigned)batch && (unsigned)c.z < (unsigned)ny && (unsigned)c.w < (unsigned)nx)
+                cell = ((long long)c.x * ny + c.z) * nx + c.w;
+            if (cell_map && (lane & 31) == 0 && cell >= 0) cell_map[cell] = p0 + pp;   // gather-form scatter: k_cell_map's job
+            if (canvas && cell >= 0) *(float2 *)(canvas + (size_t)cell * canvas_channels + canvas_offset + cp2) = make_float2(ox, oy);
         }
-        if (nsel > 24) {
-#pragma unroll
-            for (int r = 24; r < 32; ++r) rows[r] = bank[(size_t)__builtin_amdgcn_readlane(mine.x, r) * kC + lane];
-        }
-        float o = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
-        if (nsel > 16) {
-#pragma unroll
-            for (int r = 16; r < 24; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
-        }
-        if (nsel > 24) {
-#pragma unroll
-            for (int r = 24; r < 32; ++r) o = fmaf(__int_as_float(__builtin_amdgcn_readlane(mine.y, r)), rows[r], o);
-        }
-        out[(size_t)(p0 + p) * kC + lane] = o;
-        // fused encode path: the memory channels of this pillar's cell, straight into the pre-cleared NHWC canvas
-        if (canvas && cell >= 0) canvas[(size_t)cell * canvas_channels + canvas_offset + lane] = o;
-#ifdef HVPR_EXP_TIMING
-        RO_STAMP(10);
-        if ((blockIdx.x == 3 || blockIdx.x == 100) && lane == 0 && (wid & 7) == 0 && st == 0)
-            printf("readout wg %d wave %d: features %lld | logits %lld | bar %lld | tau %lld | bar %lld | hits %lld | bar %lld | list %lld (cands %d) | "
-                   "exact+topk %lld | softmax+gather %lld cycles\n", (int)blockIdx.x, wid, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3],
-                   ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6], ts[8] - ts[7], cnt, ts[9] - ts[8], ts[10] - ts[9]);
-#endif
     }
+#ifdef HVPR_EXP_TIMING
+    RO_STAMP(10);
+    if ((blockIdx.x == 3 || blockIdx.x == 100) && lane == 0 && (wid & 7) == 0)
+        printf("readout wg %d wave %d: features %lld | logits %lld | bar %lld | tau %lld | bar %lld | hits %lld | bar %lld | counts %lld (cands %d + %d%s) | "
+               "rounds %lld | rows %lld cycles\n", (int)blockIdx.x, wid, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3],
+               ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6], ts[8] - ts[7], cnt_s[0], cnt_s[1], joint ? " joint" : "", ts[9] - ts[8], ts[10] - ts[9]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
