@@ -420,7 +420,10 @@ def main():
         n_dev = torch.cuda.device_count()
         if n_dev < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
-        sys.exit(distributed.launch_local(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+        # a rank that hangs (a collective nobody else joins) must not hold the node: everything is ended after HVPR_BENCH_TIMEOUT
+        # seconds (default 40 min: N = 8 needs ~6 min including the DDP train-step line)
+        sys.exit(distributed.launch_local(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
+                                          timeout=float(os.environ.get("HVPR_BENCH_TIMEOUT", "2400"))))
     rank, local_rank, world = distributed.env_rank()
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")

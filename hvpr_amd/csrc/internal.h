@@ -31,7 +31,7 @@ struct VoxWs {
     int *sync;         // [8 + 64] one-launch index kernel: the 8-byte XCD census of barrier 1, the exit counter, barrier 2's flag per owner (idle: 0; the kernel returns them to 0)
 };
 
-static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell) {
+static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell, size_t *bytes = nullptr) {
     hvpr_carver c(ws);
     VoxWs w;
     w.cell_first = c.take<int>((size_t)batch * ncell);
@@ -49,12 +49,14 @@ static inline VoxWs hvpr_vox_carve(void *ws, int batch, int n, long long ncell) 
     w.ticket = c.take<int>(1);
     w.cell_pack = c.take<unsigned long long>((size_t)batch * ncell);
     w.sync = c.take<int>(8 + 64);
+    if (bytes) *bytes = c.off;        // everything that was carved: the size is never a guess about the last field
     return w;
 }
 
 static inline size_t hvpr_vox_ws_bytes(int batch, int n, long long ncell) {
-    VoxWs w = hvpr_vox_carve(nullptr, batch, n, ncell);
-    return (size_t)((char *)(w.sync) - (char *)nullptr) + 256;
+    size_t bytes = 0;
+    hvpr_vox_carve(nullptr, batch, n, ncell, &bytes);
+    return bytes;
 }
 
 // The dense BEV canvases of the fused encode path are cleared by EXTRA workgroups of the pillar-VFE launch (47 MB at

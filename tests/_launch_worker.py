@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hvpr_amd import distributed  # noqa: E402
 
 out_dir, mode = sys.argv[1], sys.argv[2]
+if mode == "fail_early" and int(os.environ["RANK"]) == 1:
+    sys.exit(4)         # before the rendezvous: rank 0 would wait in init_process_group for ever
 rank, local_rank, world = distributed.init("gloo")
 if mode == "fail" and rank == 1:
     sys.exit(3)

@@ -64,11 +64,16 @@ def run(wrap, sync_bn=False):
             all(p == own for p in ptrs))
 
 
-def diff(a, b):
+worst_keys = {}
+
+
+def diff(a, b, tag=""):
     worst = 0.0
     for k in a:
         if a[k].dtype.is_floating_point:
-            worst = max(worst, float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-12)))
+            d = float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-12))
+            if d > worst:
+                worst, worst_keys[tag] = d, k
         else:
             assert torch.equal(a[k], b[k]), k
     return worst
@@ -84,10 +89,10 @@ name_s, loss_s, sd_s, flat_s = run(True, sync_bn=True)
 hook_calls = conv_train._sync.get("hook_calls", 0)
 conv_train.set_sync_batchnorm(None)
 json.dump({"backend": torch.distributed.get_backend(), "seen": seen, "ddp": name_d, "plain": name_p, "losses_plain": loss_p, "losses_ddp": loss_d,
-           "losses_rerun": loss_q, "state_diff_ddp_vs_plain": diff(sd_d, sd_p), "state_diff_rerun_vs_plain": diff(sd_q, sd_p),
+           "losses_rerun": loss_q, "state_diff_ddp_vs_plain": diff(sd_d, sd_p, "ddp"), "state_diff_rerun_vs_plain": diff(sd_q, sd_p, "rerun"),
            "grads_in_flat_buffer_plain": flat_p, "grads_in_flat_buffer_ddp": flat_d,
            "losses_sync_bn": loss_s, "state_diff_sync_bn_vs_plain": diff(sd_s, sd_p), "grads_in_flat_buffer_sync_bn": flat_s,
-           "sync_bn_hook_calls": hook_calls,
+           "sync_bn_hook_calls": hook_calls, "worst_keys": worst_keys,
            "slowest": distributed.max_over_ranks(1.5, dev)}, open(out_path, "w"))
 distributed.barrier(dev)
 distributed.finalize()

@@ -259,6 +259,18 @@ def test_launch_local_propagates_a_failing_rank(tmp_path):
     assert distributed.launch_local(2, [worker, str(tmp_path), "fail"], timeout=240) != 0
 
 
+def test_launch_local_ends_the_others_when_a_rank_dies_before_the_rendezvous(tmp_path):
+    """A rank that exits before init_process_group leaves the others waiting in the rendezvous (not in a collective): the
+    launcher must end them too, well inside the rendezvous' own timeout."""
+    import time
+    from hvpr_amd import distributed
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_launch_worker.py")
+    t0 = time.time()
+    rc = distributed.launch_local(2, [worker, str(tmp_path), "fail_early"], timeout=240)
+    assert rc != 0 and rc != 124 and time.time() - t0 < 120
+    assert not os.path.exists(os.path.join(str(tmp_path), "rank0.json"))
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus N` must fail loudly when fewer than N GPUs are visible (this box has none), not run one rank."""
     import subprocess
