@@ -6,6 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 4          # hvpr_abi_version() of the library these wrappers were written against (csrc/abi.hip)
 LIB_PATH = os.environ.get("HVPR_AMD_LIB", os.path.join(_HERE, "libhvpr_amd.so"))   # override: kernel experiments only
 
 _c = ctypes
@@ -118,6 +119,9 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.hvpr_abi_version() != ABI_VERSION:      # a stale .so next to newer Python wrappers (buffer sizes, argument lists)
+            raise HvprLibraryError(f"{LIB_PATH} has ABI version {L.hvpr_abi_version()}, these wrappers need {ABI_VERSION}: "
+                                   "rebuild it with `python -m hvpr_amd.build`")
         _lib = L
     return _lib
 

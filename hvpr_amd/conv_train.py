@@ -45,13 +45,18 @@ def device_doubles(ptr, n):
 
 
 def _hook_allreduce(buf, n, stream, ctx):
-    # called by the library between two of its launches, on the thread that made the call; the kernels before it were enqueued on
-    # torch's current stream (kernels._stream()), which is also what the collective orders itself against
+    # called by the library between two of its launches, on the thread that made the call.  The collective is ordered against the
+    # stream the ENTRY POINT was given (the kernels before and after the hook run there) — torch's current stream when the call
+    # came through kernels._stream(), but a C caller may have passed any stream
     try:
         g = _sync["group"]
         if g is None or not torch.distributed.is_initialized():
             return 0
-        torch.distributed.all_reduce(device_doubles(buf, n), group=None if g is True else g)
+        if stream and int(stream) != torch.cuda.current_stream().cuda_stream:
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))):
+                torch.distributed.all_reduce(device_doubles(buf, n), group=None if g is True else g)
+        else:
+            torch.distributed.all_reduce(device_doubles(buf, n), group=None if g is True else g)
         _sync["hook_calls"] = _sync.get("hook_calls", 0) + 1
         return 0
     except Exception:        # an exception must not cross the C frame: the entry point reports HVPR_ERR_LAUNCH
@@ -80,6 +85,17 @@ def _sync_group():
     if g is None or not torch.distributed.is_available() or not torch.distributed.is_initialized():
         return None
     return None if g is True else g, True
+
+
+def any_rank_true(flag, device):
+    """`flag` (python bool) OR-ed over the ranks of the SyncBatchNorm group; `flag` itself without one.  For conditions every rank
+    must act on together because a collective follows (an empty batch on one rank)."""
+    sg = _sync_group()
+    if sg is None:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=sg[0])
+    return bool(t.item() > 0)
 
 
 def global_count(n, device):

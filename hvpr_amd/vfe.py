@@ -173,9 +173,12 @@ def _train_forward(self, batch_dict, voxels, num, coords):
     mask = (torch.arange(P, device=voxels.device).view(1, -1) < num.view(-1, 1)).unsqueeze(-1).to(voxels.dtype)
     if not (voxels.is_cuda and voxels.dtype == torch.float32):
         raise RuntimeError("hvpr_amd: PillarVFE_Scale's training forward needs fp32 GPU tensors (the HIP path has no CPU fallback)")
-    if M == 0:
+    from . import conv_train as ct
+    if ct.any_rank_true(M == 0, voxels.device):    # under SyncBatchNorm all ranks raise together: a lone raiser would leave the
+        #                                            others waiting in the statistics' all-reduce
         raise ValueError("hvpr_amd: PillarVFE_Scale's training forward got a batch without a single pillar (train-mode BatchNorm has "
-                         "no statistics to take; the reference divides by zero there)")
+                         "no statistics to take; the reference divides by zero there)" if M == 0 else
+                         "hvpr_amd: another rank's batch has no pillar — SyncBatchNorm's all-reduce cannot be joined by all ranks")
     if len(self.pfn_layers) != 2:
         raise ValueError("hvpr_amd: the VFE training kernels are built for two PFN layers (hvpr.yaml NUM_FILTERS: [32, 64])")
     l0, l1 = self.pfn_layers[0], self.pfn_layers[1]
@@ -185,7 +188,6 @@ def _train_forward(self, batch_dict, voxels, num, coords):
     x, m0, v0, m1, v1 = _PfnTrain.apply(voxels.contiguous(), _as_i32(num).contiguous(), _as_i32(coords).contiguous(),
                                         l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight,
                                         l1.norm.bias, l0.norm.eps, self.voxel_size, self.offsets)
-    from . import conv_train as ct
     cnt = ct.global_count(M * P, voxels.device)
     _update_running(l0.norm, m0, v0, cnt)
     _update_running(l1.norm, m1, v1, cnt)

@@ -34,7 +34,7 @@ enum hvpr_status {
     HVPR_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after the launch           */
 };
 
-int hvpr_abi_version(void);
+int hvpr_abi_version(void);     /* 4 (history: csrc/abi.hip); size every workspace / packed buffer with the *_bytes / *_floats functions */
 const char *hvpr_status_string(int status);
 
 /* SyncBatchNorm across ranks (reference: tools/train.py:119-120, --sync_bn -> torch.nn.SyncBatchNorm).  The training entry points

@@ -301,8 +301,13 @@ def _syncbn_worker(rank, world, port, q):
     dgamma_l, dbeta_l = (dy * xhat).sum(0), dy.sum(0)
     dg_t, db_t = conv_train.sync_backward_sums(dgamma_l, dbeta_l, n)
     dz = gamma * invstd * (dy - db_t - xhat * dg_t)
+    # a condition one rank alone sees (its batch has no pillar) must be acted on by all of them: the statistics' all-reduce follows
+    conv_train.set_sync_batchnorm(True)
+    agree = (conv_train.any_rank_true(rank == 1, torch.device("cpu")), conv_train.any_rank_true(False, torch.device("cpu")))
+    conv_train.set_sync_batchnorm(None)
+    assert conv_train.any_rank_true(rank == 1, torch.device("cpu")) == (rank == 1)       # no group: the rank's own flag
     distributed.finalize()
-    q.put((rank, y.numpy(), dz.numpy(), dgamma_l.numpy(), dbeta_l.numpy(), mean.numpy(), var.numpy(), float(n)))
+    q.put((rank, y.numpy(), dz.numpy(), dgamma_l.numpy(), dbeta_l.numpy(), mean.numpy(), var.numpy(), float(n), agree))
 
 
 def test_sync_batchnorm_two_ranks_batch1_equal_one_process_batch2():
@@ -330,8 +335,8 @@ def test_sync_batchnorm_two_ranks_batch1_equal_one_process_batch2():
     y = torch.relu(torch.nn.functional.batch_norm(x_full.permute(0, 3, 1, 2), None, None, gamma, beta, True, 0.0, 1e-3)).permute(0, 2, 3, 1)
     (y * wout).sum().backward()
     for r in range(2):
-        _, yr, dzr, _, _, mean, var, n = [torch.from_numpy(t) if hasattr(t, "dtype") else t for t in got[r]]
-        assert n == 60.0
+        _, yr, dzr, _, _, mean, var, n, agree = [torch.from_numpy(t) if hasattr(t, "dtype") else t for t in got[r]]
+        assert n == 60.0 and agree == (True, False)
         torch.testing.assert_close(yr.double().view(1, 6, 5, 8), y[r:r + 1].detach(), rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(dzr.double().view(1, 6, 5, 8), x_full.grad[r:r + 1], rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(mean.double(), x_full.detach().reshape(-1, 8).mean(0), rtol=1e-5, atol=1e-6)
