@@ -72,9 +72,21 @@ class AxisAlignedTargetAssigner:
                 "box_reg_targets": torch.cat([p[1] for p in per_class], dim=-2).reshape(B, -1, self.box_coder.code_size),
                 "reg_weights": torch.cat([p[2] for p in per_class], dim=-1).reshape(B, -1)}
 
+    FRAMES_PER_PASS = 4      # the (frames, anchors, ground truths) intermediates of one pass: ~120 MB each at 147 k anchors x 50 boxes
+
     def _assign_batch(self, anchors, gt, gt_classes, use, matched_thr, unmatched_thr):
         """anchors (A,7), gt (B,G,7), gt_classes / use (B,G) -> labels (B,A) i32, targets (B,A,7), weights (B,A) — assign_targets_single
-        (:113-213) for every frame at once."""
+        (:113-213) for FRAMES_PER_PASS frames at once: the launch count of a whole-batch pass without its peak memory (a batch of 16
+        held eight (B,A,G) intermediates of 470 MB each)."""
+        B = gt.shape[0]
+        if B <= self.FRAMES_PER_PASS:
+            return self._assign_frames(anchors, gt, gt_classes, use, matched_thr, unmatched_thr)
+        parts = [self._assign_frames(anchors, gt[b:b + self.FRAMES_PER_PASS], gt_classes[b:b + self.FRAMES_PER_PASS],
+                                     use[b:b + self.FRAMES_PER_PASS], matched_thr, unmatched_thr)
+                 for b in range(0, B, self.FRAMES_PER_PASS)]
+        return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(3))
+
+    def _assign_frames(self, anchors, gt, gt_classes, use, matched_thr, unmatched_thr):
         B, G = gt.shape[0], gt.shape[1]
         A = anchors.shape[0]
         ab = nearest_bev_boxes(anchors[:, 0:7])                                     # (A,4)
@@ -83,11 +95,13 @@ class AxisAlignedTargetAssigner:
         xr = torch.min(ab[None, :, None, 2], gb[:, None, :, 2])
         yl = torch.max(ab[None, :, None, 1], gb[:, None, :, 1])
         yr = torch.min(ab[None, :, None, 3], gb[:, None, :, 3])
-        inter = torch.clamp_min(xr - xl, 0) * torch.clamp_min(yr - yl, 0)
+        inter = xr.sub_(xl).clamp_min_(0).mul_(yr.sub_(yl).clamp_min_(0))          # (in place: xr becomes the intersection)
+        del xl, yl, yr
         area_a = (ab[:, 2] - ab[:, 0]) * (ab[:, 3] - ab[:, 1])
         area_b = (gb[:, :, 2] - gb[:, :, 0]) * (gb[:, :, 3] - gb[:, :, 1])
         iou = inter / torch.clamp_min(area_a[None, :, None] + area_b[:, None, :] - inter, 1e-6)      # (B,A,G), box_utils.py:252-272
-        iou = torch.where(use[:, None, :], iou, torch.full_like(iou, -2.0))        # masked ground truths never match
+        del inter
+        iou.masked_fill_(~use[:, None, :], -2.0)                                   # masked ground truths never match
         a2g_max, a2g_arg = iou.max(dim=2)
         g2a_max = iou.max(dim=1)[0]
         g2a_max = torch.where(g2a_max <= 0, torch.full_like(g2a_max, -1.0), g2a_max)   # no overlap at all: no forced match (:155-156)

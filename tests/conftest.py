@@ -18,3 +18,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+_OBSERVED = []
+
+
+@pytest.fixture
+def observed():
+    """observed("text"): a line for the terminal summary — margins a passing test actually used (a regression inside
+    a tolerance must be visible), shown under -q as well."""
+    return _OBSERVED.append
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _OBSERVED:
+        terminalreporter.section("observed margins")
+        for line in _OBSERVED:
+            terminalreporter.write_line(line)

@@ -39,7 +39,7 @@ def _batch(frames):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3"])
-def test_forward_one_frame_matches_oracle(model_and_params, precision):
+def test_forward_one_frame_matches_oracle(model_and_params, precision, observed):
     """The whole detector against the CPU oracle, with the SAME thresholds for the exact fp32 convolutions and for the two
     split-bf16 modes (bf16x6 = fp32 emulation, bf16x3 = three products)."""
     cfg, model, params = model_and_params
@@ -69,7 +69,9 @@ def test_forward_one_frame_matches_oracle(model_and_params, precision):
         _close(gb[..., col], rb[..., col])
     # heading: the direction bin is an argmax of two logits — compare where the bin decision is not a near-tie
     d = np.abs(gb[..., 6] - rb[..., 6])
-    assert (d < 1e-3 * np.abs(rb[..., 6]).max()).mean() > 0.999
+    off = int((d >= 1e-3 * np.abs(rb[..., 6]).max()).sum())
+    observed(f"test_gpu_e2e: headings outside 1e-3 (direction-bin near-ties): {off} of {d.size} = {off / d.size:.2e} (bar 1e-3)")
+    assert off / d.size < 1e-3
     # a8: survivors bit-exact when the oracle's post-processing is fed the GPU's own logits and boxes
     cls_gpu, box_gpu = bd["batch_cls_preds"].cpu().numpy(), gb
     scores_gpu = bd["batch_max_scores"].cpu().numpy()
@@ -81,6 +83,7 @@ def test_forward_one_frame_matches_oracle(model_and_params, precision):
     # end to end: the two pipelines keep (almost) the same boxes; fp32 round-off flips borderline suppression decisions, and
     # each flip cascades through the greedy sweep (the strict check is the one above: same logits -> identical survivors)
     a, b = set(preds[0]["selected"].cpu().numpy().tolist()), set(ref_preds[0]["selected"].tolist())
+    observed(f"test_gpu_e2e: survivors: GPU {len(a)}, oracle {len(b)}, common {len(a & b)} = {len(a & b) / max(len(a), len(b), 1):.4f} (bar 0.95)")
     assert len(a & b) >= 0.95 * max(len(a), len(b), 1), (len(a), len(b), len(a & b))
     assert 10 < len(a) <= 500
 

@@ -15,6 +15,7 @@ def test_g8_target_assignment_and_losses_on_gpu(golden_dir):
 
 def test_g8_no_ground_truth_on_gpu(golden_dir):
     C.run_g8_no_gt(golden_dir, DEV)
+    C.run_g8_batch_passes(golden_dir, DEV)
 
 
 def test_g9_onecycle_three_steps_on_gpu(golden_dir):

@@ -12,6 +12,10 @@ def test_g8_no_ground_truth_is_all_background(golden_dir):
     C.run_g8_no_gt(golden_dir)
 
 
+def test_g8_batched_assigner_passes_equal_small_batches(golden_dir):
+    C.run_g8_batch_passes(golden_dir)
+
+
 def test_g9_onecycle_schedule_and_true_weight_decay(golden_dir):
     C.run_g9(golden_dir)
 

@@ -71,6 +71,22 @@ def run_g8_no_gt(golden_dir, dev="cpu"):
     assert (t["box_cls_labels"] == 0).all() and (t["reg_weights"] == 0).all() and (t["box_reg_targets"] == 0).all()
 
 
+def run_g8_batch_passes(golden_dir, dev="cpu"):
+    """The batched assigner works through the batch FRAMES_PER_PASS frames at a time: a batch of 6 (the two fixture frames three
+    times over, the middle pair with a ground truth removed) must give, frame by frame, what batches of 2 give — which G8 pins."""
+    z = _load(golden_dir, "g8_assigner_losses.npz")
+    head = _head(z, dev)
+    gt = torch.from_numpy(z["gt_boxes"]).to(dev)
+    gt2 = gt.clone(); gt2[:, 0] = 0
+    six = head.assign_targets(torch.cat([gt, gt2, gt], dim=0))
+    assert head.target_assigner.FRAMES_PER_PASS < 6
+    for lo, g in ((0, gt), (2, gt2), (4, gt)):
+        two = head.assign_targets(g)
+        for k in ("box_cls_labels", "box_reg_targets", "reg_weights"):
+            assert torch.equal(six[k][lo:lo + 2], two[k]), (lo, k)
+    np.testing.assert_array_equal(_np(six["box_cls_labels"][:2]), z["target.box_cls_labels"])
+
+
 def run_g9(golden_dir, dev="cpu", rtol=2e-5, make_optimizer=None):
     """100 schedule steps + 3 optimiser steps; make_optimizer(net, wd) lets the GPU test run the same case through the
     fused flat-buffer kernel."""
