@@ -492,6 +492,33 @@ def main():
                         "on three HIP streams (frame latency = 3 steps)")
 
         dt_rank = dt_local[0]      # this rank's own time of the headline run (`dt` is the max over ranks)
+        # reported next to the headline, never as `value` (which stays one frame per step, hvpr_car.yaml batch = 1): the same pipeline
+        # with TWO frames per graph replay — every convolution launch sees twice the tiles (4.6 / 2.5 / 1.25 rounds of the resident
+        # workgroups instead of 2.3 / 1.25 / 0.63), frame latency doubles, per-frame results are those of batch 1 bit for bit
+        # (tests/test_gpu_e2e.py: a frame alone == the frame inside a batch)
+        two = None
+        if world == 1 and not args.no_extras and not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32":
+            def pair(i):
+                a, b = frames[i % N_POOL], frames[(i + 1) % N_POOL]
+                pts = np.concatenate([np.concatenate([np.full((len(f), 1), j, np.float32), f], 1) for j, f in enumerate((a, b))])
+                return {"points": torch.from_numpy(pts).to(device), "batch_size": 2,
+                        "point_frame_offsets": torch.tensor([0, len(a), len(a) + len(b)], dtype=torch.int32, device=device)}
+            pairs = [pair(2 * i) for i in range(N_POOL // 2)]
+            p2 = detector.PipelinedForward(model, pairs[0])
+            n2 = max(args.steps // 2, 1)
+            for i in range(max(args.warmup // 2, 4)):
+                p2(pairs[i % len(pairs)])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n2):
+                p2(pairs[i % len(pairs)])
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            for _ in p2.flush():
+                pass
+            del p2, pairs
+            two = {"value": round(2 * n2 / dt2, 2), "unit": "frames/s", "ms_per_replay_of_two_frames": round(1e3 * dt2 / n2, 4),
+                   "what": "PipelinedForward with two frames per graph replay (batch 2 through every stage); NOT `value`"}
         if args.alt and not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32":
             # reported next to the headline, never as `value`: the same pipeline with the trunk/SFM 3x3 convolutions on the bf16
             # matrix cores with split operands
@@ -677,6 +704,7 @@ def main():
                                   "with every layer on the direct kernel"},
     }
     res["alt_precision"] = alt
+    res["pipeline_two_frames_per_replay"] = two
     res["train_step_ddp"] = train_ddp
     if world == 1 and not args.no_extras:
         # driver-visible numbers for the other BASELINE.json configs (bounded step counts): the same group at batch 16 and on

@@ -67,6 +67,7 @@ static inline size_t hvpr_vox_ws_bytes(int batch, int n, long long ncell) {
 // idle while it is there.
 struct ClearJob {
     int *cell_first;              // [B * ny * nx], kIdle = empty; reset here
+    int *cell_count;              // [B * ny * nx]: returned to its idle 0 here (K3 does not when K1 handed out the slots)
     const int *cell_vid;          // rank of an occupied cell's voxel (uncapped order)
     const int *frame_base;        // [B + 1]
     const int *voxel_offsets;     // [B + 1]
@@ -92,6 +93,7 @@ __device__ __forceinline__ void hvpr_canvas_clear(const ClearJob &c, int blk, in
             if (c.state) stale = c.state[cell] != 0;
             if (c.cell_first[cell] != kIdle) {
                 c.cell_first[cell] = kIdle;
+                c.cell_count[cell] = 0;
                 const int b = (int)(cell / ((long long)c.nx * c.ny));
                 const int local = c.cell_vid[cell] - c.frame_base[b];
                 emitted = local < c.max_voxels && c.voxel_offsets[b] + local < c.capacity;

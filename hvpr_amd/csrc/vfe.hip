@@ -779,7 +779,7 @@ int hvpr_i_vfe_gather(const VoxelizeArgs &a, const VoxWs &w, const int32_t *voxe
     int idx_bits = 1;
     while (idx_bits < 22 && (1ll << idx_bits) < (long long)a.n_points) ++idx_bits;
     const long long n_cells = (long long)a.batch * a.nx * a.ny;
-    const ClearJob cj{w.cell_first, w.cell_vid, w.frame_base, voxel_offsets, a.batch, a.nx, a.ny, a.max_voxels, capacity, spatial,
+    const ClearJob cj{w.cell_first, w.cell_count, w.cell_vid, w.frame_base, voxel_offsets, a.batch, a.nx, a.ny, a.max_voxels, capacity, spatial,
                       spatial_scale, 0, n_cells, canvas_state};
     GatherSrc g{a.points, a.point_stride, a.xyz_col, a.batch, a.nx, a.ny, a.nz, a.max_voxels, a.cap_mode, capacity, w,
                 voxel_offsets, voxels, coords, num_points, spatial, spatial_channels, spatial_scale, blocks, cj, idx_bits, a.n_points,
