@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ fo
     const int r = w.cell_vid[g];
     const int b = frame_of(foff, batch, i);
     const int local = r - w.frame_base[b];
-    // the point's slot in its voxel: handed out by K1 (k1_keys_lds: arrival numbers, counted from the top here like the atomicSub) or
+    // the point's slot in its voxel: handed out by K1 (k1_keys<true>: arrival numbers, counted from the top here like the atomicSub) or
     // taken now — which also returns the count map to its idle 0
     const int slot_k1 = have_slots ? w.arena[i] : 0;
     const int4 rec = w.vox_rec[r];

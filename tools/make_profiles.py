@@ -20,8 +20,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RAW = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r04a")
-R = sys.argv[2] if len(sys.argv) > 2 else "r04"
+RAW = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r05a")
+R = sys.argv[2] if len(sys.argv) > 2 else "r05"
 OUT = os.path.join(ROOT, "profiles")
 
 

@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 runs behind profiles/ (run on the GPU box from the repo root: `gpurun -- bash tools/run_profiles.sh r04a`, then
-# `python tools/make_profiles.py r04a r04` here).  Kernel statistics and the PMC passes are separate runs (a --pmc run carries no
+# rocprofv3 runs behind profiles/ (run on the GPU box from the repo root: `gpurun -- bash tools/run_profiles.sh r05a`, then
+# `python tools/make_profiles.py r05a r04` here).  Kernel statistics and the PMC passes are separate runs (a --pmc run carries no
 # other trace domain).  Only the summaries leave the box: per-dispatch traces are deleted.
 set -u
-O=gpurun_out/${1:-r04a}
+O=gpurun_out/${1:-r05a}
 export TMPDIR=/tmp
 mkdir -p $O
 T="timeout 280"
