@@ -77,7 +77,7 @@ f_tot, f_cnt = per_kernel(os.path.join(RAW, "pmc_fetch", "f_counter_collection.c
 w_tot, w_cnt = per_kernel(os.path.join(RAW, "pmc_write", "w_counter_collection.csv"))
 frames = f_cnt[[k for k in f_cnt if "k_vfe" in k or "k_encode" in k][0]]          # runs exactly once per frame
 rows, group, conv, conv_parts = [], 0.0, 0.0, defaultdict(float)
-GROUP = ("k1_keys", "k2_scan", "k3_fill", "k4_gather", "k_vfe", "k_memory_readout", "k_cell_map", "k_scatter", "k_encode")
+GROUP = ("k_index", "k1_keys", "k2_scan", "k3_fill", "k4_gather", "k_vfe", "k_memory_readout", "k_cell_map", "k_scatter", "k_encode")
 CONV = ("k_conv", "k_wino", "k_wgrad", "k_spatial_gate", "k_deconv", "k_head", "k_pool")     # everything of the backbone + head stage
 for k in sorted(f_tot, key=lambda k: -(2 * f_tot[k] + w_tot.get(k, 0))):
     calls = f_cnt[k] / frames
