@@ -164,7 +164,7 @@ int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale
                                 float *memory_features, float *spatial, float *spatial_scale, void *workspace,
                                 size_t workspace_bytes, hvpr_stream_t stream);
 
-/* a1..a4 fused — points to BEV canvases in five launches, the form the detector's eval forward uses when it is handed raw
+/* a1..a4 fused — points to BEV canvases in three launches (five beyond 32 768 points), the form the detector's eval forward uses when it is handed raw
  *     points.  Same results, bit for bit, as hvpr_voxelize_f32 -> hvpr_pillar_vfe_fwd_f32 -> hvpr_memory_scatter_fwd_f32
  *     (data_processor.py:43-75, pillar_vfe.py:184-221, memory_module.py:60-77, pointpillar_scatter.py:169-222) with
  *       - the voxel gather fused into the VFE (the padded `voxels` tensor becomes an optional OUTPUT, may be NULL),
@@ -172,6 +172,10 @@ int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale
  *         cell cleared by extra workgroups of the (latency-bound) VFE launch: no scatter pass, no cell map.
  *     Arguments as in the three separate calls; n_feat must be 4, nz 1, max_points <= 32, channels 64 + 64 + 32.
  *     voxel_offsets[batch] is the live pillar count M (device word); rows >= M of the per-pillar outputs are unspecified.
+ *     capacity below M truncates: the first `capacity` rows are written, the canvas cells of the dropped pillars stay zero.
+ *     Up to 32 768 points the index phase is one launch whose workgroups wait for each other at two grid barriers: it needs up to
+ *     32 compute units of one XCD free at some point (any other kernel that finishes makes room) and must not be launched from a
+ *     context that can never run 32 workgroups of it at once.
  *     pillar_mask may be NULL.  workspace: hvpr_voxelize_workspace_bytes / _reset, as for hvpr_voxelize_f32.
  *     Weight / bias pointers 16-byte aligned.
  *     canvas_state (may be NULL): [batch * ny * nx] bytes that travel with ONE pair of canvases the caller keeps between calls.
