@@ -173,9 +173,11 @@ int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale
  *     Arguments as in the three separate calls; n_feat must be 4, nz 1, max_points <= 32, channels 64 + 64 + 32.
  *     voxel_offsets[batch] is the live pillar count M (device word); rows >= M of the per-pillar outputs are unspecified.
  *     capacity below M truncates: the first `capacity` rows are written, the canvas cells of the dropped pillars stay zero.
- *     Up to 32 768 points the index phase is one launch whose workgroups wait for each other at two grid barriers: it needs up to
- *     32 compute units of one XCD free at some point (any other kernel that finishes makes room) and must not be launched from a
- *     context that can never run 32 workgroups of it at once.
+ *     Up to 32 768 points the index phase is one launch whose (at most 32) workgroups wait for each other at two grid barriers on
+ *     the compute units of one XCD.  Kernels that finish make room for them, so other work on the device only delays them — but
+ *     such launches wait for EACH OTHER'S compute units when several are in flight at once: keep at most two calls of this size
+ *     in flight per device (one XCD holds the workgroups of four; the detector's frame pipeline has one), or set HVPR_INDEX_FUSED=0
+ *     in the environment to take the three-launch index phase, which has no such constraint (a frame's encode is ~2.6 us longer).
  *     pillar_mask may be NULL.  workspace: hvpr_voxelize_workspace_bytes / _reset, as for hvpr_voxelize_f32.
  *     Weight / bias pointers 16-byte aligned.
  *     canvas_state (may be NULL): [batch * ny * nx] bytes that travel with ONE pair of canvases the caller keeps between calls.
