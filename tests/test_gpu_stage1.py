@@ -482,6 +482,46 @@ def test_encode_fused_stress_shapes(P):
     _check_voxelize([heavy, base[:100]], P, 40000)
 
 
+def test_encode_fused_index_phase_under_load_many_times():
+    """The one-launch index phase hands data between workgroups through atomics and (when its owners share an XCD) that XCD's L2,
+    without a fence: check every word of its results 300 times over while another stream streams through the caches and keeps
+    every CU busy (hand-offs that are only right on an idle chip fail under uneven load), alternating two frames so that no
+    result can come from the previous call."""
+    frames = [synthetic.hvpr_frame(21, shuffle=True), synthetic.hvpr_frame(22)[:9000]]
+    folded = _folded_from(_vfe_params(5))
+    vfe_off = [VS[0] / 2 + RNG[0], VS[1] / 2 + RNG[1], VS[2] / 2 + RNG[2]]
+    W = torch.from_numpy(np.random.default_rng(5).uniform(-0.125, 0.125, (2000, 64)).astype(np.float32)).to(DEV)
+    one = torch.tensor([0], dtype=torch.int32, device=DEV)
+    pts, offs, ref = [], [], []
+    ws = kernels.VoxelizeWorkspace(1, 16384, GRID, DEV)
+    for f in frames:
+        p = torch.from_numpy(np.concatenate([np.zeros((len(f), 1), np.float32), f], 1)).to(DEV)
+        o = torch.cat([one, torch.tensor([len(f)], dtype=torch.int32, device=DEV)])
+        r = kernels.encode_fwd(p, o, 1, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1)
+        torch.cuda.synchronize()
+        pts.append(p); offs.append(o); ref.append({k: v.clone() for k, v in r.items() if v is not None})
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)       # 256 MB: through every L2 and the MALL
+    stop = 300
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            torch.mm(a, a)
+            big.add_(1.0)
+    bad = 0
+    for it in range(stop):
+        j = it & 1
+        r = kernels.encode_fwd(pts[j], offs[j], 1, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1)
+        m = int(ref[j]["voxel_offsets"][1])
+        ok = torch.equal(r["voxel_offsets"], ref[j]["voxel_offsets"])
+        for k in ("coords", "num_points", "voxels", "pillar_features", "memory_features"):
+            ok = ok and torch.equal(r[k][:m], ref[j][k][:m])
+        ok = ok and torch.equal(r["spatial"], ref[j]["spatial"]) and torch.equal(r["spatial_scale"], ref[j]["spatial_scale"])
+        bad += 0 if ok else 1
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of {stop} encodes differ"
+
+
 @pytest.mark.parametrize("env", [{"HVPR_INDEX_FUSED": "0"}, {"HVPR_INDEX_AGENT": "1"}], ids=["three_launches", "one_launch_device_scope"])
 def test_encode_other_index_forms_in_a_child_process(env):
     """The index phase of hvpr_encode_fwd_f32 has two forms — K1 / K2 / K3 as three launches (what more than 32 768 points take;
@@ -491,6 +531,6 @@ def test_encode_other_index_forms_in_a_child_process(env):
     if os.environ.get("HVPR_INDEX_CHILD"):
         pytest.skip("already the child")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                        "encode_fused_equals or voxel_cap or capacity or stress or persistent"],
+                        "encode_fused_equals or voxel_cap or capacity or stress or persistent or under_load"],
                        env={**os.environ, **env, "HVPR_INDEX_CHILD": "1"}, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
