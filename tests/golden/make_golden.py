@@ -53,6 +53,18 @@ class EasyDict(dict):
             raise AttributeError(k)
 
 
+def _import_oracle():
+    """The build's CPU oracle (C routines for the rotated geometry the reference does not ship).  Found next to this script's
+    tests/ directory, or — when the script was copied elsewhere — in $HVPR_REPO, the working directory or /root/repo."""
+    for root in (os.path.dirname(os.path.dirname(OUT)), os.environ.get("HVPR_REPO", ""), os.getcwd(), "/root/repo"):
+        if root and os.path.isdir(os.path.join(root, "oracle")):
+            if root not in sys.path:
+                sys.path.insert(0, root)
+            break
+    from oracle import hvpr_oracle as O
+    return O
+
+
 def _stub(name, path=None):
     m = types.ModuleType(name)
     if path is not None:
@@ -605,8 +617,7 @@ def g12_kitti_eval(R):
     """AP through the reference's eval.py, run as plain Python: numba.jit -> identity, the ABSENT rotate_iou.py -> a stub
     over the build's CPU rotated-intersection (oracle/iou3d_nms_ref.c, angle negated: rotation_y is clockwise in x-z).  Pins
     the evaluator's filtering / matching / PR / AP logic; the rotated intersection itself stays unpinned."""
-    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
-    from oracle import hvpr_oracle as O
+    O = _import_oracle()
 
     def jit(*a, **k):
         return a[0] if (len(a) == 1 and callable(a[0]) and not k) else (lambda f: f)
@@ -732,8 +743,7 @@ def load_post_processing(R):
     wrappers over the CPU oracle's C routines, written from the upstream signature (sort descending, optional
     pre_maxsize cut, mask + sweep, `order[keep]`).  detector3d_template.py's package-relative imports of the module zoo
     (backbones, heads, transformer ...; none is used by the two methods) are dropped."""
-    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
-    from oracle import hvpr_oracle as O
+    O = _import_oracle()
     iou = sys.modules["pcdet.ops.iou3d_nms.iou3d_nms_utils"]
 
     def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
