@@ -247,9 +247,8 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     // first) and get their exact logits from ONE batch of loads — four lanes per candidate, whose 16 bank-row values each stay in
     // registers; they are ranked inside their own pillar by counting (lane = candidate walks its pillar's zero-padded key list in
     // LDS, two keys per read: no per-pillar radix select on the scalar unit); the k best leave (id, logit) by rank in a table, the
-    // softmax runs with lane = (slot, rank), and the weighted sum of the selected rows is taken from the registers of the exact
-    // pass (weight 0 for the unselected) by a vector-halving butterfly over the 16 candidate lanes that share a channel block —
-    // the bank rows are fetched once, a wave's chain has ONE memory round trip whatever PPW is.
+    // softmax runs with lane = (slot, rank), and the weighted sum of the selected rows with lane = (slot, channel pair), in rank
+    // order: a wave's chain has TWO memory round trips (candidate rows, selected rows) whatever PPW is.
     int *const list = s_list + wid * 64;                                     // candidate ids of the round, joint positions
     unsigned long long *const keys = s_key + wid * (PPW * 64);               // [slot][64] (order bits of L, ~id), zero padded
     int2 *const top = s_top + wid * 64;                                      // [slot][rank] -> (id, L bits, then weight bits)
