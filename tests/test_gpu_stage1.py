@@ -482,6 +482,20 @@ def test_encode_fused_stress_shapes(P):
     _check_voxelize([heavy, base[:100]], P, 40000)
 
 
+@pytest.mark.parametrize("n_total", [1, 63, 511, 512, 513, 1023, 1025, 8191, 16383, 16385, 32767, 32768, 32769, 40000])
+def test_encode_fused_sizes_around_the_index_kernel_boundaries(n_total):
+    """The index phase changes form with the point count (512-point owners up to 16 384 points, 1024-point owners up to 32 768, three
+    launches with K1's slots beyond) and its owners' last tiles are ragged: the fused entry point against the separate calls, bit
+    for bit, at the sizes where something switches — as one frame and split unevenly over three (one of them empty)."""
+    rng = np.random.default_rng(n_total)
+    base = np.concatenate([synthetic.hvpr_frame(30 + i, shuffle=True) for i in range(3)])
+    pts = base[rng.permutation(len(base))[:n_total]]
+    _encode_both([pts], 40000)
+    if n_total >= 3:
+        a, b = sorted(rng.choice(np.arange(1, n_total), 2, replace=False).tolist())
+        _encode_both([pts[:a], np.zeros((0, 4), np.float32), pts[a:b], pts[b:]], 40000, cap_mode=1)
+
+
 def test_encode_fused_index_phase_under_load_many_times():
     """The one-launch index phase hands data between workgroups through atomics and (when its owners share an XCD) that XCD's L2,
     without a fence: check every word of its results 300 times over while another stream streams through the caches and keeps
@@ -531,6 +545,6 @@ def test_encode_other_index_forms_in_a_child_process(env):
     if os.environ.get("HVPR_INDEX_CHILD"):
         pytest.skip("already the child")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                        "encode_fused_equals or voxel_cap or capacity or stress or persistent or under_load"],
+                        "encode_fused_equals or voxel_cap or capacity or stress or persistent or under_load or boundaries"],
                        env={**os.environ, **env, "HVPR_INDEX_CHILD": "1"}, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
