@@ -33,14 +33,35 @@ struct WwArgs {
 constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2;     // 8 x 16 outputs = 4 x 8 blocks = 16 K steps per tile
 constexpr int BM = 64, BNN = 64;                     // co x ci of the workgroup
 constexpr int NT = 512;
-constexpr int DZ_V4 = TH * TW * BM / 4, X_V4 = PH * PW * BNN / 4;       // 1024, 1600
-constexpr int NLD_D = DZ_V4 / NT, NLD_X = (X_V4 + NT - 1) / NT;         // 4, 6
-constexpr int kLds = (TH * TW * BM + PH * PW * BNN) * 4;                // 78 KB: one workgroup per CU
+// LDS holds both tiles CHANNEL-major, [channel][pixel]: a lane (= channel) finds the neighbouring pixels of a block side by side
+// and takes them with 8-byte reads.  Channel pitches 2 * odd: 32 consecutive channels land on 32 distinct even banks of 64.
+constexpr int PA = TH * TW + 2, PB = PH * PW + 2;                       // 130, 182 floats
+constexpr int DZ_IT = (TH * TW / 2) * (BM / 4), X_IT = (PH * PW / 2) * (BNN / 4);      // (pixel pair, 4 channels) items: 1024, 1440
+constexpr int NLD_D = DZ_IT / NT, NLD_X = (X_IT + NT - 1) / NT, NIT = NLD_D + NLD_X;    // 2 + 3 items per thread
+constexpr int STAGE_F = BM * PA + BNN * PB;                             // floats per stage: 19 968
+constexpr int kLds = 2 * STAGE_F * 4;                                   // two stages, 156 KB: one workgroup per CU
+constexpr int K_STEPS = TH * TW / 8;                                    // 16
+static_assert(DZ_IT % NT == 0 && TW % 2 == 0 && PW % 2 == 0, "pixel pairs must not straddle tile rows");
+static_assert(2 * NIT <= K_STEPS - 2, "the staging units of a tile are dealt to its K steps");
+static_assert(X_IT - (NLD_X - 1) * NT > 0 && X_IT >= (NLD_X - 1) * NT, "the last patch item is partly live");
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) float *lds_cfp;       // an LDS address stays an LDS address through an empty asm
+typedef __attribute__((address_space(3))) float *lds_fp;
+#define LD2(p) (*(const __attribute__((address_space(3))) f32x2 *)(p))
+#define ST2(p) (*(__attribute__((address_space(3))) f32x2 *)(p))
+
+// One workgroup walks its pixel tiles with everything that is not an MFMA dealt to the K steps of the tile before: while tile k
+// multiplies out of LDS stage k & 1, the registers holding tile k + 1 are written to the other stage (one 2-channel store pair per
+// K step, steps 0-9) and re-filled with tile k + 2 (one 16-byte buffer load per step, steps 2-11; out-of-image / past-the-end
+// pieces take an out-of-range offset and come back as zeros, so the loop has no branch).  One barrier per tile.  (Measured before:
+// issuing the 10 loads of a tile in one go cost 3.3 k cycles and the 10 LDS store pairs 2.4 k of the 25 k cycles per tile, with the
+// matrix cores idle — tools/wgrad_phases.py.)
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_wgrad_wino(WwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_w[];
-    float *const s_dz = smem_w;                        // [pixel][co]
-    float *const s_x = smem_w + TH * TW * BM;          // [patch pixel][ci]
+    const lds_fp s0 = (lds_fp)smem_w;                  // stage: [co][pixel] pitch PA, then [ci][patch pixel] pitch PB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wa = wid & 3, ch = wid >> 2, half = lane >> 5, l31 = lane & 31;
     const int ot = blockIdx.x, chunk = blockIdx.y;
@@ -54,78 +75,154 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][nb][r] = 0.f;
 
-    float4 rd[NLD_D], rx[NLD_X];
-    auto fetch = [&](int pt) {          // global -> registers (zeros outside the image / past the channel counts)
-        const int tx = pt % a.tiles_x, ty = (pt / a.tiles_x) % a.tiles_y, n = pt / (a.tiles_x * a.tiles_y);
-        const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 - 1, ix0 = ox0 - 1;
+    // ---- staging items of this thread (tile-independent part).  An item = two neighbouring pixels x four channels: two 16-byte
+    // loads, four 8-byte LDS stores (one per channel).  Items 0..1: dz tile, 2..4: input patch; the lanes past the end of the patch
+    // list repeat their own previous item (same addresses, same values). ----
+    int it_dy[NIT], it_dx[NIT], it_c[NIT], it_lds[NIT];
+    bool it_live[NIT];
 #pragma unroll
-        for (int i = 0; i < NLD_D; ++i) {
-            const int v = tid + i * NT, px = v / (BM / 4), c4 = (v % (BM / 4)) * 4;
-            const int oy = oy0 + px / TW, ox = ox0 + px % TW;
-            const bool ok = oy < a.H && ox < a.W && co0 + c4 < a.Cout;
-            rd[i] = ok ? *(const float4 *)(a.dz + (((size_t)n * a.H + oy) * a.W + ox) * a.Cout + co0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NIT; ++i) {
+        if (i < NLD_D) {
+            const int v = tid + i * NT, pp = v / (BM / 4), c4 = (v % (BM / 4)) * 4;
+            it_dy[i] = pp / (TW / 2); it_dx[i] = 2 * (pp % (TW / 2)); it_c[i] = c4;
+            it_lds[i] = c4 * PA + 2 * pp;
+            it_live[i] = co0 + c4 < a.Cout;
+        } else {
+            int v = tid + (i - NLD_D) * NT;
+            if (v >= X_IT) v -= NT;
+            const int pp = v / (BNN / 4), c4 = (v % (BNN / 4)) * 4;
+            it_dy[i] = pp / (PW / 2) - 1; it_dx[i] = 2 * (pp % (PW / 2)) - 1; it_c[i] = c4;
+            it_lds[i] = BM * PA + c4 * PB + 2 * pp;
+            it_live[i] = ci0 + c4 < a.Cin;
         }
-#pragma unroll
-        for (int i = 0; i < NLD_X; ++i) {
-            const int v = tid + i * NT, px = v / (BNN / 4), c4 = (v % (BNN / 4)) * 4;
-            const int iy = iy0 + px / PW, ix = ix0 + px % PW;
-            const bool ok = v < X_V4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + c4 < a.Cin;
-            rx[i] = ok ? *(const float4 *)(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.Cin + ci0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    }
+    const unsigned img_dz = (unsigned)a.H * a.W * a.Cout * 4u, img_x = (unsigned)a.H * a.W * a.Cin * 4u;    // bytes per image (< 4 GB: launcher)
+    f32x4 rg[NIT][2];
+    struct Tile { int n, oy0, ox0; bool valid; };
+    auto tile_of = [&](int k) {
+        const int pt = chunk + k * a.n_chunks;
+        Tile t;
+        t.valid = pt < a.n_pt;
+        const int q = t.valid ? pt : 0;
+        t.ox0 = (q % a.tiles_x) * TW; t.oy0 = ((q / a.tiles_x) % a.tiles_y) * TH; t.n = q / (a.tiles_x * a.tiles_y);
+        return t;
     };
-    auto commit = [&]() {               // registers -> LDS
-#pragma unroll
-        for (int i = 0; i < NLD_D; ++i) *(float4 *)(s_dz + (tid + i * NT) * 4) = rd[i];
-#pragma unroll
-        for (int i = 0; i < NLD_X; ++i)
-            if (tid + i * NT < X_V4) *(float4 *)(s_x + (tid + i * NT) * 4) = rx[i];
+    auto load_unit = [&](int u, const Tile &t) {       // unit u: pixel u & 1 of item u >> 1
+        const int i = u >> 1, w = u & 1;
+        const bool is_dz = i < NLD_D;
+        const int y = t.oy0 + it_dy[i], x = t.ox0 + it_dx[i] + w, C = is_dz ? a.Cout : a.Cin;
+        const bool ok = (int)t.valid & (int)it_live[i] & (int)((unsigned)y < (unsigned)a.H) & (int)((unsigned)x < (unsigned)a.W);
+        // a piece outside the image (or of a tile past the end) gets bit 31 set: past num_records (< 2^31), the load returns zeros
+        const unsigned off = (unsigned)(((y * a.W + x) * C + it_c[i]) * 4) | (ok ? 0u : 0x80000000u);
+        const float *base = is_dz ? a.dz + (size_t)t.n * a.H * a.W * a.Cout + co0 : a.x + (size_t)t.n * a.H * a.W * a.Cin + ci0;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(is_dz ? img_dz : img_x), 0x00020000);
+        rg[i][w] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    };
+    auto store_unit = [&](int u, lds_fp stage) {       // unit u: channels 2 (u & 1), 2 (u & 1) + 1 of item u >> 1, both pixels
+        const int i = u >> 1, e = 2 * (u & 1);
+        const int P = i < NLD_D ? PA : PB;
+        const lds_fp d = stage + it_lds[i] + e * P;
+        ST2(d) = f32x2{rg[i][0][e], rg[i][1][e]};
+        ST2(d + P) = f32x2{rg[i][0][e + 1], rg[i][1][e + 1]};
     };
 
-    // Row `wa` of A (for dY) and of Bt (for d) — wave-uniform selections folded into lane base pointers and two sign constants:
-    //   A dY:   a=0: dY0     a=1: dY0 + dY1    a=2: dY0 - dY1    a=3: dY1 (true: -dY1)
-    //   Bt d:   a=0: d0 - d2 a=1: d1 + d2      a=2: d2 - d1      a=3: d1 - d3
-    const float sA = wa == 2 ? -1.f : 1.f;                        // t = first + sA * second
-    const bool single = wa == 0 || wa == 3;                        // a = 0 / 3: a single row of dY
-    const int ya0 = wa == 3 ? 1 : 0, ya1 = 1;                      // dY rows combined
+    // Row `wa` of A (for dY) and of Bt (for d) — wave-uniform selections folded into lane base pointers and two coefficients:
+    //   A dY:   a=0: dY0     a=1: dY0 + dY1    a=2: dY0 - dY1    a=3: dY1 (true: -dY1)      = first + cA * dY1
+    //   Bt d:   a=0: d0 - d2 a=1: d1 + d2      a=2: d2 - d1      a=3: d1 - d3              = first + sB * second
+    const float cA = wa == 1 ? 1.f : (wa == 2 ? -1.f : 0.f);
+    const int ya0 = wa == 3 ? 1 : 0;
     const int r0 = wa == 0 ? 0 : (wa == 2 ? 2 : 1), r1 = wa == 2 ? 1 : (wa == 3 ? 3 : 2);
     const float sB = wa == 1 ? 1.f : -1.f;
+    const f32x2 cA2 = {cA, cA}, sB2 = {sB, sB};
     // lane half h takes block 2m + h of the tile: by = m / (TW / 4), bx = 2 * (m % (TW / 4)) + h  -> two pixels to the right for h = 1
-    const float *pa0 = s_dz + (ya0 * TW + 2 * half) * BM + ch * 32 + l31;       // + ((2 by) * TW + 2 bx0 + q) * BM
-    const float *pa1 = s_dz + (ya1 * TW + 2 * half) * BM + ch * 32 + l31;
-    const float *pb0 = s_x + (r0 * PW + 2 * half) * BNN + l31;                  // + ((2 by) * PW + 2 bx0 + j) * BNN + nb * 32
-    const float *pb1 = s_x + (r1 * PW + 2 * half) * BNN + l31;
+    const int oa0 = (ch * 32 + l31) * PA + ya0 * TW + 2 * half;            // + (2 by) * TW + 2 bx0: the 2x2 of dY, one row per read
+    const int oa1 = (ch * 32 + l31) * PA + TW + 2 * half;
+    const int ob0 = BM * PA + l31 * PB + r0 * PW + 2 * half;               // + nb * 32 * PB + (2 by) * PW + 2 bx0 (+ 2): four columns of a patch row
+    const int ob1 = BM * PA + l31 * PB + r1 * PW + 2 * half;
 
-    int pt = chunk;
-    if (pt < a.n_pt) fetch(pt);
-    for (; pt < a.n_pt; pt += a.n_chunks) {
-        __syncthreads();                 // everybody is done reading the previous tile
-        commit();
-        __syncthreads();
-        if (pt + a.n_chunks < a.n_pt) fetch(pt + a.n_chunks);   // the next tile travels while this one multiplies
+    int n_tiles = 0;
+    if (chunk < a.n_pt) n_tiles = (a.n_pt - chunk + a.n_chunks - 1) / a.n_chunks;
+    {
+        const Tile t0 = tile_of(0);
 #pragma unroll
-        for (int m = 0; m < TH * TW / 8; ++m) {
+        for (int u = 0; u < 2 * NIT; ++u) load_unit(u, t0);
+#pragma unroll
+        for (int u = 0; u < 2 * NIT; ++u) store_unit(u, s0);
+        const Tile t1 = tile_of(1);
+#pragma unroll
+        for (int u = 0; u < 2 * NIT; ++u) load_unit(u, t1);
+    }
+    __syncthreads();
+#ifdef HVPR_EXP_TIMING
+    unsigned long long tph[K_STEPS + 2], tprev, tnow;
+    for (int i = 0; i < K_STEPS + 2; ++i) tph[i] = 0;
+#define WW_NOW(t) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
+#define WW_STAMP(k) do { WW_NOW(tnow); tph[k] += tnow - tprev; tprev = tnow; } while (0)
+    WW_NOW(tprev);
+#else
+#define WW_STAMP(k)
+#endif
+    for (int k = 0; k < n_tiles; ++k) {
+        const int cur = (k & 1) * STAGE_F;
+        const lds_fp wr = s0 + (STAGE_F - cur);        // tile k + 1's stage
+        const Tile t2 = tile_of(k + 2);
+        // (LDS-typed pointers kept in registers by the empty asm: the K steps then differ only in the offset fields of the reads —
+        //  no address arithmetic in the loop)
+        lds_cfp pa0 = s0 + cur + oa0, pa1 = s0 + cur + oa1, pb0[2], pb1[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            pb0[nb] = s0 + cur + ob0 + nb * 32 * PB;
+            pb1[nb] = s0 + cur + ob1 + nb * 32 * PB;
+            asm volatile("" : "+v"(pb0[nb]), "+v"(pb1[nb]));
+        }
+        asm volatile("" : "+v"(pa0), "+v"(pa1));
+#pragma unroll
+        for (int m = 0; m < K_STEPS; ++m) {
             const int by = m / (TW / 4), bx0 = 2 * (m % (TW / 4));
-            const int oa = ((2 * by) * TW + 2 * bx0) * BM, ob = ((2 * by) * PW + 2 * bx0) * BNN;
+            const int oa = (2 * by) * TW + 2 * bx0, ob = (2 * by) * PW + 2 * bx0;
             // A operand: row wa of (A dY At) for this lane's co; columns: (t0, t0 + t1, t0 - t1, t1 [true: -t1])
-            const float y00 = pa0[oa], y01 = pa0[oa + BM], y10 = pa1[oa], y11 = pa1[oa + BM];
-            const float t0 = single ? y00 : fmaf(sA, y10, y00), t1 = single ? y01 : fmaf(sA, y11, y01);
-            const float am[4] = {t0, t0 + t1, t0 - t1, t1};
+            const f32x2 t = __builtin_elementwise_fma(cA2, LD2(pa1 + oa), LD2(pa0 + oa));
+            const float am[4] = {t.x, t.x + t.y, t.x - t.y, t.y};
             // B operand: row wa of (Bt d B) for this lane's ci, two ci blocks
             float bm[2][4];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                float t[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = fmaf(sB, pb1[ob + j * BNN + nb * 32], pb0[ob + j * BNN + nb * 32]);
-                bm[nb][0] = t[0] - t[2]; bm[nb][1] = t[1] + t[2]; bm[nb][2] = t[2] - t[1]; bm[nb][3] = t[1] - t[3];
+                const f32x2 t01 = __builtin_elementwise_fma(sB2, LD2(pb1[nb] + ob), LD2(pb0[nb] + ob));
+                const f32x2 t23 = __builtin_elementwise_fma(sB2, LD2(pb1[nb] + ob + 2), LD2(pb0[nb] + ob + 2));
+                const f32x2 d = t01 - t23;                      // (t0 - t2, t1 - t3)
+                bm[nb][0] = d.x; bm[nb][1] = t01.y + t23.x; bm[nb][2] = t23.x - t01.y; bm[nb][3] = d.y;
             }
+            // the staging units sit BETWEEN the MFMAs (in the shadow of the one just issued), not in front of the step's reads: an LDS
+            // store ahead of the reads is waited for with them (LDS returns in order) and lengthens the step's dependent chain
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < 4; ++b) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
                     acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[b], bm[nb][b], acc[b][nb], 0, 0, 0);
+                if (b == 0 && m < 2 * NIT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_unit(m, wr);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (b == 1 && m >= 2 && m < 2 + 2 * NIT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_unit(m - 2, t2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            WW_STAMP(m + 1);
         }
+        __syncthreads();                 // everybody is done reading stage `cur` and writing the other one
+        WW_STAMP(K_STEPS + 1);
     }
+#ifdef HVPR_EXP_TIMING
+    if (lane == 0 && (wid == 0 || wid == 5) && ((ot == 0 && chunk == 0) || (ot == 1 && chunk == 3)))
+        printf("k_wgrad_wino wg (%d, %d) wave %d: %d tiles; cycles per tile: K steps %llu %llu %llu %llu | %llu %llu %llu %llu | %llu %llu %llu %llu | %llu %llu %llu %llu | "
+               "barrier %llu\n", ot, chunk, wid, n_tiles, tph[1] / n_tiles, tph[2] / n_tiles, tph[3] / n_tiles, tph[4] / n_tiles, tph[5] / n_tiles,
+               tph[6] / n_tiles, tph[7] / n_tiles, tph[8] / n_tiles, tph[9] / n_tiles, tph[10] / n_tiles, tph[11] / n_tiles, tph[12] / n_tiles,
+               tph[13] / n_tiles, tph[14] / n_tiles, tph[15] / n_tiles, tph[16] / n_tiles, tph[17] / n_tiles);
+#endif
     // partials [chunk][xi][co][ci]; C/D map of 32x32: column (ci) = lane & 31, row (co) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     float *out = a.part + (size_t)chunk * 16 * a.Cout * a.Cin;
 #pragma unroll
@@ -203,6 +300,7 @@ extern "C" int hvpr_conv2d_wino_wgrad_nhwc_f32(const float *x, int N, int H, int
                                                void *workspace, size_t workspace_bytes, hvpr_stream_t stream) {
     if (!x || !dz || !dw || !workspace || N < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return HVPR_ERR_INVALID_ARG;
     if (Cin % 4 != 0 || Cout % 4 != 0) return HVPR_ERR_UNSUPPORTED;
+    if ((unsigned long long)H * W * (Cin > Cout ? Cin : Cout) * sizeof(float) >= (1ull << 31)) return HVPR_ERR_UNSUPPORTED;   // 32-bit offsets inside an image
     if (workspace_bytes < hvpr_conv2d_wino_wgrad_workspace_bytes(N, H, W, Cin, Cout)) return HVPR_ERR_WORKSPACE;
     WwArgs a;
     a.x = x; a.dz = dz; a.part = (float *)workspace;
