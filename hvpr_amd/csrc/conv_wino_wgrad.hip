@@ -64,7 +64,16 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const lds_fp s0 = (lds_fp)smem_w;                  // stage: [co][pixel] pitch PA, then [ci][patch pixel] pitch PB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wa = wid & 3, ch = wid >> 2, half = lane >> 5, l31 = lane & 31;
-    const int ot = blockIdx.x, chunk = blockIdx.y;
+    // Workgroup -> (output tile, chunk).  Consecutive workgroup ids go round the 8 XCDs; the workgroups of one chunk read the same
+    // pixel tiles at the same time (each dz tile n_ci_tiles times, each patch n_co_tiles times), so they are put on ONE XCD — behind
+    // one L2 — by giving every XCD a contiguous range of (chunk, output tile) pairs.
+    int vid = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if (total % 8 == 0) vid = (vid & 7) * (total >> 3) + (vid >> 3);
+    }
+    const int n_ot = a.n_ci_tiles * ((a.Cout + BM - 1) / BM);
+    const int ot = vid % n_ot, chunk = vid / n_ot;
     const int co0 = (ot / a.n_ci_tiles) * BM, ci0 = (ot % a.n_ci_tiles) * BNN;
 
     f32x16 acc[4][2];
@@ -78,45 +87,53 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // ---- staging items of this thread (tile-independent part).  An item = two neighbouring pixels x four channels: two 16-byte
     // loads, four 8-byte LDS stores (one per channel).  Items 0..1: dz tile, 2..4: input patch; the lanes past the end of the patch
     // list repeat their own previous item (same addresses, same values). ----
-    int it_dy[NIT], it_dx[NIT], it_c[NIT], it_lds[NIT];
-    bool it_live[NIT];
+    // it_off: byte offset of the item's first pixel from the tile's first output pixel, inside the (channel-tile-based) image
+    int it_dy[NIT], it_dx[NIT], it_lds[NIT];
+    unsigned it_off[NIT];
+    constexpr int kNever = 1 << 30;                     // a row number no image has: marks dead channel groups / tiles past the end
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         if (i < NLD_D) {
             const int v = tid + i * NT, pp = v / (BM / 4), c4 = (v % (BM / 4)) * 4;
-            it_dy[i] = pp / (TW / 2); it_dx[i] = 2 * (pp % (TW / 2)); it_c[i] = c4;
+            it_dy[i] = pp / (TW / 2); it_dx[i] = 2 * (pp % (TW / 2));
             it_lds[i] = c4 * PA + 2 * pp;
-            it_live[i] = co0 + c4 < a.Cout;
+            it_off[i] = (unsigned)(((it_dy[i] * a.W + it_dx[i]) * a.Cout + c4) * 4);
+            if (co0 + c4 >= a.Cout) it_dy[i] = kNever;
         } else {
             int v = tid + (i - NLD_D) * NT;
             if (v >= X_IT) v -= NT;
             const int pp = v / (BNN / 4), c4 = (v % (BNN / 4)) * 4;
-            it_dy[i] = pp / (PW / 2) - 1; it_dx[i] = 2 * (pp % (PW / 2)) - 1; it_c[i] = c4;
+            it_dy[i] = pp / (PW / 2) - 1; it_dx[i] = 2 * (pp % (PW / 2)) - 1;
             it_lds[i] = BM * PA + c4 * PB + 2 * pp;
-            it_live[i] = ci0 + c4 < a.Cin;
+            it_off[i] = (unsigned)(((it_dy[i] * a.W + it_dx[i]) * a.Cin + c4) * 4);
+            if (ci0 + c4 >= a.Cin) it_dy[i] = kNever;
         }
     }
     const unsigned img_dz = (unsigned)a.H * a.W * a.Cout * 4u, img_x = (unsigned)a.H * a.W * a.Cin * 4u;    // bytes per image (< 4 GB: launcher)
     f32x4 rg[NIT][2];
-    struct Tile { int n, oy0, ox0; bool valid; };
+    struct Tile { int oy0, ox0; unsigned off_dz, off_x; const float *img_dz, *img_x; };     // all wave-uniform
     auto tile_of = [&](int k) {
         const int pt = chunk + k * a.n_chunks;
+        const bool valid = pt < a.n_pt;
+        const int q = valid ? pt : 0;
+        const int n = q / (a.tiles_x * a.tiles_y);
         Tile t;
-        t.valid = pt < a.n_pt;
-        const int q = t.valid ? pt : 0;
-        t.ox0 = (q % a.tiles_x) * TW; t.oy0 = ((q / a.tiles_x) % a.tiles_y) * TH; t.n = q / (a.tiles_x * a.tiles_y);
+        t.ox0 = (q % a.tiles_x) * TW; t.oy0 = ((q / a.tiles_x) % a.tiles_y) * TH;
+        t.off_dz = (unsigned)((t.oy0 * a.W + t.ox0) * a.Cout * 4); t.off_x = (unsigned)((t.oy0 * a.W + t.ox0) * a.Cin * 4);
+        t.img_dz = a.dz + (size_t)n * a.H * a.W * a.Cout + co0; t.img_x = a.x + (size_t)n * a.H * a.W * a.Cin + ci0;
+        if (!valid) t.oy0 = kNever;
         return t;
     };
     auto load_unit = [&](int u, const Tile &t) {       // unit u: pixel u & 1 of item u >> 1
         const int i = u >> 1, w = u & 1;
         const bool is_dz = i < NLD_D;
         const int y = t.oy0 + it_dy[i], x = t.ox0 + it_dx[i] + w, C = is_dz ? a.Cout : a.Cin;
-        const bool ok = (int)t.valid & (int)it_live[i] & (int)((unsigned)y < (unsigned)a.H) & (int)((unsigned)x < (unsigned)a.W);
-        // a piece outside the image (or of a tile past the end) gets bit 31 set: past num_records (< 2^31), the load returns zeros
-        const unsigned off = (unsigned)(((y * a.W + x) * C + it_c[i]) * 4) | (ok ? 0u : 0x80000000u);
-        const float *base = is_dz ? a.dz + (size_t)t.n * a.H * a.W * a.Cout + co0 : a.x + (size_t)t.n * a.H * a.W * a.Cin + ci0;
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(is_dz ? img_dz : img_x), 0x00020000);
-        rg[i][w] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        const bool ok = (int)((unsigned)y < (unsigned)a.H) & (int)((unsigned)x < (unsigned)a.W);
+        // a piece outside the image (or of a dead channel group, or of a tile past the end) gets an offset past num_records (< 2^31):
+        // the load returns zeros
+        const unsigned off = (is_dz ? t.off_dz : t.off_x) + it_off[i] + (unsigned)(w * C * 4);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)(is_dz ? t.img_dz : t.img_x), 0, (int)(is_dz ? img_dz : img_x), 0x00020000);
+        rg[i][w] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : 0x80000000u, 0, 0));
     };
     auto store_unit = [&](int u, lds_fp stage) {       // unit u: channels 2 (u & 1), 2 (u & 1) + 1 of item u >> 1, both pixels
         const int i = u >> 1, e = 2 * (u & 1);
@@ -176,22 +193,37 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
             asm volatile("" : "+v"(pb0[nb]), "+v"(pb1[nb]));
         }
         asm volatile("" : "+v"(pa0), "+v"(pa1));
-#pragma unroll
-        for (int m = 0; m < K_STEPS; ++m) {
+        // the raw operands of step m + 1 are requested before step m's MFMAs are issued (a step's chain is then its ~20 vector
+        // instructions + its MFMAs, without the LDS round trip)
+        f32x2 qa0, qa1, qb0[2][2], qb1[2][2];
+        auto request = [&](int m) {
             const int by = m / (TW / 4), bx0 = 2 * (m % (TW / 4));
             const int oa = (2 * by) * TW + 2 * bx0, ob = (2 * by) * PW + 2 * bx0;
+            qa0 = LD2(pa0 + oa); qa1 = LD2(pa1 + oa);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                qb0[nb][0] = LD2(pb0[nb] + ob); qb0[nb][1] = LD2(pb0[nb] + ob + 2);
+                qb1[nb][0] = LD2(pb1[nb] + ob); qb1[nb][1] = LD2(pb1[nb] + ob + 2);
+            }
+        };
+        request(0);
+#pragma unroll
+        for (int m = 0; m < K_STEPS; ++m) {
             // A operand: row wa of (A dY At) for this lane's co; columns: (t0, t0 + t1, t0 - t1, t1 [true: -t1])
-            const f32x2 t = __builtin_elementwise_fma(cA2, LD2(pa1 + oa), LD2(pa0 + oa));
+            const f32x2 t = __builtin_elementwise_fma(cA2, qa1, qa0);
             const float am[4] = {t.x, t.x + t.y, t.x - t.y, t.y};
             // B operand: row wa of (Bt d B) for this lane's ci, two ci blocks
             float bm[2][4];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                const f32x2 t01 = __builtin_elementwise_fma(sB2, LD2(pb1[nb] + ob), LD2(pb0[nb] + ob));
-                const f32x2 t23 = __builtin_elementwise_fma(sB2, LD2(pb1[nb] + ob + 2), LD2(pb0[nb] + ob + 2));
+                const f32x2 t01 = __builtin_elementwise_fma(sB2, qb1[nb][0], qb0[nb][0]);
+                const f32x2 t23 = __builtin_elementwise_fma(sB2, qb1[nb][1], qb0[nb][1]);
                 const f32x2 d = t01 - t23;                      // (t0 - t2, t1 - t3)
                 bm[nb][0] = d.x; bm[nb][1] = t01.y + t23.x; bm[nb][2] = t23.x - t01.y; bm[nb][3] = d.y;
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (m + 1 < K_STEPS) request(m + 1);
+            __builtin_amdgcn_sched_barrier(0);
             // the staging units sit BETWEEN the MFMAs (in the shadow of the one just issued), not in front of the step's reads: an LDS
             // store ahead of the reads is waited for with them (LDS returns in order) and lengthens the step's dependent chain
 #pragma unroll
@@ -314,7 +346,7 @@ extern "C" int hvpr_conv2d_wino_wgrad_nhwc_f32(const float *x, int N, int H, int
     hipStream_t s = (hipStream_t)stream;
     static unsigned long long lds_set = 0ull;
     if (hvpr_ensure_dyn_lds((const void *)k_wgrad_wino, kLds, &lds_set) != 0) return HVPR_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_wgrad_wino, dim3(n_ot, a.n_chunks), dim3(NT), kLds, s, a);
+    hipLaunchKernelGGL(k_wgrad_wino, dim3(n_ot * a.n_chunks), dim3(NT), kLds, s, a);
     const long long per = (long long)Cout * Cin;
     hipLaunchKernelGGL(k_wgrad_wino_reduce, dim3(hvpr_cdiv(per, 16)), dim3(256), 0, s, a.part, a.n_chunks, Cout, Cin, dw);
     HVPR_CHECK_LAUNCH();
