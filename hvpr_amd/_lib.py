@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 4          # hvpr_abi_version() of the library these wrappers were written against (csrc/abi.hip)
+ABI_VERSION = 5          # hvpr_abi_version() of the library these wrappers were written against (csrc/abi.hip)
 LIB_PATH = os.environ.get("HVPR_AMD_LIB", os.path.join(_HERE, "libhvpr_amd.so"))   # override: kernel experiments only
 
 _c = ctypes
@@ -93,6 +93,7 @@ SIGNATURES = {
     "hvpr_conv2d_wino_pack_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "hvpr_conv2d_wino_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
     "hvpr_conv2d_wino_stats_rows": (_I, [_I, _I, _I]),
+    "hvpr_bn_train_affine_f32": (_I, [_P, _P, _P, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "hvpr_bn_finalize_partials_f32": (_I, [_P, _I, _I, _c.c_longlong, _F, _P, _P, _P, _P]),
     "hvpr_conv2d_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
 }

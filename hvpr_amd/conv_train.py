@@ -179,6 +179,34 @@ def bn_statistics(z, eps, partials=None):
     return sync_moments(s1, s2, P, eps, sg[0])
 
 
+def _affine(mean, var, invstd, gamma, beta, count, running):
+    """scale = gamma * invstd, shift = beta - mean * scale for the normalising kernel.  running = (running_mean, running_var,
+    num_batches_tracked, momentum) of the nn.BatchNorm2d, or None: updated like the module does in train mode — in the same launch
+    (hvpr_bn_train_affine_f32) when the moments are this rank's own; the SyncBatchNorm path keeps its torch arithmetic and updates
+    them in _update_running.  Returns (scale, shift, running statistics are done)."""
+    if _sync_group() is not None or torch.is_tensor(count):
+        scale = (gamma.detach() * invstd).contiguous()
+        return scale, (beta.detach() - mean * scale).contiguous(), False
+    scale, shift = torch.empty_like(mean), torch.empty_like(mean)
+    rm = rv = nbt = None
+    m = mu = 0.0
+    if running is not None and running[3] is not None:
+        rm, rv, nbt, m = running
+        mu = m * count / max(count - 1, 1)
+    check(lib().hvpr_bn_train_affine_f32(mean.data_ptr(), var.data_ptr(), invstd.data_ptr(), mean.numel(), kernels._ptr(gamma.detach(), torch.float32, "gamma"),
+                                         kernels._ptr(beta.detach(), torch.float32, "beta"), float(m), float(mu), kernels._ptr(rm, torch.float32, "running_mean"),
+                                         kernels._ptr(rv, torch.float32, "running_var"), kernels._ptr(nbt, torch.int64, "num_batches_tracked"),
+                                         scale.data_ptr(), shift.data_ptr(), kernels._stream()), "hvpr_bn_train_affine_f32")
+    return scale, shift, rm is not None
+
+
+def _running_of(bn):
+    """The running buffers of `bn` for _affine (None when it keeps none or averages cumulatively: _update_running then does it)."""
+    if not bn.track_running_stats or bn.momentum is None or bn.running_mean is None:
+        return None
+    return (bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum))
+
+
 def _bn_backward(dy, z, P, C, scale, shift, mean, invstd, relu, gate, dgate, count):
     """dz, d gamma, d beta of the train-mode BatchNorm (+ ReLU, + SFM gate) — one kernel pair per rank, or, with SyncBatchNorm,
     the two halves with the all-reduce of the two sums between them (count: the global count of the forward)."""
@@ -314,14 +342,13 @@ class _BNReLU(torch.autograd.Function):
     x_att = attention(sfm(x_att), y) + x_att (base_bev_backbone.py:250-255) in the same two kernels."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, eps, relu, gate, resid, partials=None):
+    def forward(ctx, z, gamma, beta, eps, relu, gate, resid, partials=None, running=None):
         z = z.contiguous()
         C = z.shape[-1]
         P = z.numel() // C
         dev = z.device
         mean, var, invstd, count = bn_statistics(z, eps, partials)
-        scale = (gamma.detach() * invstd).contiguous()
-        shift = (beta.detach() - mean * scale).contiguous()
+        scale, shift, ctx.running_done = _affine(mean, var, invstd, gamma, beta, count, running)
         y = torch.empty_like(z)
         if gate is not None:
             gate, resid = gate.detach().contiguous(), resid.detach().contiguous()
@@ -343,7 +370,7 @@ class _BNReLU(torch.autograd.Function):
         P = z.numel() // C
         dgate = torch.empty_like(gate) if gate is not None else None
         dz, dgamma, dbeta = _bn_backward(dy, z, P, C, scale, shift, mean, invstd, ctx.relu, gate, dgate, ctx.count)
-        return dz, dgamma, dbeta, None, None, dgate, (dy if gate is not None else None), None
+        return dz, dgamma, dbeta, None, None, dgate, (dy if gate is not None else None), None, None
 
 
 _ones_cache = {}
@@ -362,15 +389,14 @@ class _SfmStep(torch.autograd.Function):
     leaving a 3-tensor element-wise add of full activations to autograd."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, eps, gate):
+    def forward(ctx, x, weight, gamma, beta, eps, gate, running=None):
         x = x.contiguous()
         z, partials = conv_fwd_raw(x, weight, 1, stats=True)
         C = z.shape[-1]
         P = z.numel() // C
         dev = z.device
         mean, var, invstd, count = bn_statistics(z, eps, partials)
-        scale = (gamma.detach() * invstd).contiguous()
-        shift = (beta.detach() - mean * scale).contiguous()
+        scale, shift, ctx.running_done = _affine(mean, var, invstd, gamma, beta, count, running)
         gate = gate.detach().contiguous()
         assert gate.numel() == P
         y = torch.empty_like(z)
@@ -400,13 +426,15 @@ class _SfmStep(torch.autograd.Function):
                 dx = conv_fwd_raw(dz, weight, 1, adjoint=True) + dy
         if ctx.needs_input_grad[1]:
             dw = conv_wgrad(x, dz, 9, 1, cout, cin)
-        return dx, dw, dgamma, dbeta, None, dgate
+        return dx, dw, dgamma, dbeta, None, dgate, None
 
 
 def sfm_step(x, weight, bn, gate):
     """gate * relu(bn(conv3x3(x))) + x with train-mode `bn` (running statistics updated like nn.BatchNorm2d), one autograd node."""
-    y, mean, var, count = _SfmStep.apply(x, weight, bn.weight, bn.bias, bn.eps, gate)
-    _update_running(bn, mean, var, count if _sync_group() is not None else x.numel() // x.shape[-1])
+    running = _running_of(bn) if _sync_group() is None else None        # then updated inside, by the launch that forms scale / shift
+    y, mean, var, count = _SfmStep.apply(x, weight, bn.weight, bn.bias, bn.eps, gate, running)
+    if running is None:
+        _update_running(bn, mean, var, count if _sync_group() is not None else x.numel() // x.shape[-1])
     return y
 
 
@@ -438,8 +466,10 @@ def deconv(x, weight):
 def bn_relu(z, bn, relu=True, gate=None, resid=None, partials=None):
     """Train-mode nn.BatchNorm2d `bn` (its weight / bias / eps / momentum / running buffers) + optional ReLU on NHWC `z`; with
     gate (N,H,W,1) and resid (N,H,W,C): gate * relu(bn(z)) + resid, differentiable in all of them."""
-    y, mean, var, count = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu, gate, resid, partials)
-    _update_running(bn, mean, var, count if _sync_group() is not None else z.numel() // z.shape[-1])
+    running = _running_of(bn) if _sync_group() is None else None        # then updated inside, by the launch that forms scale / shift
+    y, mean, var, count = _BNReLU.apply(z, bn.weight, bn.bias, bn.eps, relu, gate, resid, partials, running)
+    if running is None:
+        _update_running(bn, mean, var, count if _sync_group() is not None else z.numel() // z.shape[-1])
     return y
 
 

@@ -4,8 +4,10 @@
 // 2: packed memory bank (bank_packed argument); 3: bank_packed is required and holds IEEE fp16 tiles (v_mfma_f32_16x16x32_f16) +
 // channel maxima; 4: the packed bank ends in 128 floats (64 channel maxima, their sum and maximum: hvpr_memory_bank_packed_floats grew
 // by 64) and the voxelizer workspace holds the one-launch index kernel's per-cell words and barrier flags (hvpr_voxelize_workspace_bytes
-// grew) — a caller that sized either buffer with a version-3 formula is too small: always size them with the two functions
-extern "C" int hvpr_abi_version(void) { return 4; }
+// grew) — a caller that sized either buffer with a version-3 formula is too small: always size them with the two functions; 5: adds
+// hvpr_bn_train_affine_f32; hvpr_conv2d_wino_wgrad_nhwc_f32 answers HVPR_ERR_UNSUPPORTED for images of 2 GB and more (32-bit offsets
+// inside an image; its workspace size is unchanged)
+extern "C" int hvpr_abi_version(void) { return 5; }
 
 extern "C" const char *hvpr_status_string(int status) {
     switch (status) {

@@ -272,6 +272,23 @@ __global__ void __launch_bounds__(256) k_bn_finalize(const float *__restrict__ w
     o0[c] = (float)m; o1[c] = (float)var; o2[c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// What a train-mode nn.BatchNorm2d does with the batch moments besides normalising, in one launch instead of eight element-wise
+// ones per layer: scale = gamma * invstd, shift = beta - mean * scale for the normalising kernel, and the running statistics
+// running = (1 - momentum) * running + momentum * (mean | unbiased variance), num_batches_tracked += 1 (torch/nn/modules/batchnorm.py).
+__global__ void __launch_bounds__(256) k_bn_affine(const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ invstd,
+                                                   int C, const float *__restrict__ gamma, const float *__restrict__ beta, float momentum,
+                                                   float momentum_unbiased, float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                   long long *__restrict__ tracked, float *__restrict__ scale, float *__restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && tracked) *tracked += 1;
+    if (c >= C) return;
+    const float sc = __fmul_rn(gamma[c], invstd[c]);
+    scale[c] = sc;
+    shift[c] = __fsub_rn(beta[c], __fmul_rn(mean[c], sc));
+    if (running_mean) running_mean[c] = fmaf(momentum, mean[c], __fmul_rn(running_mean[c], 1.f - momentum));
+    if (running_var) running_var[c] = fmaf(momentum_unbiased, var[c], __fmul_rn(running_var[c], 1.f - momentum));
+}
+
 // y = relu(z * scale + shift)   (scale = gamma * invstd, shift = beta - mean * scale);  with a gate: y = gate[p] * relu(..) + resid
 // (the SFM step x_att = attention(sfm(x_att), y) + x_att, base_bev_backbone.py:250-255)
 __global__ void __launch_bounds__(256) k_bn_apply(const float4 *__restrict__ z, long long n4, int groups, const float *__restrict__ scale,
@@ -409,6 +426,17 @@ extern "C" int hvpr_bn_finalize_partials_f32(const float *partials, int rows, in
     if (C < 4 || C > 1024) return HVPR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, rows, C, (double)count, eps, 0,
                        mean, var, invstd);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_bn_train_affine_f32(const float *mean, const float *var, const float *invstd, int C, const float *gamma, const float *beta,
+                                        float momentum, float momentum_unbiased, float *running_mean, float *running_var,
+                                        long long *num_batches_tracked, float *scale, float *shift, hvpr_stream_t stream) {
+    if (!mean || !var || !invstd || !gamma || !beta || !scale || !shift || C < 1) return HVPR_ERR_INVALID_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return HVPR_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_bn_affine, dim3(hvpr_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, var, invstd, C, gamma, beta, momentum,
+                       momentum_unbiased, running_mean, running_var, num_batches_tracked, scale, shift);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }

@@ -34,7 +34,7 @@ enum hvpr_status {
     HVPR_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after the launch           */
 };
 
-int hvpr_abi_version(void);     /* 4 (history: csrc/abi.hip); size every workspace / packed buffer with the *_bytes / *_floats functions */
+int hvpr_abi_version(void);     /* 5 (history: csrc/abi.hip); size every workspace / packed buffer with the *_bytes / *_floats functions */
 const char *hvpr_status_string(int status);
 
 /* SyncBatchNorm across ranks (reference: tools/train.py:119-120, --sync_bn -> torch.nn.SyncBatchNorm).  The training entry points
@@ -403,6 +403,10 @@ int hvpr_memory_train_bwd_f32(const float *x, const float *dy, long long R, cons
  *         overwritten.  Split-K over pixel tiles into `workspace` partials, summed in a fixed order: deterministic.
  *     hvpr_bn_stats_nhwc_f32: per-channel batch mean, biased variance and 1/sqrt(var + eps) of z [P, C] (train-mode BatchNorm,
  *         double-precision final sums).
+ *     hvpr_bn_train_affine_f32: what train-mode nn.BatchNorm2d does with the batch moments besides normalising, one launch:
+ *         scale = gamma * invstd, shift = beta - mean * scale, and (running_mean / running_var both non-NULL)
+ *         running = (1 - momentum) * running + momentum * mean | momentum_unbiased * var (momentum_unbiased = momentum * n / (n - 1)),
+ *         *num_batches_tracked += 1 (int64, may be NULL).
  *     hvpr_bn_relu_fwd_nhwc_f32: y = max(0, z * scale + shift) (relu == 0: no max); scale = gamma * invstd, shift = beta - mean * scale.
  *     hvpr_bn_relu_bwd_nhwc_f32: dz, dgamma, dbeta of y = relu(gamma * (z - mean) * invstd + beta) with BATCH statistics
  *         (the mean / variance terms are differentiated through).
@@ -423,6 +427,9 @@ int hvpr_conv2d_wgrad_nhwc_f32(const float *x, int N, int H, int W, int Cin, con
 size_t hvpr_bn_workspace_bytes(long long P, int C);
 int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float eps, float *mean, float *var, float *invstd, void *workspace,
                            size_t workspace_bytes, hvpr_stream_t stream);
+int hvpr_bn_train_affine_f32(const float *mean, const float *var, const float *invstd, int C, const float *gamma, const float *beta,
+                             float momentum, float momentum_unbiased, float *running_mean, float *running_var,
+                             long long *num_batches_tracked, float *scale, float *shift, hvpr_stream_t stream);
 int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, const float *gate,
                               const float *resid, float *y, hvpr_stream_t stream);
 int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
