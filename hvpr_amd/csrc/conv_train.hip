@@ -176,20 +176,27 @@ int wgrad_chunks(int N, int OH, int OW, int Cin, int Cout, int taps, int stride)
 // z [P, C] with C % 4 == 0.  A workgroup of 256 threads covers C/4 channel groups x (256 / (C/4)) pixel lanes and walks a
 // slab of pixels; per-thread fp32 partial sums over <= kSlab / lanes pixels, combined per workgroup in LDS in a fixed order,
 // one row per workgroup in the workspace, final sum in double by the finalising kernel: deterministic.
-constexpr int kBnSlab = 2048;       // pixels per workgroup
+// Pixels per workgroup: at most 2048, fewer while the pass has under ~2048 workgroups (eight per CU: a fixed 2048 gave the 73 k pixels
+// of the 512-channel level at batch 16 — 4 MB per tensor and workgroup — 36 workgroups on 256 CUs, and the 1.17 M pixels of the first
+// level 573: two on some CUs, three on others).
+int bn_slab(long long P) {
+    int slab = 2048;
+    while (slab > 64 && P / slab < 2048) slab >>= 1;
+    return slab;
+}
 
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_bn_reduce(const float *__restrict__ z, const float *__restrict__ dy, long long P, int C,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                    const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
                                                    const float *__restrict__ gate /* [P] or null: dy is multiplied by it */,
-                                                   float *__restrict__ ws /* [blocks][2][C] */) {
+                                                   int slab, float *__restrict__ ws /* [blocks][2][C] */) {
     __shared__ float4 s_a[256], s_b[256];
     const int groups = C / 4;                       // channel groups of 4
     const int lanes = 256 / groups > 0 ? 256 / groups : 1;     // pixel lanes per workgroup (groups <= 256)
     const int g = threadIdx.x % groups, pl = threadIdx.x / groups;
-    const long long p0 = (long long)blockIdx.x * kBnSlab;
-    const long long p1 = p0 + kBnSlab < P ? p0 + kBnSlab : P;
+    const long long p0 = (long long)blockIdx.x * slab;
+    const long long p1 = p0 + slab < P ? p0 + slab : P;
     float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
     if (pl < lanes) {
         float4 sc = A, sh = A, mu = A, is = A;
@@ -365,7 +372,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4 *__restrict__
     }
 }
 
-int bn_blocks(long long P) { return (int)((P + kBnSlab - 1) / kBnSlab); }
+int bn_blocks(long long P) { const int slab = bn_slab(P); return (int)((P + slab - 1) / slab); }
 
 __global__ void __launch_bounds__(256) k_zero_p(float *__restrict__ p, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
@@ -412,7 +419,7 @@ extern "C" int hvpr_bn_stats_nhwc_f32(const float *z, long long P, int C, float 
     if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
     const int blocks = bn_blocks(P);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, s, z, nullptr, P, C, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+    hipLaunchKernelGGL(k_bn_reduce<false>, dim3(blocks), dim3(256), 0, s, z, nullptr, P, C, nullptr, nullptr, nullptr, nullptr, 0, nullptr, bn_slab(P),
                        (float *)workspace);
     hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, eps, 0, mean,
                        var, invstd);
@@ -464,7 +471,7 @@ extern "C" int hvpr_bn_relu_bwd_sums_nhwc_f32(const float *dy, const float *z, l
     if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
     const int blocks = bn_blocks(P);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, s, z, dy, P, C, scale, shift, mean, invstd, relu, gate, (float *)workspace);
+    hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, s, z, dy, P, C, scale, shift, mean, invstd, relu, gate, bn_slab(P), (float *)workspace);
     // s1 -> dbeta, s2 -> dgamma  (d beta = sum dy_m, d gamma = sum dy_m * xhat)
     hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, s, (const float *)workspace, blocks, C, (double)P, 0.f, 1, dbeta,
                        dgamma, (float *)nullptr);
