@@ -173,16 +173,24 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     const unsigned w_co0 = (unsigned)(co0 * 4 * sizeof(float));
     const char *in_n = (const char *)(a.in + (size_t)n * a.H * a.W * a.Cin);   // uniform
 
-    auto stage = [&](int chunk, int buf) {
-        const char *pbase = in_n + (size_t)chunk * (KSTAGE * sizeof(float));
-        const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * sizeof(float);
-#pragma unroll
-        for (int i = 0; i < NLD_P; ++i)
+    // one staging piece of (chunk, buf): pieces 0 .. NLD_P-1 = input patch, NLD_P .. NLD_P+NLD_W-1 = weight slab
+    auto stage_piece = [&](int chunk, int buf, int i) {
+        if (i < NLD_P) {
+            const char *pbase = in_n + (size_t)chunk * (KSTAGE * sizeof(float));
             if (pok[i]) lds_dma16(pbase, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * 256) * 16u);
-#pragma unroll
-        for (int i = 0; i < NLD_W; ++i)
-            if (wok[i]) lds_dma16(wbase, woff0[i] + w_co0, lds_w0 + (unsigned)(buf * W_PAD + i * 256) * 16u);
+        } else {
+            const int j = i - NLD_P;
+            const char *wbase = (const char *)a.wpk + (size_t)chunk * NSUB * w_chunk_stride * sizeof(float);
+            if (wok[j]) lds_dma16(wbase, woff0[j] + w_co0, lds_w0 + (unsigned)(buf * W_PAD + j * 256) * 16u);
+        }
     };
+    auto stage = [&](int chunk, int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD_P + NLD_W; ++i) stage_piece(chunk, buf, i);
+    };
+    // taps of a chunk after whose MFMAs the next stage's DMA pieces go out (conv_wino.hip: issued in one go in front of the chunk
+    // they are several hundred cycles in which this wave feeds the matrix cores nothing); 0 = in front (one-tap chunks are too short)
+    constexpr int DEAL = TAPS == 9 ? 6 : (TAPS == 4 ? 3 : 0);
     // a DMA piece outside the image is skipped and must read as zero: clear both stages first when this tile's patch
     // sticks out of the image (uniform decision; interior tiles overwrite every slot they read)
     const bool border = iy0 < 0 || ix0 < 0 || iy0 + PH > a.H || ix0 + PW > a.W;
@@ -216,7 +224,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
 #ifdef HVPR_EXP_TIMING
         const long long q1 = __builtin_readcyclecounter();
 #endif
-        if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
+        if (DEAL == 0 && c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
 #ifdef HVPR_EXP_TIMING
         const long long q2 = __builtin_readcyclecounter();
 #endif
@@ -250,6 +258,12 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][nb].w, av[cur][mb].w, acc[mb][nb], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
+            if (DEAL > 0 && tap < DEAL && c + 1 < n_chunks) {
+                constexpr int NPC = (NLD_P + NLD_W + DEAL - 1) / (DEAL > 0 ? DEAL : 1);
+#pragma unroll
+                for (int i = tap * NPC; i < (tap + 1) * NPC && i < NLD_P + NLD_W; ++i) stage_piece(c + 1, BUF ^ 1, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #ifdef HVPR_EXP_TIMING
         if (dbg_slot >= 0 && dbg_tile == 1 && lane == 0 && c < 64) {

@@ -138,16 +138,21 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
     const char *w_ct = (const char *)(a.wpk + (size_t)(NB == 2 ? ct : ct >> 1) * n_chunks * (W_V4 * 4));           // uniform
     const unsigned w_half = NB == 2 ? 0u : (unsigned)(ct & 1) * 32u * 16u;
 
-    auto stage = [&](int chunk, int buf) {
-        const char *pbase_g = in_n + (size_t)chunk * (KC * sizeof(float));
-        const char *wbase = w_ct + (size_t)chunk * (W_V4 * 16);
-#pragma unroll
-        for (int i = 0; i < NLD_P; ++i)
+    // one staging piece of (chunk, buf): pieces 0 .. NLD_P-1 = input patch, NLD_P .. NLD_P+NLD_W-1 = filter slab
+    auto stage_piece = [&](int chunk, int buf, int i) {
+        if (i < NLD_P) {
+            const char *pbase_g = in_n + (size_t)chunk * (KC * sizeof(float));
             if (pok[i]) lds_dma16(pbase_g, poff[i], lds_patch0 + (unsigned)(buf * PATCH_PAD + i * NT) * 16u);
+        } else {
+            const int j = i - NLD_P;
+            const char *wbase = w_ct + (size_t)chunk * (W_V4 * 16);
+            lds_dma16(wbase, NB == 2 ? (unsigned)((tid + j * NT) * 16) : (unsigned)((((tid + j * NT) >> 5) * 64 + ((tid + j * NT) & 31)) * 16) + w_half,
+                      lds_w0 + (unsigned)(buf * W_V4T + j * NT) * 16u);
+        }
+    };
+    auto stage = [&](int chunk, int buf) {
 #pragma unroll
-        for (int i = 0; i < NLD_W; ++i)
-            lds_dma16(wbase, NB == 2 ? (unsigned)((tid + i * NT) * 16) : (unsigned)((((tid + i * NT) >> 5) * 64 + ((tid + i * NT) & 31)) * 16) + w_half,
-                      lds_w0 + (unsigned)(buf * W_V4T + i * NT) * 16u);
+        for (int i = 0; i < NLD_P + NLD_W; ++i) stage_piece(chunk, buf, i);
     };
     const bool border = iy0 < 0 || ix0 < 0 || iy0 + PH > a.H || ix0 + PW > a.W;
     if (border) {
@@ -172,8 +177,7 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
         const float4 *sp = s_patch + BUF * PATCH_PAD;
         const float4 *sw = s_w + BUF * W_V4T;
         float4 d0[4], d1[4], u[4][NB];
-        // this chunk's first operands are requested BEFORE the next stage's DMA pieces are issued: the ~10 pieces take a few
-        // hundred cycles of issue, which covers the LDS latency of the reads (other stage: no conflict)
+        // this chunk's first operands
 #pragma unroll
         for (int jx = 0; jx < 4; ++jx) {
             d0[jx] = sp[p_off0 + (jx & 1) * 10 + (jx >> 1)];
@@ -183,8 +187,6 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) u[b][nb] = sw[u_off + b * 2 * BNT + nb * 32];
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < n_chunks) stage(c + 1, BUF ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         // input transform: t_j = d[r0][j] +- d[r1][j];  V[a][.] = (t0 - t2, t1 + t2, t2 - t1, t1 - t3)
         float4 t[4], v[4];
@@ -204,6 +206,16 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].y, v[b].y, acc[b][nb], 0, 0, 0);
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].z, v[b].z, acc[b][nb], 0, 0, 0);
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].w, v[b].w, acc[b][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // The next stage's DMA pieces go out after the first three of the chunk's four MFMA groups, in the shadow of the eight
+            // MFMAs just queued — issued in one go ahead of the transform (the round-4 form) the ~10 pieces are several hundred cycles in
+            // which this wave feeds the matrix cores nothing; after the last group they would land too late for the next chunk.
+            // Frame pipeline 424 -> 439 frames/s; dealt to two groups 435, to all four 428 (profiles/NOTES_r05.md section 11).
+            if (c + 1 < n_chunks) {
+                constexpr int NPC = (NLD_P + NLD_W + 2) / 3;
+#pragma unroll
+                for (int i = b * NPC; i < (b + 1) * NPC && i < NLD_P + NLD_W; ++i) stage_piece(c + 1, BUF ^ 1, i);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
