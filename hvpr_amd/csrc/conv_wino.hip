@@ -206,16 +206,19 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].y, v[b].y, acc[b][nb], 0, 0, 0);
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].z, v[b].z, acc[b][nb], 0, 0, 0);
                 acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[b][nb].w, v[b].w, acc[b][nb], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // The next stage's DMA pieces go out after the first three of the chunk's four MFMA groups, in the shadow of the eight
-            // MFMAs just queued — issued in one go ahead of the transform (the round-4 form) the ~10 pieces are several hundred cycles in
-            // which this wave feeds the matrix cores nothing; after the last group they would land too late for the next chunk.
-            // Frame pipeline 424 -> 439 frames/s; dealt to two groups 435, to all four 428 (profiles/NOTES_r05.md section 11).
-            if (c + 1 < n_chunks) {
-                constexpr int NPC = (NLD_P + NLD_W + 2) / 3;
+                // The next stage's DMA pieces go out a few at a time after the first DEAL of the chunk's 4 NB groups of four MFMAs, in
+                // the shadow of the MFMAs just queued.  Issued in one go ahead of the transform (the round-4 form) the ~10 pieces are
+                // several hundred cycles in which this wave feeds the matrix cores nothing; after the last groups they would land too
+                // late for the next chunk.  Frame pipeline, frames/s: in front 424 | after the b groups: first two 435, first three
+                // 439, all four 428 | after the groups of four: first four 440.5, first five 444.7, first six 444.0 (NOTES_r05 section 11).
+                constexpr int DEAL = 4 * NB > 5 ? 5 : 4 * NB - 1, NPF = (NLD_P + NLD_W + DEAL - 1) / DEAL;
+                static_assert(DEAL * NPF >= NLD_P + NLD_W, "every piece goes out");
+                if (c + 1 < n_chunks && b * NB + nb < DEAL) {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = b * NPC; i < (b + 1) * NPC && i < NLD_P + NLD_W; ++i) stage_piece(c + 1, BUF ^ 1, i);
+                    for (int i = (b * NB + nb) * NPF; i < (b * NB + nb + 1) * NPF && i < NLD_P + NLD_W; ++i) stage_piece(c + 1, BUF ^ 1, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
