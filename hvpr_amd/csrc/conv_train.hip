@@ -29,9 +29,12 @@ struct WgradArgs {
     int tiles_x, tiles_y, n_pt, n_chunks, n_ci_tiles;
 };
 
-template <int TAPS, int S, int TH, int TW, int MB, int NB>
+// WM x WN = 4 waves over (co, ci): 2 x 2, or 1 x 4 for layers with few output channels (the detection head: 24 — a 128-row block
+// multiplies four zero rows for every real one)
+template <int TAPS, int S, int TH, int TW, int MB, int NB, int WM = 2>
 __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
-    constexpr int BM = 64 * MB, BN = 64 * NB;                 // co x ci block of the workgroup
+    constexpr int WN = 4 / WM;
+    constexpr int BM = 32 * WM * MB, BN = 32 * WN * NB;       // co x ci block of the workgroup
     constexpr int HALO = TAPS == 9 ? 2 : 0;
     constexpr int PH = (TH - 1) * S + 1 + HALO, PW = (TW - 1) * S + 1 + HALO;
     constexpr int NPX = TH * TW, NPP = PH * PW;
@@ -41,7 +44,7 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float s_x[NPP * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1, half = lane >> 5, l31 = lane & 31;
+    const int wm = wid / WN, wn = wid % WN, half = lane >> 5, l31 = lane & 31;
     const int ot = blockIdx.x, chunk = blockIdx.y;
     const int co0 = (ot / a.n_ci_tiles) * BM, ci0 = (ot % a.n_ci_tiles) * BN;
 
@@ -149,23 +152,28 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ 
     dw[((size_t)co * Cin + ci) * taps + t] = s;
 }
 
-template <int TAPS, int S, int TH, int TW, int MB, int NB>
+template <int TAPS, int S, int TH, int TW, int MB, int NB, int WM = 2>
 int launch_wgrad(WgradArgs a, int target_wgs, hipStream_t s) {
+    constexpr int BM = 32 * WM * MB, BN = 32 * (4 / WM) * NB;
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
     a.n_pt = a.N * a.tiles_x * a.tiles_y;
-    a.n_ci_tiles = (a.Cin + 64 * NB - 1) / (64 * NB);
-    const int n_ot = a.n_ci_tiles * ((a.Cout + 64 * MB - 1) / (64 * MB));
-    hipLaunchKernelGGL((k_wgrad<TAPS, S, TH, TW, MB, NB>), dim3(n_ot, a.n_chunks), dim3(256), 0, s, a);
+    a.n_ci_tiles = (a.Cin + BN - 1) / BN;
+    const int n_ot = a.n_ci_tiles * ((a.Cout + BM - 1) / BM);
+    hipLaunchKernelGGL((k_wgrad<TAPS, S, TH, TW, MB, NB, WM>), dim3(n_ot, a.n_chunks), dim3(256), 0, s, a);
     (void)target_wgs;
     return 0;
 }
 
+// 1x1 layers with at most 32 output channels and more than 256 input channels: one 32-row block, all four waves along ci (32 x 384)
+bool wgrad_few_rows(int Cin, int Cout, int taps) { return taps == 1 && Cout <= 32 && Cin > 256; }
+
 int wgrad_chunks(int N, int OH, int OW, int Cin, int Cout, int taps, int stride) {
     const int th = (taps == 9 && stride == 1) ? 8 : 4, tw = 8;
     const long long n_pt = (long long)N * ((OH + th - 1) / th) * ((OW + tw - 1) / tw);
-    const int bm = taps == 9 ? 64 : 128;
-    const int n_ot = ((Cin + bm - 1) / bm) * ((Cout + bm - 1) / bm);
+    const bool few = wgrad_few_rows(Cin, Cout, taps);
+    const int bm = few ? 32 : (taps == 9 ? 64 : 128), bn = few ? 384 : bm;
+    const int n_ot = ((Cin + bn - 1) / bn) * ((Cout + bm - 1) / bm);
     long long chunks = (512 + n_ot - 1) / n_ot;                 // ~2 workgroups per CU
     if (chunks > n_pt) chunks = n_pt;
     if (chunks < 1) chunks = 1;
@@ -400,6 +408,7 @@ extern "C" int hvpr_conv2d_wgrad_nhwc_f32(const float *x, int N, int H, int W, i
     hipStream_t s = (hipStream_t)stream;
     if (taps == 9 && stride == 1) launch_wgrad<9, 1, 8, 8, 1, 1>(a, 512, s);
     else if (taps == 9) launch_wgrad<9, 2, 4, 8, 1, 1>(a, 512, s);
+    else if (wgrad_few_rows(Cin, Cout, taps)) launch_wgrad<1, 1, 4, 8, 1, 3, 1>(a, 512, s);
     else launch_wgrad<1, 1, 4, 8, 2, 2>(a, 512, s);
     const long long per = (long long)taps * Cout * Cin;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(hvpr_cdiv(per, 256)), dim3(256), 0, s, a.part, a.n_chunks, taps, Cout, Cin, dw);

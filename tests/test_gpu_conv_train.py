@@ -50,6 +50,26 @@ def test_conv3x3_forward_dgrad_wgrad_match_torch(N, H, W, cin, cout, stride):
     _close(dw, dwr, what="wgrad")
 
 
+# 1x1 layers: the detection head (384 -> 24: the few-output-rows form of the weight gradient, all four waves along ci), the same with
+# ragged channel counts / sizes, and the 128 x 128 block form on either side of the switch (Cout <= 32 and Cin > 256)
+@pytest.mark.parametrize("N,H,W,cin,cout", [(1, 248, 296, 384, 24), (2, 31, 45, 384, 8), (1, 9, 7, 512, 32), (2, 13, 5, 264, 16),
+                                            (1, 31, 45, 256, 24), (1, 31, 45, 384, 40), (1, 62, 74, 512, 128)])
+def test_conv1x1_forward_dgrad_wgrad_match_float64(N, H, W, cin, cout):
+    g = torch.Generator().manual_seed(H + cin + cout)
+    x = torch.randn(N, H, W, cin, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV).requires_grad_(True)
+    z = ct.conv(x, w, 1)
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    zr = F.conv2d(xr.permute(0, 3, 1, 2), wr).permute(0, 2, 3, 1)
+    _close(z, zr, rtol=2e-5, what="forward")
+    dz = torch.randn(z.shape, generator=g).to(DEV)
+    dx, dw = torch.autograd.grad(z, (x, w), dz)
+    dxr, dwr = torch.autograd.grad(zr, (xr, wr), dz.double())
+    _close(dx, dxr, rtol=2e-5, what="dgrad")
+    _close(dw, dwr, rtol=2e-5, what="wgrad")
+    assert torch.equal(dw, ct.conv_wgrad(x.detach(), dz, 1, 1, cout, cin))          # deterministic
+
+
 @pytest.mark.parametrize("N,H,W,cin,cout,s", [(1, 248, 296, 128, 128, 1), (1, 124, 148, 256, 128, 2), (1, 62, 74, 512, 128, 4),
                                                (2, 9, 7, 128, 128, 2), (2, 5, 6, 64, 128, 4)])
 def test_deconv_forward_and_backward_match_torch(N, H, W, cin, cout, s):
