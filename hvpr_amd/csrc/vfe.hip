@@ -459,7 +459,8 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
 #ifdef HVPR_EXP_TIMING
     long long tstamp[10];
     tstamp[0] = __builtin_readcyclecounter();
-    int t_passes = 0, t_sorted = 0;
+    int t_passes = 0;
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_front0 = 0, t_win = 0, t_winacc = 0;
 #endif
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, col = lane & 31;
     // One frame is a single round of windows with most SIMDs idle, and the launch lasts as long as its slowest wave: a wave
@@ -523,7 +524,14 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
         unsigned long long todo = __ballot(flag && lane <= kWin && rec.y >= 0);
 
         bool first = true;
+#ifdef HVPR_EXP_TIMING
+        t_win = __builtin_readcyclecounter();
+#endif
         while (todo != 0ull) {
+#ifdef HVPR_EXP_TIMING
+            t_front0 = __builtin_readcyclecounter();
+            t_winacc += t_front0 - t_win;
+#endif
             const bool mine = !g.split || (first ? role == 0 : role == 1);
             if (g.split && role == 0 && !first) break;
             first = false;
@@ -705,10 +713,17 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
                 }
             }
 #ifdef HVPR_EXP_TIMING
-            if (t_passes++ == 0) tstamp[2] = __builtin_readcyclecounter();
+            t_passes++;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            tstamp[2] = __builtin_readcyclecounter();
+            tacc[0] += tstamp[2] - t_front0;
 #endif
             vfe_pass<true>(W, L, s_zt[wid], v, pt, live, live, proc, proc && n < P, n, seg0, cd, row, cell, endmask, startsproc, g.spatial,
                            g.spatial_channels, g.spatial_scale VFE_TPASS);
+#ifdef HVPR_EXP_TIMING
+            for (int q = 0; q < 7; ++q) tacc[1 + q] += tstamp[3 + q] - tstamp[2 + q];
+            t_win = __builtin_readcyclecounter();
+#endif
 #ifdef HVPR_EXP_TIMING
             if (false)
                 printf("vfe wg %d pass %d (pillars %d): prologue %lld | to first pass %lld | front %lld | decor %lld | l0+a %lld | xmax %lld | "
@@ -723,8 +738,8 @@ __global__ void __launch_bounds__(256, 2) k_vfe_gather(int P, VfeParams v, Gathe
 #ifdef HVPR_EXP_TIMING
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if ((wblk % 37) == 0 && threadIdx.x == 0)
-        printf("vfe-abs work blk %d role %d passes %d (sorted %d): %lld .. %lld (x10 ns), prologue %lld | to first pass %lld | front %lld decor %lld l0 %lld xmax %lld pillar %lld combine %lld final %lld cycles\n", wblk, role, t_passes, t_sorted, rt0,
-               (long long)__builtin_amdgcn_s_memrealtime(), tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4], tstamp[6] - tstamp[5], tstamp[7] - tstamp[6], tstamp[8] - tstamp[7], tstamp[9] - tstamp[8]);
+        printf("vfe-abs work blk %d role %d passes %d: %lld x10 ns, prologue %lld | sums over passes: between passes %lld front %lld | s23 %lld s34 %lld s45 %lld s56 %lld s67 %lld s78 %lld s89 %lld cycles\n", wblk, role, t_passes,
+               (long long)__builtin_amdgcn_s_memrealtime() - rt0, tstamp[1] - tstamp[0], t_winacc, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6], tacc[7]);
 #endif
 }
 
