@@ -257,7 +257,8 @@ def conv_wgrad(x, dz, taps, stride, cout, cin):
     OH, OW = dz.shape[1], dz.shape[2]
     k = 3 if taps == 9 else 1
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
-    if taps == 9 and stride == 1 and kernels.conv_algo() == "winograd":
+    # (the Winograd-domain kernel addresses inside an image with 32 bits: images of 2 GB and more go to the direct kernel)
+    if taps == 9 and stride == 1 and kernels.conv_algo() == "winograd" and H * W * max(cin, cout) * 4 < 2 ** 31:
         nbytes = lib().hvpr_conv2d_wino_wgrad_workspace_bytes(N, H, W, cin, cout)
         ws = _workspace(nbytes, x.device)
         check(lib().hvpr_conv2d_wino_wgrad_nhwc_f32(kernels._ptr(x, torch.float32, "x"), N, H, W, cin, kernels._ptr(dz, torch.float32, "dz"),
