@@ -162,6 +162,11 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
             for (int i = 0; i < NLD_P; ++i) s_patch[b * PATCH_PAD + tid + i * NT] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
+    // This tile's bias row (BNT floats) is parked in the patch area's unused tail (slots PH * ROWP .. of plane 0, stage 0: never a DMA
+    // destination, never a K-loop operand) by sixteen lanes now; the epilogue then takes its eight float4 from LDS instead of issuing
+    // eight global loads per lane between its stores — a vector-memory instruction costs the issuing wave ≈145 cycles on this part.
+    static_assert(PH * ROWP + BNT / 4 <= PPAD, "room for the bias row behind the patch");
+    if (tid < BNT / 4) s_patch[PH * ROWP + tid] = *(const float4 *)(a.bias + co0 + tid * 4);
     f32x16 acc[4][NB];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -271,7 +276,7 @@ __global__ void __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(2
                     const float4 x0 = s_w[((((grp * 4 + p) * 2 + q) * NBP + nl) * 4 + g) * 64 + lane];
                     const float4 x1 = s_w[((((grp * 4 + p + 1) * 2 + q) * NBP + nl) * 4 + g) * 64 + lane];
                     const float4 x2 = s_w[((((grp * 4 + p + 2) * 2 + q) * NBP + nl) * 4 + g) * 64 + lane];
-                    const float4 bias = *(const float4 *)(a.bias + col);
+                    const float4 bias = s_patch[PH * ROWP + (col - co0) / 4];
                     float4 y = f4_add(f4_fma(sg, x2, f4_fma(sg, x1, x0)), bias);       // p = 0: x0 + x1 + x2;  p = 1: x1 - x2 - x3
                     if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
                     if (a.gate) {
