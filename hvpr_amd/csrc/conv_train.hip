@@ -287,34 +287,40 @@ __global__ void __launch_bounds__(256) k_bn_finalize(const float *__restrict__ w
     o0[c] = (float)m; o1[c] = (float)var; o2[c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// The same for C % 4 == 0 with four adjacent channels per wave: a lane takes the row's 16 bytes of them (the one-channel form reads 4
-// of every 64-byte sector it touches; with the 2 k rows of the finer slabs and the 9 k pixel tiles of a level-0 Winograd layer the pass
-// was 24 us per call, 138 calls per training step).  Same sums in the same order per channel.
+// The same for C % 4 == 0 with four adjacent channels per WORKGROUP: thread t takes rows t, t + 256, ... as 16-byte reads (the one-channel
+// form reads 4 of every 64-byte sector it touches and gives a channel one wave: with the 2 k rows of the finer slabs and the 9 k pixel
+// tiles of a level-0 Winograd layer the pass was 24 us per call, 138 calls per training step), the four waves' sums meet in LDS in wave
+// order: deterministic.
 __global__ void __launch_bounds__(256) k_bn_finalize4(const float *__restrict__ ws, int blocks, int C, double count, float eps, int bwd,
                                                       float *__restrict__ o0, float *__restrict__ o1, float *__restrict__ o2) {
-    const int c = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4, lane = threadIdx.x & 63;
-    if (c >= C) return;
+    __shared__ double s_part[4][8];
+    const int c = blockIdx.x * 4, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = lane; i < blocks; i += 64) {
+    for (int i = threadIdx.x; i < blocks; i += 256) {
         const float4 x = *(const float4 *)(ws + (size_t)i * 2 * C + c), y = *(const float4 *)(ws + (size_t)i * 2 * C + C + c);
         a[0] += (double)x.x; a[1] += (double)x.y; a[2] += (double)x.z; a[3] += (double)x.w;
         b[0] += (double)y.x; b[1] += (double)y.y; b[2] += (double)y.z; b[3] += (double)y.w;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a[k] = wave_sum_f64(a[k]); b[k] = wave_sum_f64(b[k]); }
-    if (lane != 0) return;
+    if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (bwd) { o0[c + k] = (float)a[k]; o1[c + k] = (float)b[k]; continue; }
-        const double m = a[k] / count;
-        double var = b[k] / count - m * m;
-        if (var < 0.0) var = 0.0;
-        o0[c + k] = (float)m; o1[c + k] = (float)var; o2[c + k] = (float)(1.0 / sqrt(var + (double)eps));
+        for (int k = 0; k < 4; ++k) { s_part[wid][k] = a[k]; s_part[wid][4 + k] = b[k]; }
     }
+    __syncthreads();
+    if (threadIdx.x >= 4) return;
+    const int k = threadIdx.x;
+    const double sa = ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k];
+    const double sb = ((s_part[0][4 + k] + s_part[1][4 + k]) + s_part[2][4 + k]) + s_part[3][4 + k];
+    if (bwd) { o0[c + k] = (float)sa; o1[c + k] = (float)sb; return; }
+    const double m = sa / count;
+    double var = sb / count - m * m;
+    if (var < 0.0) var = 0.0;
+    o0[c + k] = (float)m; o1[c + k] = (float)var; o2[c + k] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 void launch_bn_finalize(const float *ws, int blocks, int C, double count, float eps, int bwd, float *o0, float *o1, float *o2, hipStream_t s) {
-    if (C % 4 == 0) hipLaunchKernelGGL(k_bn_finalize4, dim3(hvpr_cdiv(C, 16)), dim3(256), 0, s, ws, blocks, C, count, eps, bwd, o0, o1, o2);
+    if (C % 4 == 0) hipLaunchKernelGGL(k_bn_finalize4, dim3(C / 4), dim3(256), 0, s, ws, blocks, C, count, eps, bwd, o0, o1, o2);
     else hipLaunchKernelGGL(k_bn_finalize, dim3(hvpr_cdiv(C, 4)), dim3(256), 0, s, ws, blocks, C, count, eps, bwd, o0, o1, o2);
 }
 
