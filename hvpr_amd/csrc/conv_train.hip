@@ -140,14 +140,28 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs a) {
             }
 }
 
-// dW[co][ci][tap] (torch's (Cout, Cin, k, k) layout) = sum over chunks of part[chunk][tap][co][ci], in chunk order
+// dW[co][ci][tap] (torch's (Cout, Cin, k, k) layout) = sum over chunks of part[chunk][tap][co][ci].  A workgroup = 64 elements x 4 chunk
+// slices: thread (e, sl) adds chunks sl, sl + 4, ... in four independent partial sums (one thread per element walking all chunks is a chain
+// of up to 512 dependent loads on a few dozen workgroups: 88 us per call for the one-tile layers), the slices meet in LDS in a fixed order.
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ part, int n_chunks, int taps, int Cout, int Cin,
                                                       float *__restrict__ dw) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // over [tap][co][ci]
+    __shared__ float s_sl[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;                       // over [tap][co][ci]
     const long long per = (long long)taps * Cout * Cin;
-    if (i >= per) return;
-    float s = 0.f;
-    for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * per + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < per) {
+        const float *src = part + i;
+        int c = sl;
+        for (; c + 12 < n_chunks; c += 16) {
+            s0 += src[(size_t)c * per]; s1 += src[(size_t)(c + 4) * per]; s2 += src[(size_t)(c + 8) * per]; s3 += src[(size_t)(c + 12) * per];
+        }
+        for (; c < n_chunks; c += 4) s0 += src[(size_t)c * per];
+    }
+    s_sl[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl != 0 || i >= per) return;
+    const float s = (s_sl[0][e] + s_sl[1][e]) + (s_sl[2][e] + s_sl[3][e]);
     const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), t = (int)(i / ((long long)Cin * Cout));
     dw[((size_t)co * Cin + ci) * taps + t] = s;
 }
@@ -448,7 +462,7 @@ extern "C" int hvpr_conv2d_wgrad_nhwc_f32(const float *x, int N, int H, int W, i
     else if (wgrad_few_rows(Cin, Cout, taps)) launch_wgrad<1, 1, 4, 8, 1, 3, 1>(a, 512, s);
     else launch_wgrad<1, 1, 4, 8, 2, 2>(a, 512, s);
     const long long per = (long long)taps * Cout * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(hvpr_cdiv(per, 256)), dim3(256), 0, s, a.part, a.n_chunks, taps, Cout, Cin, dw);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(hvpr_cdiv(per, 64)), dim3(256), 0, s, a.part, a.n_chunks, taps, Cout, Cin, dw);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
