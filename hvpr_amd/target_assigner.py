@@ -91,21 +91,23 @@ class AxisAlignedTargetAssigner:
         A = anchors.shape[0]
         ab = nearest_bev_boxes(anchors[:, 0:7])                                     # (A,4)
         gb = nearest_bev_boxes(gt.reshape(B * G, -1)[:, 0:7]).view(B, G, 4)
-        xl = torch.max(ab[None, :, None, 0], gb[:, None, :, 0])
-        xr = torch.min(ab[None, :, None, 2], gb[:, None, :, 2])
-        yl = torch.max(ab[None, :, None, 1], gb[:, None, :, 1])
-        yr = torch.min(ab[None, :, None, 3], gb[:, None, :, 3])
+        # (B,G,A) with the anchors innermost: the maximum over the G ground truths then runs over a strided outer dimension and the one
+        # over the anchors over contiguous rows — with G innermost torch reduced 8-element rows at 46 GB/s (0.4 ms per pass of four frames)
+        xl = torch.max(ab[None, None, :, 0], gb[:, :, None, 0])
+        xr = torch.min(ab[None, None, :, 2], gb[:, :, None, 2])
+        yl = torch.max(ab[None, None, :, 1], gb[:, :, None, 1])
+        yr = torch.min(ab[None, None, :, 3], gb[:, :, None, 3])
         inter = xr.sub_(xl).clamp_min_(0).mul_(yr.sub_(yl).clamp_min_(0))          # (in place: xr becomes the intersection)
         del xl, yl, yr
         area_a = (ab[:, 2] - ab[:, 0]) * (ab[:, 3] - ab[:, 1])
         area_b = (gb[:, :, 2] - gb[:, :, 0]) * (gb[:, :, 3] - gb[:, :, 1])
-        iou = inter / torch.clamp_min(area_a[None, :, None] + area_b[:, None, :] - inter, 1e-6)      # (B,A,G), box_utils.py:252-272
+        iou = inter / torch.clamp_min(area_a[None, None, :] + area_b[:, :, None] - inter, 1e-6)      # (B,G,A), box_utils.py:252-272
         del inter
-        iou.masked_fill_(~use[:, None, :], -2.0)                                   # masked ground truths never match
-        a2g_max, a2g_arg = iou.max(dim=2)
-        g2a_max = iou.max(dim=1)[0]
+        iou.masked_fill_(~use[:, :, None], -2.0)                                   # masked ground truths never match
+        a2g_max, a2g_arg = iou.max(dim=1)
+        g2a_max = iou.max(dim=2)[0]
         g2a_max = torch.where(g2a_max <= 0, torch.full_like(g2a_max, -1.0), g2a_max)   # no overlap at all: no forced match (:155-156)
-        force = (iou == g2a_max[:, None, :]).any(dim=2)                            # best anchor(s) of every ground truth (:158-161)
+        force = (iou == g2a_max[:, :, None]).any(dim=1)                            # best anchor(s) of every ground truth (:158-161)
         cls_of = torch.gather(gt_classes, 1, a2g_arg)
         labels = torch.full((B, A), -1, dtype=torch.int32, device=anchors.device)
         labels = torch.where(force, cls_of, labels)
