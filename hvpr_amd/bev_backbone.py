@@ -242,10 +242,14 @@ class BaseBEVBackbone_Scale(nn.Module):
                     xa = cbr(self.sfmblocks_down[i], xa, gate=g, resid=xa)
                     xpa = cbr(self.sfmblocks_down[i], xpa, gate=g, resid=xpa)
             de = self.deblocks[i]
-            ups.append(ct.bn_relu(ct.deconv(xa, de[0].weight), de[1]))
-            ups_p.append(ct.bn_relu(ct.deconv(xpa, de[0].weight), de[1]))
-        data_dict["spatial_features_2d"] = torch.cat(ups, dim=-1).permute(0, 3, 1, 2)          # (B, 384, H, W), channels_last
-        data_dict["spatial_features_point_2d"] = torch.cat(ups_p, dim=-1).permute(0, 3, 1, 2)
+            ups.append(ct.deconv(xa, de[0].weight))
+            ups_p.append(ct.deconv(xpa, de[0].weight))
+        # BatchNorm + ReLU of the three branches write straight into their slices of the concatenation (:262-279).  The two streams share
+        # the BatchNorm modules: statistics per stream, running statistics updated by the first stream's call and then the second's, as
+        # the reference's two passes do
+        bns = [de[1] for de in self.deblocks]
+        data_dict["spatial_features_2d"] = ct.bn_relu_cat(ups, bns).permute(0, 3, 1, 2)          # (B, 384, H, W), channels_last
+        data_dict["spatial_features_point_2d"] = ct.bn_relu_cat(ups_p, bns).permute(0, 3, 1, 2)
         return data_dict
 
     def forward(self, data_dict):

@@ -212,9 +212,10 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float *__restrict__ z, 
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                    const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
                                                    const float *__restrict__ gate /* [P] or null: dy is multiplied by it */,
-                                                   int slab, float *__restrict__ ws /* [blocks][2][C] */) {
+                                                   int slab, float *__restrict__ ws /* [blocks][2][C] */, int dy_cstride = 0 /* 0: C */) {
     __shared__ float4 s_a[256], s_b[256];
     const int groups = C / 4;                       // channel groups of 4
+    const int DC = dy_cstride > 0 ? dy_cstride : C; // row pitch of dy (a channel slice of a wider tensor: the caller offsets the pointer)
     const int lanes = 256 / groups > 0 ? 256 / groups : 1;     // pixel lanes per workgroup (groups <= 256)
     const int g = threadIdx.x % groups, pl = threadIdx.x / groups;
     const long long p0 = (long long)blockIdx.x * slab;
@@ -251,14 +252,14 @@ __global__ void __launch_bounds__(256) k_bn_reduce(const float *__restrict__ z, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = *(const float4 *)(z + (p + u * lanes) * C + 4 * g);
-                d[u] = BWD ? *(const float4 *)(dy + (p + u * lanes) * C + 4 * g) : zero4;
+                d[u] = BWD ? *(const float4 *)(dy + (p + u * lanes) * DC + 4 * g) : zero4;
                 gp[u] = (BWD && gate) ? gate[p + u * lanes] : 1.f;
             }
             one(v[0], d[0], gp[0], A, B); one(v[1], d[1], gp[1], A1, B1); one(v[2], d[2], gp[2], A2, B2); one(v[3], d[3], gp[3], A3, B3);
         }
         for (; p < p1; p += lanes) {
             const float4 v = *(const float4 *)(z + p * C + 4 * g);
-            const float4 d = BWD ? *(const float4 *)(dy + p * C + 4 * g) : zero4;
+            const float4 d = BWD ? *(const float4 *)(dy + p * DC + 4 * g) : zero4;
             one(v, d, (BWD && gate) ? gate[p] : 1.f, A, B);
         }
         A.x += (A1.x + A2.x) + A3.x; A.y += (A1.y + A2.y) + A3.y; A.z += (A1.z + A2.z) + A3.z; A.w += (A1.w + A2.w) + A3.w;
@@ -357,9 +358,10 @@ __global__ void __launch_bounds__(256) k_bn_affine(const float *__restrict__ mea
 
 // y = relu(z * scale + shift)   (scale = gamma * invstd, shift = beta - mean * scale);  with a gate: y = gate[p] * relu(..) + resid
 // (the SFM step x_att = attention(sfm(x_att), y) + x_att, base_bev_backbone.py:250-255)
+// (y_stride4 / y_off4: row pitch and channel offset of y in float4 — a channel slice of a wider tensor; y_stride4 == groups: y[i])
 __global__ void __launch_bounds__(256) k_bn_apply(const float4 *__restrict__ z, long long n4, int groups, const float *__restrict__ scale,
                                                   const float *__restrict__ shift, int relu, const float *__restrict__ gate,
-                                                  const float4 *__restrict__ resid, float4 *__restrict__ y) {
+                                                  const float4 *__restrict__ resid, float4 *__restrict__ y, int y_stride4, int y_off4) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(i % groups);
         const float4 sc = *(const float4 *)(scale + 4 * g), sh = *(const float4 *)(shift + 4 * g);
@@ -371,7 +373,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(const float4 *__restrict__ z, 
             const float4 q = resid[i];
             r = make_float4(fmaf(gp, r.x, q.x), fmaf(gp, r.y, q.y), fmaf(gp, r.z, q.z), fmaf(gp, r.w, q.w));
         }
-        y[i] = r;
+        y[y_stride4 == groups ? i : (i / groups) * y_stride4 + y_off4 + g] = r;
     }
 }
 
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4 *__restrict__
                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
                                                       const float *__restrict__ s1, const float *__restrict__ s2, float inv_n, int relu,
                                                       const float *__restrict__ gate, float *__restrict__ dgate /* zeroed, atomics */,
-                                                      float4 *__restrict__ dz) {
+                                                      float4 *__restrict__ dz, int dy_stride4 /* row pitch of dy in float4; == groups: dy[i] */) {
     // grid-stride loop with trip counts that are uniform per wave (the stride is a multiple of 64 and of `groups`): the lanes of
     // one pixel stay together, so the per-pixel sum for dgate is a butterfly inside the wave
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const float4 *__restrict__
         const float4 mu = *(const float4 *)(mean + 4 * g), is = *(const float4 *)(invstd + 4 * g);
         const float4 a1 = *(const float4 *)(s1 + 4 * g), a2 = *(const float4 *)(s2 + 4 * g);
         const float4 v = z[i];
-        float4 d = dy[i];
+        float4 d = dy[dy_stride4 == groups ? i : (i / groups) * dy_stride4 + g];
         if (gate) {          // y = gate * a + resid: d a = gate * dy, d gate = sum_c a * dy
             const float4 a = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
             ga = (relu ? fmaxf(a.x, 0.f) : a.x) * d.x + (relu ? fmaxf(a.y, 0.f) : a.y) * d.y + (relu ? fmaxf(a.z, 0.f) : a.z) * d.z +
@@ -514,7 +516,22 @@ extern "C" int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, con
     long long blocks = (n4 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)z, n4, C / 4, scale, shift, relu,
-                       gate, (const float4 *)resid, (float4 *)y);
+                       gate, (const float4 *)resid, (float4 *)y, C / 4, 0);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+// The same into / out of a channel slice of a wider NHWC tensor (the deconvolution branches write their 128 channels straight into the
+// 384-channel concatenation the head reads, and take their gradient out of its gradient: no torch.cat, no slice copies).
+extern "C" int hvpr_bn_relu_fwd_slice_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, float *y,
+                                               int y_cstride, int y_coff, hvpr_stream_t stream) {
+    if (!z || !scale || !shift || !y || P < 1) return HVPR_ERR_INVALID_ARG;
+    if (C < 4 || C % 4 != 0 || y_cstride % 4 != 0 || y_coff % 4 != 0 || y_coff < 0 || y_coff + C > y_cstride) return HVPR_ERR_UNSUPPORTED;
+    const long long n4 = P * (C / 4);
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)z, n4, C / 4, scale, shift, relu,
+                       (const float *)nullptr, (const float4 *)nullptr, (float4 *)y, y_cstride / 4, y_coff / 4);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }
@@ -549,7 +566,30 @@ extern "C" int hvpr_bn_relu_bwd_apply_nhwc_f32(const float *dy, const float *z, 
     long long g = (n4 + 255) / 256;
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, s, (const float4 *)dy, (const float4 *)z, n4, C / 4, scale, shift, mean,
-                       invstd, dbeta_total, dgamma_total, (float)inv_count, relu, gate, dgate, (float4 *)dz);
+                       invstd, dbeta_total, dgamma_total, (float)inv_count, relu, gate, dgate, (float4 *)dz, C / 4);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
+
+extern "C" int hvpr_bn_relu_bwd_slice_nhwc_f32(const float *dy, int dy_cstride, int dy_coff, const float *z, long long P, int C,
+                                               const float *scale, const float *shift, const float *mean, const float *invstd, int relu,
+                                               float *dz, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                               hvpr_stream_t stream) {
+    if (!dy || !z || !scale || !shift || !mean || !invstd || !dz || !dgamma || !dbeta || !workspace || P < 1) return HVPR_ERR_INVALID_ARG;
+    if (C < 4 || C % 4 != 0 || C > 1024 || dy_cstride % 4 != 0 || dy_coff % 4 != 0 || dy_coff < 0 || dy_coff + C > dy_cstride) return HVPR_ERR_UNSUPPORTED;
+    if (workspace_bytes < hvpr_bn_workspace_bytes(P, C)) return HVPR_ERR_WORKSPACE;
+    const int blocks = bn_blocks(P);
+    hipStream_t s = (hipStream_t)stream;
+    const float *dys = dy + dy_coff;
+    hipLaunchKernelGGL(k_bn_reduce<true>, dim3(blocks), dim3(256), 0, s, z, dys, P, C, scale, shift, mean, invstd, relu, (const float *)nullptr,
+                       bn_slab(P), (float *)workspace, dy_cstride);
+    launch_bn_finalize((const float *)workspace, blocks, C, (double)P, 0.f, 1, dbeta, dgamma, (float *)nullptr, s);
+    const long long n4 = P * (C / 4);
+    long long g = (n4 + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)g), dim3(256), 0, s, (const float4 *)dys, (const float4 *)z, n4, C / 4, scale, shift, mean,
+                       invstd, dbeta, dgamma, (float)(1.0 / (double)P), relu, (const float *)nullptr, (float *)nullptr, (float4 *)dz,
+                       dy_cstride / 4);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
 }

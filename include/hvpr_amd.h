@@ -432,6 +432,13 @@ int hvpr_bn_train_affine_f32(const float *mean, const float *var, const float *i
                              long long *num_batches_tracked, float *scale, float *shift, hvpr_stream_t stream);
 int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, const float *gate,
                               const float *resid, float *y, hvpr_stream_t stream);
+/* ... into / out of a channel slice [coff, coff + C) of a wider NHWC tensor with cstride channels per pixel (no gate): the backbone's
+ * deconvolution branches write straight into the 384-channel concatenation and take their gradient out of its gradient. */
+int hvpr_bn_relu_fwd_slice_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, float *y,
+                                    int y_cstride, int y_coff, hvpr_stream_t stream);
+int hvpr_bn_relu_bwd_slice_nhwc_f32(const float *dy, int dy_cstride, int dy_coff, const float *z, long long P, int C, const float *scale,
+                                    const float *shift, const float *mean, const float *invstd, int relu, float *dz, float *dgamma,
+                                    float *dbeta, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
 int hvpr_bn_relu_bwd_nhwc_f32(const float *dy, const float *z, long long P, int C, const float *scale, const float *shift,
                               const float *mean, const float *invstd, int relu, const float *gate, float *dgate, float *dz, float *dgamma,
                               float *dbeta, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);

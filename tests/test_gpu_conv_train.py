@@ -179,6 +179,37 @@ def test_backbone_training_forward_backward_hip_equals_torch_autograd():
         _close(h[4][k].float(), r[4][k].float(), rtol=1e-4, what="buffer " + k)
 
 
+@pytest.mark.parametrize("N,H,W,Cs", [(2, 31, 45, (128, 128, 128)), (1, 9, 7, (32, 64, 16)), (3, 5, 6, (256,))])
+def test_bn_relu_cat_equals_the_concatenation_of_bn_relu(N, H, W, Cs):
+    """bn_relu_cat (every branch normalised into / differentiated out of its channel slice) against torch.cat of the plain bn_relu
+    calls: output, running statistics and all gradients bit for bit — the same kernels on the same values, only the addresses differ."""
+    g = torch.Generator().manual_seed(H * 3 + len(Cs))
+    zs = [(torch.randn(N, H, W, C, generator=g) * 1.5 + 0.2).to(DEV) for C in Cs]
+    def make():
+        bns = [torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(DEV).train() for C in Cs]
+        gg = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for bn in bns:
+                bn.weight.copy_(torch.rand(bn.weight.shape, generator=gg) + 0.5); bn.bias.copy_(torch.randn(bn.bias.shape, generator=gg) * 0.1)
+        return bns
+    bns_a, bns_b = make(), make()
+    za = [z.clone().requires_grad_(True) for z in zs]
+    zb = [z.clone().requires_grad_(True) for z in zs]
+    ya = ct.bn_relu_cat(za, bns_a)
+    yb = torch.cat([ct.bn_relu(z, bn) for z, bn in zip(zb, bns_b)], dim=-1)
+    assert torch.equal(ya, yb)
+    dy = torch.randn(ya.shape, generator=g).to(DEV)
+    pa = [p for bn in bns_a for p in (bn.weight, bn.bias)]
+    pb = [p for bn in bns_b for p in (bn.weight, bn.bias)]
+    ga = torch.autograd.grad(ya, za + pa, dy)
+    gb = torch.autograd.grad(yb, zb + pb, dy)
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
+    for a, b in zip(bns_a, bns_b):
+        assert torch.equal(a.running_mean, b.running_mean) and torch.equal(a.running_var, b.running_var)
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 48, 128), (1, 31, 45, 256), (2, 9, 7, 512), (3, 5, 6, 32)])
 def test_bn_relu_with_fused_sfm_gate_matches_torch(shape):
     """gate * relu(BN_train(z)) + resid in one forward / one backward kernel pair (the SFM step, base_bev_backbone.py:250-255):

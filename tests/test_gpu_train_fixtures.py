@@ -56,8 +56,8 @@ def _op_names(cfg):
         names += [f"L{i}.x.block{k}" for k in range(n + 1)] + [f"L{i}.xp.block{k}" for k in range(n + 1)] + [f"L{i}.y"]
         for j in range(ns):
             names += [f"L{i}.x.sfm{j}", f"L{i}.xp.sfm{j}"]
-        names += [f"L{i}.x.up", f"L{i}.xp.up"]
-    return names
+    # the deconvolution branches' BatchNorm + ReLU: one bn_relu_cat call per stream at the end, every branch a channel slice of its output
+    return names + [f"L{i}.x.up" for i in range(len(cfg.LAYER_NUMS))] + [f"L{i}.xp.up" for i in range(len(cfg.LAYER_NUMS))]
 
 
 @pytest.mark.parametrize("tag", ["small", "full"])
@@ -97,9 +97,19 @@ def test_g4_train_two_stream_backbone_on_gpu(golden_dir, tag, monkeypatch):
             acts.append((next(names), y, k.get("resid") if "resid" in k else (a[0] if fn is orig_sfm else None)))
             return y
         return inner
+    def tap_cat(fn):
+        def inner(zs, bns):
+            y = fn(zs, bns)
+            off = 0
+            for zj in zs:
+                acts.append((next(names), y[..., off:off + zj.shape[-1]], None))
+                off += zj.shape[-1]
+            return y
+        return inner
     orig_sfm = ct.sfm_step
     monkeypatch.setattr(ct, "bn_relu", tap(ct.bn_relu))
     monkeypatch.setattr(ct, "sfm_step", tap(ct.sfm_step))
+    monkeypatch.setattr(ct, "bn_relu_cat", tap_cat(ct.bn_relu_cat))
     in_keys = ("spatial_features", "spatial_features_point", "spatial_scale_features")
     ins = [torch.from_numpy(z[k]).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) for k in in_keys]
     d = m({"spatial_features": ins[0], "spatial_features_point": ins[1], "spatial_scale_features": ins[2]})
