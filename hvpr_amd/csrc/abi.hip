@@ -5,7 +5,7 @@
 // channel maxima; 4: the packed bank ends in 128 floats (64 channel maxima, their sum and maximum: hvpr_memory_bank_packed_floats grew
 // by 64) and the voxelizer workspace holds the one-launch index kernel's per-cell words and barrier flags (hvpr_voxelize_workspace_bytes
 // grew) — a caller that sized either buffer with a version-3 formula is too small: always size them with the two functions; 5: adds
-// hvpr_bn_train_affine_f32; hvpr_conv2d_wino_wgrad_nhwc_f32 answers HVPR_ERR_UNSUPPORTED for images of 2 GB and more (32-bit offsets
+// hvpr_bn_train_affine_f32 and hvpr_bn_relu_fwd / bwd_slice_nhwc_f32; hvpr_conv2d_wino_wgrad_nhwc_f32 answers HVPR_ERR_UNSUPPORTED for images of 2 GB and more (32-bit offsets
 // inside an image; its workspace size is unchanged)
 extern "C" int hvpr_abi_version(void) { return 5; }
 
