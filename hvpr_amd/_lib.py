@@ -93,6 +93,7 @@ SIGNATURES = {
     "hvpr_conv2d_wino_pack_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "hvpr_conv2d_wino_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
     "hvpr_conv2d_wino_stats_rows": (_I, [_I, _I, _I]),
+    "hvpr_conv2d_s2_dgrad_nhwc_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "hvpr_bn_relu_fwd_slice_nhwc_f32": (_I, [_P, _c.c_longlong, _I, _P, _P, _I, _P, _I, _I, _P]),
     "hvpr_bn_relu_bwd_slice_nhwc_f32": (_I, [_P, _I, _I, _P, _c.c_longlong, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "hvpr_bn_train_affine_f32": (_I, [_P, _P, _P, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),

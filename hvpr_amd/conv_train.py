@@ -297,7 +297,11 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if s == 1:
                 dx = conv_fwd_raw(dz, weight, 1, adjoint=True)
-            else:            # y[o] = sum x[2 o + k - 1] w[k]  =>  dx = conv_stride1(zero-upsampled dz, flipped w)
+            elif k == 3 and cout % 8 == 0 and cin % 4 == 0:
+                # y[o] = sum x[2 o + k - 1] w[k]  =>  dx[2a + py, 2b + px] = sum over the taps of that parity class of w[k]^T dz[...]:
+                # the gather form on the direct kernel (a stride-1 convolution over the zero-upsampled dz multiplied four zeros in five)
+                dx = kernels.conv2d_s2_dgrad_nhwc(dz, weight, x.shape[1], x.shape[2])
+            else:            # ... = conv_stride1(zero-upsampled dz, flipped w)
                 N, H, W, _ = x.shape
                 OH, OW = dz.shape[1], dz.shape[2]
                 up = torch.zeros((N, H, W, cout), dtype=torch.float32, device=dz.device)

@@ -68,8 +68,18 @@ struct ConvArgs {
 __device__ long long g_conv_dbg[8 * 4 * 64 * 4];
 #endif
 
-template <int TH, int TW, int BN, int S, int TAPS>
+// UP2 (TAPS == 9, S == 1): the DATA GRADIENT of a stride-2 3x3 (pad 1) convolution as a gather over its output gradient, without the
+// zero-upsampled tensor.  in = dz [N, H, W, Cin] at half resolution, out = dx [N, OH, OW, cout] at full resolution (OH, OW given by the
+// caller: H = (OH + 2 - 3) / 2 + 1), weights = the layer's filter with (cout, cin) swapped, tap t = ky * 3 + kx NOT flipped:
+//     dx[2a + py, 2b + px] = sum over the taps with ky = 1 (py == 0) | ky in {0, 2} (py == 1), kx likewise, of
+//                            W[ky][kx]^T dz[a + (ky == 0), b + (kx == 0)]
+// — 1 / 2 / 2 / 4 taps for the four parity classes instead of the 9 a stride-1 convolution over a zero-upsampled dz multiplies
+// (conv_train.py ran that one on the Winograd kernel: 4.7 ms per layer at batch 16 for 173 GFLOP of useful work).  A 16 x 16 output
+// tile = 8 x 8 positions (a, b) x 4 classes; MFMA block mb of a wave IS class (mb >> 1, mb & 1) for the wave's 4 x 8 positions, so which
+// taps a block multiplies is known at compile time and every wave does the same 9 (tap, class) products per chunk.
+template <int TH, int TW, int BN, int S, int TAPS, bool UP2 = false>
 __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
+    static_assert(!UP2 || (TAPS == 9 && S == 1 && TH == 16 && TW == 16), "UP2: 16 x 16 output tiles of a 3x3 stride-2 layer's data gradient");
     constexpr int BM = TH * TW;
     constexpr int WM = BM / 2, WN = BN / 2;        // per-wave tile
     constexpr int MB = WM / 32, NB = WN / 32;
@@ -79,7 +89,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     constexpr int HALO = TAPS == 9 ? 2 : 0;
     constexpr int NSUB = TAPS == 4 ? 4 : 1;        // 8-channel sub-chunks per stage
     constexpr int KSTAGE = KC * NSUB;              // input channels per stage
-    constexpr int PH = (TH - 1) * S + 1 + HALO, PW = (TW - 1) * S + 1 + HALO;
+    constexpr int PH = UP2 ? TH / 2 + 1 : (TH - 1) * S + 1 + HALO, PW = UP2 ? TW / 2 + 1 : (TW - 1) * S + 1 + HALO;
     // LDS images (float4 units), both split into two channel-half planes so that a half-wave (32 lanes, same half)
     // reads 32 consecutive float4 = conflict-free ds_read_b128:
     //   patch   [half][PPAD]       pixel-major inside a plane
@@ -132,6 +142,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
         const int q = mb * 32 + l31;
         const int py = wm * (TH / 2) + q / TW, px = q % TW;
         a_off[mb] = half * PPAD + (py * S) * PW + px * S;
+        if (UP2) a_off[mb] = half * PPAD + (wm * 4 + (l31 >> 3)) * PW + (l31 & 7);      // position (a, b) of the tile; the class is mb
     }
     int b_off[NB];
 #pragma unroll
@@ -159,7 +170,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     const int ty = pt % a.tiles_y;
     const int n = pt / a.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - (HALO / 2), ix0 = ox0 * S - (HALO / 2);
+    const int iy0 = UP2 ? oy0 / 2 : oy0 * S - (HALO / 2), ix0 = UP2 ? ox0 / 2 : ox0 * S - (HALO / 2);
     const int co0 = ct * BN;
 
     unsigned poff[NLD_P];    // byte offset of this lane's 16 B inside image n (without the chunk term)
@@ -234,10 +245,19 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
         // MFMA chain cannot hide a ds_read issued right before its wait)
         constexpr int PF = TAPS >= 3 ? 2 : 0;
         float4 av[PF + 1][MB], bv[PF + 1][NB];
+        // UP2: class (mb >> 1, mb & 1) multiplies tap (ky, kx) iff ky is 1 for an even row / 0 or 2 for an odd one (kx likewise), with
+        // the gradient pixel one row down / one column right for ky == 0 / kx == 0
+        auto up2_uses = [](int mb, int tap) { return (((mb >> 1) == 0) == (tap / 3 == 1)) && (((mb & 1) == 0) == (tap % 3 == 1)); };
         auto lds_load = [&](int tap, int slot) {
             const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[slot][mb] = sp[a_off[mb] + (TAPS == 4 ? tap * 2 * PPAD : ky * PW + kx)];
+            for (int mb = 0; mb < MB; ++mb) {
+                if (UP2) {
+                    if (up2_uses(mb, tap)) av[slot][mb] = sp[a_off[mb] + (ky == 0 ? PW : 0) + (kx == 0 ? 1 : 0)];
+                    continue;
+                }
+                av[slot][mb] = sp[a_off[mb] + (TAPS == 4 ? tap * 2 * PPAD : ky * PW + kx)];
+            }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) bv[slot][nb] = sw[b_off[nb] + tap * BN * 2];
         };
@@ -252,6 +272,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
+                    if (UP2 && !up2_uses(mb, tap)) continue;
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][nb].x, av[cur][mb].x, acc[mb][nb], 0, 0, 0);
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][nb].y, av[cur][mb].y, acc[mb][nb], 0, 0, 0);
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][nb].z, av[cur][mb].z, acc[mb][nb], 0, 0, 0);
@@ -286,7 +307,8 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int q = mb * 32 + l31;
-        const int oy = oy0 + wm * (TH / 2) + q / TW, ox = ox0 + q % TW;
+        const int oy = UP2 ? oy0 + 2 * (wm * 4 + (l31 >> 3)) + (mb >> 1) : oy0 + wm * (TH / 2) + q / TW;
+        const int ox = UP2 ? ox0 + 2 * (l31 & 7) + (mb & 1) : ox0 + q % TW;
         if (oy >= a.OH || ox >= a.OW) continue;
         const size_t pix = ((size_t)n * a.OH + oy) * a.OW + ox;
         const float gate = a.gate ? a.gate[pix] : 0.f;
@@ -319,7 +341,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     }
 }
 
-template <int TH, int TW, int BN, int S, int TAPS>
+template <int TH, int TW, int BN, int S, int TAPS, bool UP2 = false>
 int launch(ConvArgs a, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
@@ -330,13 +352,13 @@ int launch(ConvArgs a, hipStream_t s) {
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv<TH, TW, BN, S, TAPS>, 256, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv<TH, TW, BN, S, TAPS, UP2>, 256, 0) != hipSuccess || per_cu < 1)
             per_cu = 1;
         resident = per_cu * cus;
     }
     long long blocks = tiles < resident ? (tiles + 7) / 8 * 8 : resident;   // a multiple of 8: workgroup id % 8 = its XCD
     if (blocks > resident && resident >= 8) blocks = resident / 8 * 8;
-    hipLaunchKernelGGL((k_conv<TH, TW, BN, S, TAPS>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_conv<TH, TW, BN, S, TAPS, UP2>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return 0;
 }
 
@@ -347,6 +369,27 @@ extern "C" int hvpr_exp_conv_dbg(long long *host_out, int n_words) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_dbg), sizeof(long long) * n_words) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// Data gradient of a 3x3 stride-2 (pad 1) convolution: dz [N, H, W, Cin] (the layer's OUTPUT gradient; Cin = the layer's output channels) ->
+// dx [N, OH, OW, cout] (its input's gradient, H == (OH + 2 - 3) / 2 + 1 likewise W), w_packed = hvpr_conv_pack_weights_f32 of the layer's
+// filter with the two channel axes swapped ((cout = layer Cin, Cin = layer Cout, 3, 3), taps not flipped), bias [cout_pad] (zeros).
+extern "C" int hvpr_conv2d_s2_dgrad_nhwc_f32(const float *dz, int N, int H, int W, int Cin, const float *w_packed, const float *bias, int cout,
+                                             int cout_pad, int OH, int OW, float *dx, int out_cstride, int out_coff, hvpr_stream_t stream) {
+    if (!dz || !w_packed || !bias || !dx || N < 1 || H < 1 || W < 1 || Cin < 8 || cout < 1 || OH < 1 || OW < 1) return HVPR_ERR_INVALID_ARG;
+    if (H != (OH + 2 - 3) / 2 + 1 || W != (OW + 2 - 3) / 2 + 1) return HVPR_ERR_INVALID_ARG;
+    if (Cin % KC != 0 || cout % 4 != 0 || out_cstride % 4 != 0 || out_coff % 4 != 0 || cout_pad % 64 != 0 || cout_pad < cout) return HVPR_ERR_UNSUPPORTED;
+    if ((long long)H * W * Cin * 4 >= (1ll << 31)) return HVPR_ERR_UNSUPPORTED;
+    ConvArgs a;
+    a.in = dz; a.wpk = w_packed; a.bias = bias; a.out = dx; a.gate = nullptr; a.resid = nullptr;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin;
+    a.OH = OH; a.OW = OW;
+    a.cout_gemm = cout; a.cout_pad = cout_pad; a.cout_real = cout;
+    a.out_cstride = out_cstride; a.out_coff = out_coff; a.resid_cstride = 0;
+    a.relu = 0; a.up = 1;
+    launch<16, 16, 64, 1, 9, true>(a, (hipStream_t)stream);
+    HVPR_CHECK_LAUNCH();
+    return HVPR_OK;
+}
 
 extern "C" int hvpr_conv2d_nhwc_f32(const float *in, int N, int H, int W, int Cin, const float *w_packed,
                                     const float *bias, int taps, int stride, int cout, int cout_pad, int up,

@@ -434,6 +434,13 @@ int hvpr_bn_relu_fwd_nhwc_f32(const float *z, long long P, int C, const float *s
                               const float *resid, float *y, hvpr_stream_t stream);
 /* ... into / out of a channel slice [coff, coff + C) of a wider NHWC tensor with cstride channels per pixel (no gate): the backbone's
  * deconvolution branches write straight into the 384-channel concatenation and take their gradient out of its gradient. */
+/* Data gradient of a 3x3 stride-2 (pad 1) convolution, gathered per output-pixel parity class (1 / 2 / 2 / 4 taps) instead of a
+ * stride-1 convolution over a zero-upsampled gradient: dz [N, H, W, Cin] (the layer's output gradient; Cin = its output channels) ->
+ * dx [N, OH, OW, out_cstride] channels [out_coff, out_coff + cout) (its input's gradient; H == (OH + 2 - 3) / 2 + 1, W likewise).
+ * w_packed = hvpr_conv2d_nhwc_f32's weight image of the layer's filter with the channel axes swapped ((cout, Cin, 3, 3), taps NOT
+ * flipped), bias [cout_pad] (zeros for a plain gradient), cout_pad a multiple of 64. */
+int hvpr_conv2d_s2_dgrad_nhwc_f32(const float *dz, int N, int H, int W, int Cin, const float *w_packed, const float *bias, int cout,
+                                  int cout_pad, int OH, int OW, float *dx, int out_cstride, int out_coff, hvpr_stream_t stream);
 int hvpr_bn_relu_fwd_slice_nhwc_f32(const float *z, long long P, int C, const float *scale, const float *shift, int relu, float *y,
                                     int y_cstride, int y_coff, hvpr_stream_t stream);
 int hvpr_bn_relu_bwd_slice_nhwc_f32(const float *dy, int dy_cstride, int dy_coff, const float *z, long long P, int C, const float *scale,
