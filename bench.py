@@ -264,8 +264,8 @@ def extra_group_lines(device):
 def train_conv_flops(model, H, W):
     """Direct-convolution FLOPs (2 * MACs) of ONE frame's training step through the backbone and head — forward, data gradient and
     weight gradient of BOTH streams (the scale stream once) — and the part of them that is EXECUTED: the stride-1 3x3 layers run
-    forward, data gradient and weight gradient in the Winograd F(2x2,3x3) domain (16 of 36 multiplies); the stride-2 data gradient
-    runs Winograd on the zero-upsampled gradient (4 x 16/36 of its direct count)."""
+    forward, data gradient and weight gradient in the Winograd F(2x2,3x3) domain (16 of 36 multiplies); the stride-2 layers run all three
+    directly (the data gradient as a gather per output-pixel parity class: its direct count)."""
     bb = model.backbone_2d
     direct = executed = 0.0
     h, w = H, W
@@ -281,7 +281,7 @@ def train_conv_flops(model, H, W):
             if stride == 1:
                 executed += 3 * f * 16.0 / 36.0
             else:
-                executed += f + f + 4 * f * 16.0 / 36.0 * stride * stride / 4    # fwd, wgrad direct; dgrad on the upsampled gradient
+                executed += 3 * f                                 # fwd, dgrad (hvpr_conv2d_s2_dgrad_nhwc_f32), wgrad: direct
         convs = [m for m in blk if isinstance(m, torch.nn.Conv2d)]
         for c in convs:
             add(c.in_channels, c.out_channels, c.stride[0], 2)
