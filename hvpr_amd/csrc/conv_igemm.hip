@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
     constexpr int PATCH_PAD = NLD_P * 256, W_PAD = NLD_W * 256;
     __shared__ __attribute__((aligned(16))) float4 s_patch[2][PATCH_PAD];
     __shared__ __attribute__((aligned(16))) float4 s_w[2][W_PAD];
+    __shared__ __attribute__((aligned(16))) float4 s_bias[BN / 4];     // this tile's bias row: the epilogue reads it from LDS (conv_wino.hip)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned wave_s = __builtin_amdgcn_readfirstlane((unsigned)(threadIdx.x >> 6));
@@ -212,7 +213,8 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
             for (int i = 0; i < NLD_P; ++i) s_patch[b][tid + i * 256] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
-    f32x16 acc[MB][NB];
+    if (tid < BN / 4) s_bias[tid] = *(const float4 *)(a.bias + co0 + tid * 4);   // (visible by the chunk barriers; the previous tile's
+    f32x16 acc[MB][NB];                                                           //  readers are behind its closing barrier)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(256) k_conv(ConvArgs a) {
             for (int g = 0; g < 4; ++g) {
                 const int col = co0 + wn * WN + nb * 32 + 8 * g + 4 * half;
                 if (col >= a.cout_gemm) continue;
-                const float4 bias = *(const float4 *)(a.bias + col);
+                const float4 bias = s_bias[(col - co0) >> 2];
                 float4 y = make_float4(acc[mb][nb][4 * g] + bias.x, acc[mb][nb][4 * g + 1] + bias.y,
                                        acc[mb][nb][4 * g + 2] + bias.z, acc[mb][nb][4 * g + 3] + bias.w);
                 if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
