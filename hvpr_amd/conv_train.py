@@ -230,6 +230,34 @@ def _bn_backward(dy, z, P, C, scale, shift, mean, invstd, relu, gate, dgate, cou
     return dz, dgamma, dbeta          # parameter gradients: this rank's sums (DistributedDataParallel averages them)
 
 
+_wino_pack_cache = {}
+_weights_epoch = [0]
+
+
+def weights_changed():
+    """Parameters were written behind torch's back (the flat fused optimiser's kernel): cached packed filters are stale."""
+    _weights_epoch[0] += 1
+    _wino_pack_cache.clear()
+
+
+def _pack_wino(weight, adjoint):
+    """kernels.pack_conv_wino(weight, relu=False, adjoint=adjoint), kept for as long as the parameter is not written: the weight-shared
+    SFM layer is convolved six times forward and six times backward per step (three steps x two streams), every other layer twice —
+    78 pack launches per step before.  An entry belongs to ONE tensor object (weak reference: an address can be handed to another
+    tensor) at one version (torch's in-place updates bump it; the flat fused optimiser, which writes through a raw pointer, calls
+    weights_changed())."""
+    import weakref
+    key = (id(weight), bool(adjoint))
+    hit = _wino_pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+        return hit[2]
+    pc = kernels.pack_conv_wino(weight.detach(), relu=False, px_groups=_wino_groups(), adjoint=adjoint)
+    if len(_wino_pack_cache) > 512:
+        _wino_pack_cache.clear()
+    _wino_pack_cache[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), pc)
+    return pc
+
+
 def conv_fwd_raw(x, weight, stride=1, adjoint=False, stats=False):
     """x (N,H,W,Cin) -> conv(x, weight) (N,OH,OW,Cout), no bias / activation.  weight (Cout,Cin,k,k), k in {1,3}, pad (k-1)/2.
     stats: return (z, partials) — partials = the batch statistics' per-tile sums when the Winograd kernel produced them, else None.
@@ -243,7 +271,7 @@ def conv_fwd_raw(x, weight, stride=1, adjoint=False, stats=False):
             N, H, W, _ = x.shape
             cout = weight.shape[1 if adjoint else 0]
             partials = torch.empty((lib().hvpr_conv2d_wino_stats_rows(N, H, W), 2, cout), dtype=torch.float32, device=x.device)
-        z = kernels.conv2d_wino_nhwc(x, kernels.pack_conv_wino(weight, relu=False, px_groups=g, adjoint=adjoint), bn_partials=partials)
+        z = kernels.conv2d_wino_nhwc(x, _pack_wino(weight, adjoint), bn_partials=partials)
         return (z, partials) if stats else z
     if adjoint:
         weight = weight.detach().permute(1, 0, 2, 3).flip(2, 3)                 # (Cin, Cout, k, k): the adjoint kernel
@@ -425,7 +453,7 @@ class _SfmStep(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if kernels.conv_algo() == "winograd" and cin % 4 == 0 and cout % 8 == 0:
-                pc = kernels.pack_conv_wino(weight, relu=False, px_groups=_wino_groups(), adjoint=True)
+                pc = _pack_wino(weight, True)
                 dx = kernels.conv2d_wino_nhwc(dz, pc, gate=_ones(tuple(dz.shape[:3]), dz.device), resid=dy)    # + the residual path
             else:
                 dx = conv_fwd_raw(dz, weight, 1, adjoint=True) + dy

@@ -212,6 +212,10 @@ class FusedAdamOneCycle:
                                                self.exp_avg_sq.data_ptr(), self.numel, self._lr, self._mom, self.beta2, self.eps,
                                                self.wd, self.steps, None if self._scale is None else self._scale.data_ptr(),
                                                self._kernels._stream()), "hvpr_fused_adam_truewd_f32")
+        # the kernel writes the parameters through a raw pointer: torch's version counters do not see it, so whatever is derived from
+        # the weights and cached by version (conv_train's packed Winograd filters) is told here
+        from . import conv_train
+        conv_train.weights_changed()
 
     def state_dict(self):
         state = {}

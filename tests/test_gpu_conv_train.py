@@ -179,6 +179,38 @@ def test_backbone_training_forward_backward_hip_equals_torch_autograd():
         _close(h[4][k].float(), r[4][k].float(), rtol=1e-4, what="buffer " + k)
 
 
+def test_packed_filter_cache_follows_the_weights():
+    """conv_train keeps the packed Winograd filters of a parameter between calls: an in-place update (version counter), a write behind
+    torch's back announced by weights_changed() (the flat fused optimiser), a re-pointed .data and a NEW tensor must all be seen."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 9, 11, 64, generator=g).to(DEV)
+    w = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV))
+
+    def ref(wt):
+        return F.conv2d(x.permute(0, 3, 1, 2).double(), wt.detach().double(), padding=1).permute(0, 2, 3, 1)
+    _close(ct.conv(x, w, 1), ref(w), rtol=2e-5, what="first call")
+    _close(ct.conv(x, w, 1), ref(w), rtol=2e-5, what="cached call")
+    with torch.no_grad():
+        w.mul_(-0.5)                                            # version counter
+    _close(ct.conv(x, w, 1), ref(w), rtol=2e-5, what="after an in-place update")
+    w2 = w.detach().clone() * 3.0
+    torch.cuda.synchronize()
+    import ctypes
+    ver = w._version
+    hip = ctypes.CDLL("libamdhip64.so")                          # a write the version counter does not see (the fused optimiser's kind)
+    assert hip.hipMemcpy(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(w2.data_ptr()), ctypes.c_size_t(w.numel() * 4), 3) == 0
+    torch.cuda.synchronize()
+    assert w._version == ver and torch.equal(w.detach(), w2)
+    ct.weights_changed()
+    _close(ct.conv(x, w, 1), ref(w), rtol=2e-5, what="after a raw write + weights_changed()")
+    w.data = (w.detach() * 0.25 + 0.01).clone()                 # same object, new storage
+    _close(ct.conv(x, w, 1), ref(w), rtol=2e-5, what="after re-pointing .data")
+    for _ in range(3):                                          # new tensors, possibly at a recycled address
+        wn = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV))
+        _close(ct.conv(x, wn, 1), ref(wn), rtol=2e-5, what="a new parameter")
+        del wn
+
+
 @pytest.mark.parametrize("N,H,W,Cs", [(2, 31, 45, (128, 128, 128)), (1, 9, 7, (32, 64, 16)), (3, 5, 6, (256,))])
 def test_bn_relu_cat_equals_the_concatenation_of_bn_relu(N, H, W, Cs):
     """bn_relu_cat (every branch normalised into / differentiated out of its channel slice) against torch.cat of the plain bn_relu
