@@ -240,22 +240,28 @@ def weights_changed():
     _wino_pack_cache.clear()
 
 
-def _pack_wino(weight, adjoint):
-    """kernels.pack_conv_wino(weight, relu=False, adjoint=adjoint), kept for as long as the parameter is not written: the weight-shared
-    SFM layer is convolved six times forward and six times backward per step (three steps x two streams), every other layer twice —
-    78 pack launches per step before.  An entry belongs to ONE tensor object (weak reference: an address can be handed to another
-    tensor) at one version (torch's in-place updates bump it; the flat fused optimiser, which writes through a raw pointer, calls
-    weights_changed())."""
+def _packed(weight, kind, build):
+    """build() — a packed image derived from `weight` alone — kept for as long as the parameter is not written.  Every convolution of
+    the training step packed its filter first: 78 `k_wino_pack` launches per step (the weight-shared SFM layer six times forward and
+    six times for the data gradient) and four torch launches per direct-kernel call.  An entry belongs to ONE tensor object (weak
+    reference: an address can be handed to another tensor), one version and one data pointer (torch's in-place updates bump the
+    version; the flat fused optimiser, which writes through a raw pointer, calls weights_changed())."""
     import weakref
-    key = (id(weight), bool(adjoint))
+    key = (id(weight), kind)
+    state = (weight._version, weight.data_ptr())
     hit = _wino_pack_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+    if hit is not None and hit[0]() is weight and hit[1] == state:
         return hit[2]
-    pc = kernels.pack_conv_wino(weight.detach(), relu=False, px_groups=_wino_groups(), adjoint=adjoint)
-    if len(_wino_pack_cache) > 512:
+    pc = build()
+    if len(_wino_pack_cache) > 1024:
         _wino_pack_cache.clear()
-    _wino_pack_cache[key] = (weakref.ref(weight), (weight._version, weight.data_ptr()), pc)
+    _wino_pack_cache[key] = (weakref.ref(weight), state, pc)
     return pc
+
+
+def _pack_wino(weight, adjoint):
+    return _packed(weight, ("wino", bool(adjoint)),
+                   lambda: kernels.pack_conv_wino(weight.detach(), relu=False, px_groups=_wino_groups(), adjoint=adjoint))
 
 
 def conv_fwd_raw(x, weight, stride=1, adjoint=False, stats=False):
@@ -273,9 +279,10 @@ def conv_fwd_raw(x, weight, stride=1, adjoint=False, stats=False):
             partials = torch.empty((lib().hvpr_conv2d_wino_stats_rows(N, H, W), 2, cout), dtype=torch.float32, device=x.device)
         z = kernels.conv2d_wino_nhwc(x, _pack_wino(weight, adjoint), bn_partials=partials)
         return (z, partials) if stats else z
-    if adjoint:
-        weight = weight.detach().permute(1, 0, 2, 3).flip(2, 3)                 # (Cin, Cout, k, k): the adjoint kernel
-    pc = kernels.pack_conv(weight, None, None, stride=stride, relu=False, tile_cfg=_tile_cfg(weight.shape[0]))
+    def build():
+        w = weight.detach().permute(1, 0, 2, 3).flip(2, 3) if adjoint else weight       # (Cin, Cout, k, k): the adjoint kernel
+        return kernels.pack_conv(w, None, None, stride=stride, relu=False, tile_cfg=_tile_cfg(w.shape[0]))
+    pc = _packed(weight, ("direct", int(stride), bool(adjoint)), build)
     z = kernels.conv2d_nhwc(x, pc)
     return (z, None) if stats else z
 
@@ -328,7 +335,7 @@ class _Conv(torch.autograd.Function):
             elif k == 3 and cout % 8 == 0 and cin % 4 == 0:
                 # y[o] = sum x[2 o + k - 1] w[k]  =>  dx[2a + py, 2b + px] = sum over the taps of that parity class of w[k]^T dz[...]:
                 # the gather form on the direct kernel (a stride-1 convolution over the zero-upsampled dz multiplied four zeros in five)
-                dx = kernels.conv2d_s2_dgrad_nhwc(dz, weight, x.shape[1], x.shape[2])
+                dx = kernels.conv2d_s2_dgrad_nhwc(dz, weight, x.shape[1], x.shape[2], pc=_packed(weight, "s2dgrad", lambda: kernels.pack_conv_s2_dgrad(weight)))
             else:            # ... = conv_stride1(zero-upsampled dz, flipped w)
                 N, H, W, _ = x.shape
                 OH, OW = dz.shape[1], dz.shape[2]
@@ -347,8 +354,10 @@ class _Deconv(torch.autograd.Function):
     def forward(ctx, x, weight):
         x = x.contiguous()
         cin, cout, s, _ = weight.shape
-        ones, zeros = torch.ones(cout, device=x.device), torch.zeros(cout, device=x.device)
-        pc = kernels.pack_deconv(weight, ones, zeros, relu=False, tile_cfg=1 if s < 4 else 2)
+        def build():
+            ones, zeros = torch.ones(cout, device=x.device), torch.zeros(cout, device=x.device)
+            return kernels.pack_deconv(weight, ones, zeros, relu=False, tile_cfg=1 if s < 4 else 2)
+        pc = _packed(weight, "deconv", build)
         ctx.save_for_backward(x, weight)
         return kernels.conv2d_nhwc(x, pc)
 
@@ -362,8 +371,10 @@ class _Deconv(torch.autograd.Function):
         dzs = dz.reshape(N, H, s, W, s, cout).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, cols).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            g = weight.detach().permute(0, 2, 3, 1).reshape(cin, cols, 1, 1)     # dx[ci] = sum_col dzs[col] * g[ci][col]
-            dx = conv_fwd_raw(dzs, g, 1)
+            def build():
+                g = weight.detach().permute(0, 2, 3, 1).reshape(cin, cols, 1, 1)     # dx[ci] = sum_col dzs[col] * g[ci][col]
+                return kernels.pack_conv(g, None, None, stride=1, relu=False, tile_cfg=_tile_cfg(cin))
+            dx = kernels.conv2d_nhwc(dzs, _packed(weight, "deconv_dgrad", build))
         if ctx.needs_input_grad[1]:
             dg = conv_wgrad(x, dzs, 1, 1, cols, cin)                              # (cols, Cin, 1, 1)
             dw = dg.reshape(s, s, cout, cin).permute(3, 2, 0, 1).contiguous()

@@ -544,14 +544,20 @@ def conv2d_nhwc(x, pc, out=None, out_coff=0, gate=None, resid=None):
     return out
 
 
-def conv2d_s2_dgrad_nhwc(dz, weight, H, W):
+def pack_conv_s2_dgrad(weight):
+    """The weight image conv2d_s2_dgrad_nhwc multiplies with: the filter with its channel axes swapped, taps not flipped."""
+    return pack_conv(weight.detach().permute(1, 0, 2, 3), None, None, stride=1, relu=False, tile_cfg=1)
+
+
+def conv2d_s2_dgrad_nhwc(dz, weight, H, W, pc=None):
     """Data gradient of a 3x3 stride-2 (pad 1) convolution with `weight` (Cout, Cin, 3, 3): dz (N,OH,OW,Cout) -> dx (N,H,W,Cin), gathered
     per output-pixel parity class (hvpr_conv2d_s2_dgrad_nhwc_f32: 2.25 taps per pixel instead of a stride-1 convolution's 9 over a
     zero-upsampled dz)."""
     N, OH, OW, cout = dz.shape
     cin = weight.shape[1]
     assert weight.shape[0] == cout and tuple(weight.shape[2:]) == (3, 3) and OH == (H + 2 - 3) // 2 + 1 and OW == (W + 2 - 3) // 2 + 1
-    pc = pack_conv(weight.detach().permute(1, 0, 2, 3), None, None, stride=1, relu=False, tile_cfg=1)     # (Cin, Cout, 3, 3): taps not flipped
+    if pc is None:
+        pc = pack_conv_s2_dgrad(weight)                                                                    # (Cin, Cout, 3, 3): taps not flipped
     dx = torch.empty((N, H, W, cin), dtype=torch.float32, device=dz.device)
     check(lib().hvpr_conv2d_s2_dgrad_nhwc_f32(_ptr(dz, torch.float32, "dz"), N, OH, OW, cout, pc.w.data_ptr(), pc.bias.data_ptr(), cin,
                                               pc.cout_pad, H, W, dx.data_ptr(), cin, 0, _stream()), "hvpr_conv2d_s2_dgrad_nhwc_f32")
