@@ -320,10 +320,13 @@ class _Conv(torch.autograd.Function):
         if partials is None:
             partials = z.new_empty((0, 2, z.shape[-1]))
         ctx.mark_non_differentiable(partials)
+        ctx.set_materialize_grads(False)     # (their gradients would arrive as zero tensors: one allocation + fill each, per call)
         return z, partials
 
     @staticmethod
     def backward(ctx, dz, _dp=None):
+        if dz is None:
+            return None, None, None, None
         x, weight = ctx.saved_tensors
         dz = dz.contiguous()
         cout, cin, k, _ = weight.shape
@@ -404,10 +407,13 @@ class _BNReLU(torch.autograd.Function):
         ctx.relu, ctx.count = relu, count
         cnt = count if torch.is_tensor(count) else torch.tensor(float(count), dtype=torch.float64)      # (a HOST tensor: no copy to the device, no sync)
         ctx.mark_non_differentiable(mean, var, cnt)
+        ctx.set_materialize_grads(False)     # (their gradients would arrive as zero tensors: one allocation + fill each, per call)
         return y, mean, var, cnt
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv, _dc):
+        if dy is None:
+            return (None,) * 9
         z, scale, shift, mean, invstd, gate = ctx.saved_tensors
         dy = dy.contiguous()
         C = z.shape[-1]
@@ -450,10 +456,13 @@ class _SfmStep(torch.autograd.Function):
         ctx.count = count
         cnt = count if torch.is_tensor(count) else torch.tensor(float(count), dtype=torch.float64)      # (a HOST tensor: no copy to the device, no sync)
         ctx.mark_non_differentiable(mean, var, cnt)
+        ctx.set_materialize_grads(False)     # (their gradients would arrive as zero tensors: one allocation + fill each, per call)
         return y, mean, var, cnt
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv, _dc):
+        if dy is None:
+            return (None,) * 7
         x, weight, z, scale, shift, mean, invstd, gate = ctx.saved_tensors
         dy = dy.contiguous()
         C = z.shape[-1]
@@ -604,10 +613,13 @@ class _GateTrain(torch.autograd.Function):
         ctx.wshape = tuple(weight.shape)
         mean, var = stats[0:1], stats[1:2]
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)     # (their gradients would arrive as zero tensors: one allocation + fill each, per call)
         return gate, mean, var
 
     @staticmethod
     def backward(ctx, dgate, _dm, _dv):
+        if dgate is None:
+            return (None,) * 6
         gate, a, stats, pooled, argmax, w18, g_ = ctx.saved_tensors
         N, H, W, C = ctx.dims
         dev = gate.device

@@ -125,11 +125,14 @@ class _PfnTrain(torch.autograd.Function):
         ctx.save_for_backward(voxels, num, coords, *args)
         ctx.geom = (float(eps), tuple(vs), tuple(off))
         ctx.mark_non_differentiable(m0, v0, m1, v1)
+        ctx.set_materialize_grads(False)     # (their gradients would arrive as zero tensors: one allocation + fill each, per call)
         return out, m0, v0, m1, v1
 
     @staticmethod
     def backward(ctx, d_out, *_):
         voxels, num, coords, w0, g0, b0, w1, g1, b1 = ctx.saved_tensors
+        if d_out is None:
+            d_out = torch.zeros((voxels.shape[0], w1.shape[0]), dtype=torch.float32, device=voxels.device)
         eps, vs, off = ctx.geom
         M, P, _ = voxels.shape
         grads = [torch.empty_like(t) for t in (w0, g0, b0, w1, g1, b1)]
