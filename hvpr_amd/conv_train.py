@@ -235,7 +235,8 @@ _weights_epoch = [0]
 
 
 def weights_changed():
-    """Parameters were written behind torch's back (the flat fused optimiser's kernel): cached packed filters are stale."""
+    """Parameters were written behind torch's back — through a raw pointer (the flat fused optimiser's kernel) or in place through
+    `.data`, which has its own version counter: cached packed filters are stale.  Anything that writes weights that way calls this."""
     _weights_epoch[0] += 1
     _wino_pack_cache.clear()
 
