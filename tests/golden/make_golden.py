@@ -922,6 +922,132 @@ def g15_post_processing(R):
     np.savez_compressed(os.path.join(OUT, "g15_post_processing.npz"), **out)
 
 
+def g16_train_branch_gradients(R):
+    """G16: which tensor receives which gradient in the training branch — the reference's own
+    PointPillarScatter_Agg_Memory_1_scale.forward (pointpillar_scatter.py:87-167, get_score :67-83), MemoryUnit_Agg training
+    branch (memory_module.py:31-59), AnchorHeadSingle training forward (anchor_head_single.py:41-108) and get_loss
+    (anchor_head_template.py:262-291), CPU, fp32 and float64.
+
+    T1 is patched in exactly as DESIGN.md decided, and nothing else: get_score additionally returns the k
+    positive point features it already computes (:76), and the training branch hands them to the memory as its second input
+    (`self.memory(pillars.t(), self.k)` at :133 has one argument too few for memory_module.py:29-34).
+
+    The head is fed the canvases directly (128 input channels; the backbone between them is pinned by G4-train), so the stored
+    scalars are the three losses of get_loss, and a fixed cotangent on the scale canvas gives that stream a gradient too:
+        L = rpn_loss + rpn_loss_point + mem_loss + sum(spatial_scale_features * cot_scale).
+    Stored: the three canvases, point / memory positive features, the losses (fp32 module), and from the float64 module the
+    gradient of EACH loss separately w.r.t. pillar_features, point_features and memory.weight (an exactly-zero block = a
+    `.detach()` of the reference: :76,:80,:140, memory_module.py:56, anchor_head_template.py:268), the gradient of L w.r.t.
+    pillar_scale_features and every head parameter, and the norm-wise distance of the fp32 module's gradients from them."""
+    import copy
+
+    def patch_t1(src):
+        a = "return {'output': output, 'att': score}"
+        b = "points_memory = self.memory(pillars.t(), self.k)"
+        assert src.count(a) == 1 and src.count(b) == 2          # the first occurrence is the training branch (:133), the second eval (:200)
+        src = src.replace(a, "return {'output': output, 'att': score, 'positive': points_positive}")
+        return src.replace(b, "points_memory = self.memory(pillars.t(), self.k, points_positive_['positive'])", 1)
+
+    sc_mod = _load("pcdet.models.backbones_2d.map_to_bev.pointpillar_scatter_t1",
+                   "pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py", patch_t1)
+    seed = 1616
+    gen = torch.Generator().manual_seed(seed)
+    nx, ny, B = 12, 10, 2
+    rng = np.array([0, -2.5, -2.5, 6.0, 2.5, 0.5], dtype=np.float32)                # 0.5 m cells
+    cfg = EasyDict(NUM_BEV_FEATURES=128, NUM_COORD_POINTS=3, NUM_PT_FEATURES=64, NUM_SCALE_FEATURES=32, NUM_K=20, NUM_M=2000,
+                   SHRINK_TH=0.0025)
+    scat = sc_mod.PointPillarScatter_Agg_Memory_1_scale(model_cfg=cfg, grid_size=np.array([nx, ny, 1]))
+    # the bank at 4x its initial range: with U(+-1/8) rows and post-ReLU features every softmax value stays below SHRINK_TH and
+    # the addressing is identically zero (G10's regime); here 30-80 items per row pass the threshold
+    W = det_state({"memory.weight": (2000, 64)}, seed)["memory.weight"] * 4.0
+    scat.memory.weight.data = torch.from_numpy(W)
+    scat.train()
+    torch.manual_seed(seed)
+    head = R.head_single.AnchorHeadSingle(model_cfg=_head_cfg(1), input_channels=128, num_class=1, class_names=["Car"],
+                                          grid_size=np.array([nx, ny, 1]), point_cloud_range=rng)
+    head.conv_cls.weight.data.normal_(0, 0.05, generator=gen)
+    head.conv_box.weight.data.normal_(0, 0.05, generator=gen)
+    head.conv_dir_cls.weight.data.normal_(0, 0.1, generator=gen)
+    head.conv_box.bias.data.normal_(0, 0.1, generator=gen)
+    head.train()
+    M = [57, 63]
+    N = [900, 860]
+    cells = [torch.randperm(nx * ny, generator=gen)[:m] for m in M]
+    coords = torch.cat([torch.stack([torch.full((m,), b), torch.zeros(m, dtype=torch.long), c // nx, c % nx], dim=1)
+                        for b, (m, c) in enumerate(zip(M, cells))]).float()
+    pillars = torch.relu(torch.randn(sum(M), 64, generator=gen))
+    scale = torch.relu(torch.randn(sum(M), 32, generator=gen))
+    points = torch.relu(torch.randn(sum(N), 64, generator=gen)) * 0.5
+    point_coords = torch.cat([torch.cat([torch.full((n, 1), float(b)), torch.rand(n, 3, generator=gen)], dim=1) for b, n in enumerate(N)])
+    gt = torch.zeros(B, 4, 8)
+    gt[0, 0] = torch.tensor([2.2, 0.3, -1.0, 3.9, 1.6, 1.56, 0.1, 1])
+    gt[0, 1] = torch.tensor([4.1, -1.4, -1.0, 3.6, 1.5, 1.5, 1.45, 1])
+    gt[1, 0] = torch.tensor([3.3, -0.4, -1.1, 3.8, 1.6, 1.5, 0.8, 1])
+    gt[1, 1] = torch.tensor([1.4, 1.5, -1.0, 4.0, 1.65, 1.55, 1.6, 1])
+    gt[1, 2] = torch.tensor([5.0, 0.9, -0.9, 4.2, 1.7, 1.6, -2.9, 1])
+    cot = torch.from_numpy(det_state({"cotangent.scale": (B, 32, ny, nx)}, seed)["cotangent.scale"]) * 0.01
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        s, h = copy.deepcopy(scat).to(dt), copy.deepcopy(head).to(dt)
+        h.anchors = [a.to(dt) for a in h.anchors]
+        ins = {k: v.clone().to(dt).requires_grad_(True) for k, v in (("pillar_features", pillars), ("point_features", points),
+                                                                      ("pillar_scale_features", scale))}
+        d = s({**ins, "pillar_mask": torch.ones(sum(M), 32, 1, dtype=dt), "voxel_coords": coords.to(dt),
+               "point_coords": point_coords.to(dt)})
+        canv = {k: d[k] for k in ("spatial_features", "spatial_features_point", "spatial_scale_features")}
+        d.update(spatial_features_2d=d["spatial_features"], spatial_features_point_2d=d["spatial_features_point"],
+                 gt_boxes=gt.clone().to(dt), batch_size=B)
+        h(d)
+        rpn, rpn_pt, mem, tb, items = h.get_loss()
+        assert items is s.memory.weight
+        leaves = [ins["pillar_features"], ins["point_features"], s.memory.weight]
+        per = {}
+        for name, val in (("rpn_loss", rpn), ("rpn_loss_point", rpn_pt), ("mem_loss", mem)):
+            g = torch.autograd.grad(val, leaves, retain_graph=True, allow_unused=True)
+            per[name] = [torch.zeros_like(l) if x is None else x for x, l in zip(g, leaves)]
+        total = rpn + rpn_pt + mem + (canv["spatial_scale_features"] * cot.to(dt)).sum()
+        hp = dict(h.named_parameters())
+        g = torch.autograd.grad(total, [ins["pillar_scale_features"]] + list(hp.values()))
+        res[dt] = dict(canv={k: v.detach() for k, v in canv.items()}, pos_point=d["point_positive_features"].detach(),
+                       pos_mem=d["memory_positive_features"].detach(), losses=(rpn.item(), rpn_pt.item(), mem.item()),
+                       tb={k: float(v) for k, v in tb.items()}, per=per, gscale=g[0], ghead=dict(zip(hp.keys(), g[1:])),
+                       labels=h.forward_ret_dict["box_cls_labels"].detach())
+    r32, r64 = res[torch.float32], res[torch.float64]
+
+    def nerr(a, b):
+        return float((a.double() - b).norm() / b.norm().clamp_min(1e-300))
+    out = dict(nx=nx, ny=ny, point_cloud_range=rng, seed=seed, bank_scale=4.0, pillar_features=pillars.numpy(),
+               pillar_scale_features=scale.numpy(), point_features=points.numpy(), voxel_coords=coords.numpy(),
+               point_coords=point_coords.numpy(), gt_boxes=gt.numpy(), cot_scale=cot.numpy(),
+               box_cls_labels=r32["labels"].numpy(), losses=np.array(r32["losses"], dtype=np.float64),
+               losses_f64=np.array(r64["losses"], dtype=np.float64), point_positive_features=r32["pos_point"].numpy(),
+               memory_positive_features=r32["pos_mem"].numpy(),
+               memory_positive_features_f64=r64["pos_mem"].float().numpy())
+    for k, v in r32["canv"].items():
+        out[k] = v.numpy()
+    for k, v in r32["tb"].items():
+        out["tb." + k] = np.float64(v)
+    for k, v in sd_np(head).items():
+        out["param." + k] = v
+    for loss in ("rpn_loss", "rpn_loss_point", "mem_loss"):
+        for name, g32, g64 in zip(("pillar_features", "point_features", "memory.weight"), r32["per"][loss], r64["per"][loss]):
+            key = f"{loss}.{name}"
+            if float(g64.abs().max()) == 0.0:
+                assert float(g32.abs().max()) == 0.0
+                out["zero." + key] = True                          # a detach of the reference: exactly no gradient
+            else:
+                out["zero." + key] = False
+                out["grad." + key] = g64.float().numpy()
+                out["ref32_err." + key] = nerr(g32, g64)
+    out["grad.total.pillar_scale_features"] = r64["gscale"].float().numpy()
+    out["ref32_err.total.pillar_scale_features"] = nerr(r32["gscale"], r64["gscale"])
+    for k, g64 in r64["ghead"].items():
+        out["grad.total.head." + k] = g64.float().numpy()
+        out["ref32_err.total.head." + k] = nerr(r32["ghead"][k], g64)
+    np.savez_compressed(os.path.join(OUT, "g16_train_branch_gradients.npz"), **out)
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     R = load_reference()
@@ -939,6 +1065,7 @@ if __name__ == "__main__":
     g13_voxel_index(R)
     g14_axis_aligned_iou(R)
     g15_post_processing(R)
+    g16_train_branch_gradients(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")

@@ -24,6 +24,20 @@ def test_g10_point_pillar_attention_and_memory_train_branch(golden_dir):
     C.run_g10(golden_dir)
 
 
+def test_g16_torch_forms_reproduce_the_reference_gradients_float64(golden_dir):
+    """The comparator of the GPU parity tests (tests/torch_forms.py: scatter training branch, get_score, memory addressing, head)
+    + the product's target assigner and losses.py against the reference's own modules in float64: values, and the gradient of each
+    of the three losses w.r.t. pillar / point features and the memory bank to 1e-6 norm-wise, exact zeros where the reference detaches."""
+    import torch
+    rep = C.run_g16(golden_dir, "cpu", torch.float64, value_rtol=1e-5, grad_tol=1e-6)
+    assert len(rep) == 13 and max(e for e, _ in rep.values()) < 1e-6
+
+
+def test_g16_torch_forms_fp32(golden_dir):
+    import torch
+    C.run_g16(golden_dir, "cpu", torch.float32, value_rtol=1e-5, grad_tol=1e-5)
+
+
 def test_training_modules_refuse_cpu_tensors():
     """The product path has no CPU fallback: get_score / the memory training branch / the backbone, head and VFE training forwards
     raise on CPU tensors; the torch forms the fixtures above run through live in tests/torch_forms.py."""

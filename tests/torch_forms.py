@@ -9,6 +9,7 @@ updates), following the reference line by line:
   vfe_train        PillarVFE_Scale.forward                              pcdet/models/backbones_3d/vfe/pillar_vfe.py:184-221
   memory_train     MemoryUnit_Agg.forward, training branch              pcdet/models/backbones_2d/map_to_bev/memory_module.py:31-59
   topk_points      the top-k of PointPillarScatter...get_score          .../map_to_bev/pointpillar_scatter.py:67-83
+  scatter_train    PointPillarScatter_Agg_Memory_1_scale.forward, training branch   .../pointpillar_scatter.py:87-167
   head_train       AnchorHeadSingle.forward, training branch            pcdet/models/dense_heads/anchor_head_single.py:41-108
   sa_forward / fp_forward   PointnetSAModuleMSG / PointnetFPModule with torch shared MLPs (pointnet2_backbone.py:27-47)
 
@@ -104,6 +105,37 @@ def get_score(self, points, pillars):
     return (w.detach().unsqueeze(2) * positives).sum(dim=1), positives
 
 
+def scatter_train(self, batch_dict):
+    """pointpillar_scatter.py:87-167 as written there: a loop over the frames with boolean masks, get_score, the memory with the
+    positives as its second input (T1), dense canvases filled by column assignment; the pillar half of the memory-fed canvas is
+    detached (:140)."""
+    pf, sf, coords = batch_dict["pillar_features"], batch_dict["pillar_scale_features"], batch_dict["voxel_coords"]
+    point_f, point_c = batch_dict["point_features"], batch_dict["point_coords"]
+    B = int(batch_dict["batch_size"]) if "batch_size" in batch_dict else int(coords[:, 0].max().item()) + 1
+    cells = self.nx * self.ny
+    sp, spp, sc, pos_point, pos_mem = [], [], [], [], []
+    for b in range(B):
+        vm, pm = coords[:, 0] == b, point_c[:, 0] == b
+        c = coords[vm]
+        idx = (c[:, 1] + c[:, 2] * self.nx + c[:, 3]).long()
+        pillars = pf[vm]
+        agg, positives = get_score(self, point_f[pm], pillars)
+        mem = self.memory(pillars, self.k, positives)["output"]
+        canv = [pf.new_zeros(self.num_bev_features, cells), pf.new_zeros(self.num_bev_features, cells), sf.new_zeros(sf.shape[1], cells)]
+        canv[0][:, idx] = torch.cat((pillars.detach(), mem), dim=1).t()
+        canv[1][:, idx] = torch.cat((pillars, agg), dim=1).t()
+        canv[2][:, idx] = sf[vm].t()
+        sp.append(canv[0]); spp.append(canv[1]); sc.append(canv[2])
+        pos_point.append(agg); pos_mem.append(mem)
+    batch_dict["spatial_features"] = torch.stack(sp, 0).view(B, -1, self.ny, self.nx)
+    batch_dict["spatial_features_point"] = torch.stack(spp, 0).view(B, -1, self.ny, self.nx)
+    batch_dict["spatial_scale_features"] = torch.stack(sc, 0).view(B, -1, self.ny, self.nx)
+    batch_dict["point_positive_features"] = torch.cat(pos_point, 0)
+    batch_dict["memory_positive_features"] = torch.cat(pos_mem, 0)
+    batch_dict["memory_items"] = self.memory.weight
+    return batch_dict
+
+
 # ------------------------------------------------------------------------------------------------ a6 head (training)
 def head_train(self, data_dict):
     fr = self.forward_ret_dict
@@ -158,7 +190,8 @@ def _table():
         bev_backbone.BaseBEVBackbone_Scale: {"_forward_train": backbone_train},
         vfe.PillarVFE_Scale: {"_forward_train": vfe_train},
         map_to_bev.MemoryUnit_Agg: {"_forward_train": memory_train},
-        map_to_bev.PointPillarScatter_Agg_Memory_1_scale: {"get_score": get_score, "_topk_points": topk_points},
+        map_to_bev.PointPillarScatter_Agg_Memory_1_scale: {"get_score": get_score, "_topk_points": topk_points,
+                                                           "_forward_train": scatter_train},
         anchor_head.AnchorHeadSingle: {"_forward_train": head_train},
     }
 

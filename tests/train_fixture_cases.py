@@ -137,3 +137,83 @@ def run_g10(golden_dir, dev="cpu", rtol=1e-5):
     # gradients flow to the bank through the read-out and to the pillars through the point stream weights only via detach rules
     out["output"].sum().backward()
     assert m.memory.weight.grad is not None and torch.isfinite(m.memory.weight.grad).all()
+
+
+def _g16_modules(z, dev, dtype):
+    cfg = AttrDict(NUM_BEV_FEATURES=128, NUM_COORD_POINTS=3, NUM_PT_FEATURES=64, NUM_SCALE_FEATURES=32, NUM_K=20, NUM_M=2000, SHRINK_TH=0.0025)
+    nx, ny = int(z["nx"]), int(z["ny"])
+    scat = map_to_bev.PointPillarScatter_Agg_Memory_1_scale(cfg, np.array([nx, ny, 1]))
+    scat.memory.weight.data = torch.from_numpy(det_tensor("memory.weight", (2000, 64), int(z["seed"])) * np.float32(z["bank_scale"]))
+    head = anchor_head.AnchorHeadSingle(model_cfg=_head_cfg(), input_channels=128, num_class=1, class_names=["Car"],
+                                        grid_size=np.array([nx, ny, 1]), point_cloud_range=z["point_cloud_range"])
+    head.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")})
+    scat, head = scat.to(dev).to(dtype).train(), head.to(dev).to(dtype).train()
+    head.anchors = [a.to(dev).to(dtype) for a in head.anchors]
+    return scat, head
+
+
+def run_g16(golden_dir, dev="cpu", dtype=torch.float32, value_rtol=1e-5, grad_tol=1e-6):
+    """Fixture G16 — the reference's scatter training branch + memory addressing + head + get_loss, and WHICH tensor receives WHICH
+    gradient (every `.detach()` of pointpillar_scatter.py:75-80,140, memory_module.py:56, anchor_head_template.py:268 shows as an
+    exactly-zero block).  On the CPU the torch forms of tests/torch_forms.py run (float64: gradients to grad_tol norm-wise); on
+    cuda:0 the product's kernels (fp32: tolerance = max(grad_tol, 3 x the distance of the reference's OWN fp32 gradients from its
+    float64 ones))."""
+    z = _load(golden_dir, "g16_train_branch_gradients.npz")
+    scat, head = _g16_modules(z, dev, dtype)
+    on_cpu = torch.device(dev).type == "cpu"
+    if on_cpu:
+        torch_forms.patch(scat)
+        torch_forms.patch(head)
+    t = lambda k: torch.from_numpy(z[k]).to(dev).to(dtype)
+    ins = {k: t(k).requires_grad_(True) for k in ("pillar_features", "point_features", "pillar_scale_features")}
+    d = scat({**ins, "voxel_coords": t("voxel_coords"), "point_coords": t("point_coords"), "batch_size": 2})
+    canv = {k: d[k] for k in ("spatial_features", "spatial_features_point", "spatial_scale_features")}
+    d.update(spatial_features_2d=d["spatial_features"], spatial_features_point_2d=d["spatial_features_point"], gt_boxes=t("gt_boxes"))
+    head(d)
+    np.testing.assert_array_equal(_np(head.forward_ret_dict["box_cls_labels"]), z["box_cls_labels"])
+    rpn, rpn_pt, mem, tb, items = head.get_loss()
+    assert items is scat.memory.weight
+
+    # ---- values (fp32 fixture values; the float64 run is closer to them than the fp32 reference's own round-off)
+    vt = max(value_rtol, 1e-5)
+    for k, v in canv.items():
+        ref = z[k]
+        assert np.abs(_np(v).astype(np.float64) - ref).max() <= vt * np.abs(ref).max(), k
+        assert ((_np(v) != 0) == (ref != 0)).all(), k                   # the same cells / channels are occupied
+    np.testing.assert_allclose(_np(d["point_positive_features"]), z["point_positive_features"], rtol=0, atol=vt * np.abs(z["point_positive_features"]).max())
+    ref_mem = z["memory_positive_features_f64"] if dtype == torch.float64 else z["memory_positive_features"]
+    # a softmax value within round-off of SHRINK_TH may pass on one side and not on the other: one item of one row, norm-wise small
+    err = np.linalg.norm(_np(d["memory_positive_features"]).astype(np.float64) - ref_mem) / np.linalg.norm(ref_mem)
+    assert err < 10 * vt, err
+    ref_losses = z["losses_f64"] if dtype == torch.float64 else z["losses"]
+    np.testing.assert_allclose([rpn.item(), rpn_pt.item(), mem.item()], ref_losses, rtol=value_rtol if dtype == torch.float32 else 1e-9)
+    if dtype == torch.float32:
+        for k in ("rpn_loss_cls", "rpn_loss_loc", "rpn_loss_dir", "rpn_loss_cls_pt", "rpn_loss_loc_pt", "rpn_loss_dir_pt", "mem_loss"):
+            np.testing.assert_allclose(float(tb[k]), float(z["tb." + k]), rtol=value_rtol, err_msg=k)
+
+    # ---- gradients, loss by loss: who gets one and who does not
+    leaves = {"pillar_features": ins["pillar_features"], "point_features": ins["point_features"], "memory.weight": scat.memory.weight}
+    report = {}
+    for lname, val in (("rpn_loss", rpn), ("rpn_loss_point", rpn_pt), ("mem_loss", mem)):
+        g = torch.autograd.grad(val, list(leaves.values()), retain_graph=True, allow_unused=True)
+        for (name, leaf), gv in zip(leaves.items(), g):
+            key = f"{lname}.{name}"
+            if bool(z["zero." + key]):
+                assert gv is None or float(gv.abs().max()) == 0.0, f"{key}: the reference detaches here, got a gradient"
+                continue
+            assert gv is not None, f"{key}: the reference has a gradient here"
+            ref = z["grad." + key].astype(np.float64)
+            e = np.linalg.norm(_np(gv).astype(np.float64) - ref) / np.linalg.norm(ref)
+            tol = grad_tol if dtype == torch.float64 else max(grad_tol, 3 * float(z["ref32_err." + key]))
+            report[key] = (e, tol)
+            assert e < tol, (key, e, tol)
+    total = rpn + rpn_pt + mem + (canv["spatial_scale_features"] * t("cot_scale")).sum()
+    hp = dict(head.named_parameters())
+    g = torch.autograd.grad(total, [ins["pillar_scale_features"]] + list(hp.values()))
+    for key, gv in zip(["pillar_scale_features"] + ["head." + k for k in hp], g):
+        ref = z["grad.total." + key].astype(np.float64)
+        e = np.linalg.norm(_np(gv).astype(np.float64) - ref) / np.linalg.norm(ref)
+        tol = grad_tol if dtype == torch.float64 else max(grad_tol, 3 * float(z["ref32_err.total." + key]))
+        report["total." + key] = (e, tol)
+        assert e < tol, (key, e, tol)
+    return report
