@@ -26,6 +26,18 @@ def test_g10_get_score_and_memory_train_branch_on_gpu(golden_dir):
     C.run_g10(golden_dir, DEV, rtol=1e-4)
 
 
+def test_g16_training_branch_gradient_semantics_on_gpu(golden_dir):
+    """Rows a10 + a13 against the REFERENCE's autograd (fixture G16): the product's scatter training branch (point top-k kernel,
+    hvpr_gather_rows / segment sums, hvpr_memory_train_fwd/bwd, scatter + its gather-back), the head's training forward on the
+    library's convolutions and losses.py.  Values 1e-4; the gradient of EACH loss w.r.t. pillar features, point features and the
+    memory bank norm-wise within max(1e-4, 3 x the reference's own fp32-vs-float64 distance), and exactly zero wherever the
+    reference detaches (pointpillar_scatter.py:75-80,140, memory_module.py:56, anchor_head_template.py:268)."""
+    import torch
+    rep = C.run_g16(golden_dir, DEV, torch.float32, value_rtol=1e-4, grad_tol=1e-4)
+    assert len(rep) == 13
+    print("G16 on gpu:", {k: f"{e:.1e}/{t:.0e}" for k, (e, t) in rep.items()})
+
+
 def _g4_train_setup(golden_dir, tag):
     import numpy as np
     import torch

@@ -179,7 +179,8 @@ def run_g16(golden_dir, dev="cpu", dtype=torch.float32, value_rtol=1e-5, grad_to
     for k, v in canv.items():
         ref = z[k]
         assert np.abs(_np(v).astype(np.float64) - ref).max() <= vt * np.abs(ref).max(), k
-        assert ((_np(v) != 0) == (ref != 0)).all(), k                   # the same cells / channels are occupied
+        occ = slice(0, 64) if k == "spatial_features" else slice(None)   # (a memory row is all zero when no item passes SHRINK_TH)
+        assert ((_np(v)[:, occ] != 0) == (ref[:, occ] != 0)).all(), k   # the same cells / channels are occupied
     np.testing.assert_allclose(_np(d["point_positive_features"]), z["point_positive_features"], rtol=0, atol=vt * np.abs(z["point_positive_features"]).max())
     ref_mem = z["memory_positive_features_f64"] if dtype == torch.float64 else z["memory_positive_features"]
     # a softmax value within round-off of SHRINK_TH may pass on one side and not on the other: one item of one row, norm-wise small
