@@ -145,6 +145,16 @@ class StagedGraphs:
         return self.out
 
 
+def _no_grad(fn):
+    if fn is None:
+        return None
+
+    def wrapped(*a, **k):
+        with torch.no_grad():
+            return fn(*a, **k)
+    return wrapped
+
+
 def host_cores():
     """Cores this process may really use: the cgroup CPU quota when there is one (the GPU box shows 256 logical CPUs
     behind a 16-CPU quota; running 256 torch threads against it is 60x slower than 16), else the affinity mask."""
@@ -158,25 +168,157 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cfg, params, n_timed=10, n_warm=3):
-    """the CPU restatement of a1..a8 on this box's host cores, 3 warm-up + 10 timed frames."""
+def cpu_baseline(cfg, params, n_timed=10, n_warm=3, check=None):
+    """the CPU restatement of a1..a8 on this box's host cores, 3 warm-up + 10 timed frames.  check(frame, preds,
+    intermediates) is called for every frame OUTSIDE the timed intervals: the parity gates (the GPU pipeline that produced `value`
+    is handed the same frame and compared stage by stage)."""
     from oracle import hvpr_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
     ocfg = O.cfg_from_model_cfg(cfg)
     frames = [synthetic.hvpr_frame(1000 + i) for i in range(n_timed + n_warm)]
     for f in frames[:n_warm]:
-        O.forward_frames([f], params, ocfg)             # warm-up (allocators, oneDNN primitives)
+        preds, inter = O.forward_frames([f], params, ocfg)             # warm-up (allocators, oneDNN primitives)
+        if check is not None:
+            check(f, preds, inter)
+        del preds, inter
     timings = {}
-    t0 = time.perf_counter()
+    dt = 0.0
     for f in frames[n_warm:]:
-        O.forward_frames([f], params, ocfg, timings=timings)
-    dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        preds, inter = O.forward_frames([f], params, ocfg, timings=timings)
+        dt += time.perf_counter() - t0
+        if check is not None:
+            check(f, preds, inter)
+        del preds, inter
     return {"value": n_timed / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n_timed} synthetic hvpr_car frames (batch=1, a1..a8) after {n_warm} warm-up frames",
             "threads": {"dense stages (VFE, memory, scatter, backbone, head, decode)": f"torch CPU fp32, {cores} threads",
                         "voxelize, top-k + rotated NMS": "C restatement, 1 thread (sequential algorithms)"},
             "stage_ms": {k: round(1e3 * v / n_timed, 2) for k, v in timings.items()}}
+
+
+# ---------------------------------------------------------------------------------------------------------------- parity gates
+PARITY_RTOL = 1e-3            # north_star: feature tensors and box regressions within 1e-3 relative (fp32)
+# A survivor-set difference between the GPU pipeline and the CPU oracle must hang on a root decision whose quantity differs between
+# the two sides by no more than oracle/survivor_flips.DELTA_SCORE / DELTA_IOU (calibration: that file's header)
+
+
+def _relerr(got, ref):
+    """max over elements of |got - ref| / (|ref| + rms(ref)): <= rtol is the element-wise statement |got - ref| <= rtol |ref| +
+    rtol rms(ref) of tests/test_gpu_e2e.py (the absolute term is tied to the tensor's own scale)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    rms = float(np.sqrt(np.mean(np.square(ref)))) or 1e-30
+    return float((np.abs(got - ref) / (np.abs(ref) + rms)).max()) if ref.size else 0.0
+
+
+def eager_inspect(model, batch):
+    """The dictionary PipelinedForward.inspect returns, from one eager forward (modes without the frame pipeline)."""
+    out, _, bd = model(dict(batch), sync=False)
+    torch.cuda.synchronize()
+    d = {k: bd[k] for k in ("voxel_coords", "voxel_num_points", "voxel_offsets", "pillar_features", "pillar_scale_features",
+                            "spatial_features", "spatial_scale_features", "spatial_features_2d", "batch_cls_preds", "batch_box_preds",
+                            "batch_max_scores", "batch_max_labels")}
+    d["post_input"] = {k: bd[k] for k in ("batch_cls_preds", "batch_box_preds", "batch_max_scores", "batch_max_labels")}
+    d["post"] = out
+    return d
+
+
+class ParityGates:
+    """SURVEY.md §8d "parity gates run with every benchmark": the object that was TIMED (the frame pipeline / graph / eager model of
+    this run, its persistent canvases, packed weights and workspaces as the timed replays left them) is handed the frames the CPU
+    oracle has just been timed on, and compared with the oracle's intermediates:
+      voxel coords + counts + order bit-exact; pillar features, canvases, the 384-channel feature map and box regressions within
+      1e-3 relative; NMS survivor ids bit-exact when the oracle's post-processing is fed the GPU's own scores and boxes; and the two
+      pipelines' OWN survivor sets differ only where oracle/survivor_flips.explain can exhibit a root decision within round-off of
+      its threshold."""
+
+    def __init__(self, inspect, model_cfg, device):
+        pp = model_cfg.POST_PROCESSING
+        self.inspect, self.device = inspect, device
+        self.post = (float(pp.SCORE_THRESH), float(pp.NMS_CONFIG.NMS_THRESH), int(pp.NMS_CONFIG.NMS_PRE_MAXSIZE), int(pp.NMS_CONFIG.NMS_POST_MAXSIZE))
+        self.n = 0
+        self.worst = {"pillar_rel": 0.0, "pillar_scale_rel": 0.0, "canvas_rel": 0.0, "feat2d_rel": 0.0, "cls_rel": 0.0, "box_rel": 0.0,
+                      "heading_outside_frac": 0.0, "score_absdiff": 0.0}
+        self.voxel_exact = self.nms_exact = True
+        self.common = self.total = self.flips = self.unexplained = 0
+        self.min_common_frac = 1.0
+        self.roots, self.kept, self.same_order = [], [], [0, 0]
+
+    def __call__(self, frame, ref_preds, inter):
+        from oracle import hvpr_oracle as O
+        from oracle import survivor_flips
+        got = self.inspect(make_batch(frame, self.device))
+        cpu = lambda t: t.detach().cpu().numpy()
+        m = len(inter["voxel_coords"])
+        ok = int(cpu(got["voxel_offsets"])[-1]) == m
+        ok = ok and np.array_equal(cpu(got["voxel_coords"][:m]), inter["voxel_coords"])
+        ok = ok and np.array_equal(cpu(got["voxel_num_points"][:m]), inter["voxel_num_points"])
+        self.voxel_exact &= bool(ok)
+        w = self.worst
+        if ok:
+            w["pillar_rel"] = max(w["pillar_rel"], _relerr(cpu(got["pillar_features"][:m]), inter["pillar_features"].numpy()))
+            w["pillar_scale_rel"] = max(w["pillar_scale_rel"], _relerr(cpu(got["pillar_scale_features"][:m]), inter["pillar_scale_features"].numpy()))
+        w["canvas_rel"] = max(w["canvas_rel"], _relerr(cpu(got["spatial_features"]), inter["spatial_features"].numpy()),
+                              _relerr(cpu(got["spatial_scale_features"]), inter["spatial_scale_features"].numpy()))
+        w["feat2d_rel"] = max(w["feat2d_rel"], _relerr(cpu(got["spatial_features_2d"]), inter["spatial_features_2d"].numpy()))
+        w["cls_rel"] = max(w["cls_rel"], _relerr(cpu(got["batch_cls_preds"]), inter["batch_cls_preds"].numpy()))
+        gb, rb = cpu(got["batch_box_preds"]), inter["batch_box_preds"].numpy()
+        w["box_rel"] = max([w["box_rel"]] + [_relerr(gb[..., c], rb[..., c]) for c in range(6)])
+        # heading: the direction bin is an argmax of two logits — a near-tie may land in the other bin (anchor_head_template.py:327-333)
+        w["heading_outside_frac"] = max(w["heading_outside_frac"],
+                                        float((np.abs(gb[..., 6] - rb[..., 6]) >= PARITY_RTOL * np.abs(rb[..., 6]).max()).mean()))
+        # a8, strict: the oracle's post-processing on the GPU's own scores and boxes (the tensors the captured top-k + NMS read)
+        pin = got["post_input"]
+        s_gpu, b_gpu = cpu(pin["batch_max_scores"])[0], cpu(pin["batch_box_preds"])[0]
+        sel_ref, sc_ref = O.class_agnostic_nms(s_gpu, b_gpu, *self.post)
+        rec = got["post"][0]
+        n = int(rec["pred_count"].item())
+        sel = cpu(rec["selected"][:n])
+        self.nms_exact &= bool(np.array_equal(sel, sel_ref) and np.array_equal(cpu(rec["pred_scores"][:n]), sc_ref)
+                               and np.array_equal(cpu(rec["pred_boxes"][:n]), b_gpu[sel_ref]))
+        self.kept.append(n)
+        # a8, end to end: each pipeline on its own logits; every difference traced to its root
+        s_cpu = torch.sigmoid(inter["batch_cls_preds"][0]).max(dim=-1)[0].numpy()
+        w["score_absdiff"] = max(w["score_absdiff"], float(np.abs(s_gpu - s_cpu).max()))
+        r = survivor_flips.explain(s_gpu, b_gpu, s_cpu, rb[0], *self.post, delta_score=survivor_flips.DELTA_SCORE, delta_iou=survivor_flips.DELTA_IOU)
+        # the same with ONE score order (the GPU's scores on both sides, each side its own boxes): what is left are IoU decisions
+        r1 = survivor_flips.explain(s_gpu, b_gpu, s_gpu, rb[0], *self.post, delta_score=0.0, delta_iou=survivor_flips.DELTA_IOU)
+        self.same_order[0] += r1["common"]
+        self.same_order[1] += max(r1["survivors_a"], r1["survivors_b"])
+        self.unexplained += len(r1["unexplained"])
+        assert r["survivors_b"] == len(ref_preds[0]["selected"])          # side b IS the oracle's own post-processing
+        self.common += r["common"]
+        self.total += max(r["survivors_a"], r["survivors_b"])
+        self.min_common_frac = min(self.min_common_frac, r["common"] / max(r["survivors_a"], r["survivors_b"], 1))
+        self.flips += len(r["flips"])
+        self.unexplained += len(r["unexplained"])
+        for root in r["roots"]:
+            if len(self.roots) < 12:
+                self.roots.append({"frame": self.n, **{k: (round(v, 8) if isinstance(v, float) else v) for k, v in root.items()}})
+        self.n += 1
+
+    def result(self):
+        from oracle import survivor_flips
+        w = {k: float(f"{v:.3e}") for k, v in self.worst.items()}
+        ok = (self.n > 0 and self.voxel_exact and self.nms_exact and self.unexplained == 0 and w["heading_outside_frac"] < PARITY_RTOL
+              and self.same_order[0] >= 0.99 * self.same_order[1]
+              and all(w[k] <= PARITY_RTOL for k in ("pillar_rel", "pillar_scale_rel", "canvas_rel", "feat2d_rel", "cls_rel", "box_rel")))
+        return {"ok": bool(ok), "frames": self.n, "voxel_exact": bool(self.voxel_exact), **w, "rtol": PARITY_RTOL,
+                "nms_exact_on_gpu_logits": bool(self.nms_exact), "boxes_kept_per_frame": self.kept,
+                "survivors_common": [self.common, self.total], "survivors_common_min_frac": round(self.min_common_frac, 4),
+                "survivors_common_same_score_order": self.same_order,
+                "survivor_flips": self.flips, "survivor_flips_unexplained": self.unexplained,
+                "flip_delta": {"score": survivor_flips.DELTA_SCORE, "iou": survivor_flips.DELTA_IOU}, "flip_roots": self.roots,
+                "what": "the timed object (same pipeline / graphs, persistent canvases, packed weights) run on the cpu_baseline frames and "
+                        "compared with the CPU oracle stage by stage: voxel coords + counts + order exact; *_rel = max |gpu - cpu| / (|cpu| + "
+                        "rms(cpu)) <= rtol; heading_outside_frac = direction-bin near-ties; nms_exact_on_gpu_logits = oracle NMS on the GPU's "
+                        "scores and boxes gives the GPU's ids, scores and boxes bit for bit; survivors_common = [common, max(|gpu|, |cpu|)] "
+                        "summed over frames, each pipeline on its OWN logits; every id in the symmetric difference is traced to a root decision "
+                        "(flip_roots: quantity on side a = GPU and b = CPU oracle, threshold; order_swap = two overlapping candidates whose scores "
+                        "agree to a few ulp come in the other order) whose two values differ by <= flip_delta; "
+                        "survivors_common_same_score_order = the same with the GPU's scores on both sides (each side its own boxes): only IoU "
+                        "decisions can differ then"}
 
 
 class GroupGraphs:
@@ -401,6 +543,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates (profiling runs); the JSON line then carries parity = null")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-16 / dense-scene group lines and the train-step line")
     ap.add_argument("--probe-steps", type=int, default=30, help="extra untimed steps with per-stage HIP events")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
@@ -469,6 +612,7 @@ def main():
         return distributed.max_over_ranks(dt_local[0], device)
 
     alt = None
+    timed_object = None
     with torch.no_grad():
         if args.no_graph:
             mode = "eager launches"
@@ -486,6 +630,7 @@ def main():
                 dt = timed(pipe)
                 for _ in pipe.flush():
                     pass
+                timed_object = pipe                       # the parity gates below run on THIS object
                 mode = ("4-stage frame pipeline: one hipGraph replay per step = encode(k) | trunk + branches 0,1 (k-1) | last branch + head + "
                         "decode (k-2) | top-k+NMS (k-3) on separate HIP streams (frame latency = 4 steps)") if pipe.depth == 4 else \
                        ("3-stage frame pipeline: one hipGraph replay per step = encode(k) | convolutions(k-1) | top-k+NMS(k-2) "
@@ -706,6 +851,22 @@ def main():
     res["alt_precision"] = alt
     res["pipeline_two_frames_per_replay"] = two
     res["train_step_ddp"] = train_ddp
+    # cpu_baseline + parity gates while the timed object is still alive: the oracle's frames go through it as well
+    gates = None
+    if not args.no_parity:
+        with torch.no_grad():
+            gates = ParityGates(timed_object.inspect if timed_object is not None else (lambda b: eager_inspect(model, b)), cfg.MODEL, device)
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, params, check=_no_grad(gates))
+    else:
+        res["cpu_baseline"] = None
+        if gates is not None:                     # N > 1 (or --no-cpu-baseline): the gates alone, on two frames
+            from oracle import hvpr_oracle as O
+            for i in range(2):
+                f = synthetic.hvpr_frame(1000 + i)
+                _no_grad(gates)(f, *O.forward_frames([f], params, O.cfg_from_model_cfg(cfg)))
+    res["parity"] = None if gates is None else gates.result()
+    del timed_object
     if world == 1 and not args.no_extras:
         # driver-visible numbers for the other BASELINE.json configs (bounded step counts): the same group at batch 16 and on
         # the dense scene (configs[4]); the full train step (configs[2])
@@ -714,12 +875,11 @@ def main():
         res["group_other_configs"] = extra_group_lines(device)
         res["train_step"] = train_step_line(device, "car", 16)
         res["train_step_3class_b8"] = train_step_line(device, "3class", 8)          # BASELINE.json configs[3], one GPU's share
-    if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(cfg, params)
-    else:
-        res["cpu_baseline"] = None
     print(json.dumps(res), flush=True)
     distributed.finalize()
+    if res["parity"] is not None and not res["parity"]["ok"]:
+        print("bench.py: PARITY GATE FAILED: " + json.dumps({k: v for k, v in res["parity"].items() if k != "what"}), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

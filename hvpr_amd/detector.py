@@ -547,6 +547,7 @@ class PipelinedForward:
         self.B = example_batch["batch_size"]
         self.inp = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()} for _ in range(2)]
         self.canvas, self.head, self.aux, self.split = [None, None], [None, None], [None, None], [None, None]
+        self.enc, self.f2d = [None, None], [None, None]
         # each lane owns its canvases for good, so the encode stage only clears what the lane's previous frame left in them
         self.own = [model.persistent_canvases(example_batch) if hasattr(model, "persistent_canvases") else {} for _ in range(2)]
         side = torch.cuda.Stream()
@@ -584,10 +585,12 @@ class PipelinedForward:
                 with torch.cuda.stream(self.s_enc):       # frame k (lane p): points -> canvases of lane p
                     bd = model.stage_encode({**self.inp[p], "_out_spatial": self.canvas[p], **self.own[p]})
                     self.aux[p] = bd["voxel_offsets"]
+                    self.enc[p] = {k: bd[k] for k in ("voxel_coords", "voxel_num_points", "voxel_offsets", "pillar_features",
+                                                      "pillar_scale_features") if bd.get(k) is not None}
                 dense_in = {"batch_size": self.B, "spatial_features": self.canvas[q][0], "spatial_scale_features": self.canvas[q][1]}
                 if depth == 3:
                     # frame k-1 (lane q): convolutions on the capture stream (+ the backbone's own branch streams)
-                    model.stage_dense({**dense_in, "_out_head": self.head[q]})
+                    self.f2d[q] = model.stage_dense({**dense_in, "_out_head": self.head[q]})["spatial_features_2d"]
                 else:
                     self.s_b.wait_stream(main)
                     with torch.cuda.stream(self.s_b):     # frame k-2 (lane p): last branch + head + decode
@@ -613,6 +616,30 @@ class PipelinedForward:
         self.graphs[p].replay()
         self.step += 1
         return self.out[p] if self.step >= self.depth else None
+
+    def inspect(self, batch):
+        """Parity hook (bench.py's parity gates, tests): push ONE frame through every stage of THIS pipeline — `depth` steps with the
+        same input, after which every lane's boundary buffers hold that frame — synchronise, and return copies of the encode
+        stage's outputs, the canvases, the 384-channel feature map, the head's decoded outputs and the frame's post-processing
+        result.  Nothing is recomputed outside the captured graphs: these are the tensors the timed replays produce."""
+        for _ in range(self.depth):
+            out = self(batch)
+        torch.cuda.synchronize()
+        p = (self.step - 1) & 1                     # lane the last step encoded into; its head buffers were written in the same step
+        q = 1 - p
+        d = {k: v.clone() for k, v in self.enc[p].items()}
+        d["spatial_features"], d["spatial_scale_features"] = self.canvas[p][0].clone(), self.canvas[p][1].clone()
+        if self.depth == 4:
+            d["spatial_features_2d"] = self.split[p]["out"].permute(0, 3, 1, 2).clone()
+            head_now, head_post = self.head[p], self.head[q]
+        else:
+            d["spatial_features_2d"] = self.f2d[q].clone()
+            head_now, head_post = self.head[q], self.head[p]
+        d.update({k: v.clone() for k, v in zip(self._HEAD_KEYS, head_now)})
+        # the post-processing of the last step read the OTHER lane's head buffers (the same frame, one step earlier)
+        d["post_input"] = {k: v.clone() for k, v in zip(self._HEAD_KEYS, head_post)}
+        d["post"] = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in rec.items()} for rec in out]
+        return d
 
     def flush(self):
         """depth - 1 more steps (re-encoding the last inputs, whose results are dropped): yields the results of the frames still in

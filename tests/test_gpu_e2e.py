@@ -38,12 +38,19 @@ def _batch(frames):
     return {"points": torch.from_numpy(pts).to(DEV), "batch_size": len(frames)}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3"])
-def test_forward_one_frame_matches_oracle(model_and_params, precision, observed):
-    """The whole detector against the CPU oracle, with the SAME thresholds for the exact fp32 convolutions and for the two
-    split-bf16 modes (bf16x6 = fp32 emulation, bf16x3 = three products)."""
-    cfg, model, params = model_and_params
-    frames = [synthetic.hvpr_frame(0)]
+@pytest.fixture(scope="module")
+def model_bench_bias():
+    """The configuration bench.py times: conv_cls.bias = -log(99) (anchor_head_single.py:35-37)."""
+    cfg = hvpr_car_cfg()
+    model = detector.build_network(cfg.MODEL, len(cfg.CLASS_NAMES), detector.SyntheticDataset(cfg))
+    params = synthetic_weights.load_synthetic(model, seed=0, cls_bias=-4.59511985013459)
+    model.export_voxels = True
+    return cfg, model.to(DEV).eval(), params
+
+
+def _check_frame_against_oracle(cfg, model, params, frame_id, precision, observed):
+    from oracle import survivor_flips as SF
+    frames = [synthetic.hvpr_frame(frame_id)]
     model.backbone_2d.set_conv_precision(precision)
     try:
         with torch.no_grad():
@@ -70,22 +77,116 @@ def test_forward_one_frame_matches_oracle(model_and_params, precision, observed)
     # heading: the direction bin is an argmax of two logits — compare where the bin decision is not a near-tie
     d = np.abs(gb[..., 6] - rb[..., 6])
     off = int((d >= 1e-3 * np.abs(rb[..., 6]).max()).sum())
-    observed(f"test_gpu_e2e: headings outside 1e-3 (direction-bin near-ties): {off} of {d.size} = {off / d.size:.2e} (bar 1e-3)")
+    observed(f"test_gpu_e2e[{precision}, frame {frame_id}]: headings outside 1e-3 (direction-bin near-ties): {off} of {d.size} = {off / d.size:.2e} (bar 1e-3)")
     assert off / d.size < 1e-3
     # a8: survivors bit-exact when the oracle's post-processing is fed the GPU's own logits and boxes
-    cls_gpu, box_gpu = bd["batch_cls_preds"].cpu().numpy(), gb
     scores_gpu = bd["batch_max_scores"].cpu().numpy()
-    ref = O.class_agnostic_nms(scores_gpu[0], box_gpu[0], 0.1, 0.1, 4096, 500)
+    ref = O.class_agnostic_nms(scores_gpu[0], gb[0], 0.1, 0.1, 4096, 500)
     np.testing.assert_array_equal(preds[0]["selected"].cpu().numpy(), ref[0])
     np.testing.assert_array_equal(preds[0]["pred_scores"].cpu().numpy(), ref[1])
-    np.testing.assert_array_equal(preds[0]["pred_boxes"].cpu().numpy(), box_gpu[0][ref[0]])
+    np.testing.assert_array_equal(preds[0]["pred_boxes"].cpu().numpy(), gb[0][ref[0]])
     assert (preds[0]["pred_labels"].cpu().numpy() == 1).all()
-    # end to end: the two pipelines keep (almost) the same boxes; fp32 round-off flips borderline suppression decisions, and
-    # each flip cascades through the greedy sweep (the strict check is the one above: same logits -> identical survivors)
-    a, b = set(preds[0]["selected"].cpu().numpy().tolist()), set(ref_preds[0]["selected"].tolist())
-    observed(f"test_gpu_e2e: survivors: GPU {len(a)}, oracle {len(b)}, common {len(a & b)} = {len(a & b) / max(len(a), len(b), 1):.4f} (bar 0.95)")
-    assert len(a & b) >= 0.95 * max(len(a), len(b), 1), (len(a), len(b), len(a & b))
-    assert 10 < len(a) <= 500
+    # end to end, each pipeline on its OWN logits: post-processing is a chain of hard decisions, so round-off-sized differences
+    # may flip one and the greedy sweep carries it on.  The exact statement: EVERY id kept by only one side is traced
+    # (oracle/survivor_flips.py) to a root decision whose quantity differs between the sides by <= DELTA_SCORE / DELTA_IOU —
+    # on these synthetic weights always an order swap of two overlapping candidates whose scores agree to a few ulp
+    scores_cpu = torch.sigmoid(inter["batch_cls_preds"][0]).max(dim=-1)[0].numpy()
+    loose = precision == "bf16x3"                          # three-product mode: ~2^-16 per product, not round-off
+    ds, di = (SF.DELTA_SCORE, SF.DELTA_IOU) if not loose else (1e-4, 1e-3)
+    r = SF.explain(scores_gpu[0], gb[0], scores_cpu, rb[0], 0.1, 0.1, 4096, 500, delta_score=ds, delta_iou=di)
+    assert r["survivors_b"] == len(ref_preds[0]["selected"]) and r["survivors_a"] == len(ref[0])
+    kinds = sorted({x["kind"] for x in r["roots"]})
+    observed(f"test_gpu_e2e[{precision}, frame {frame_id}]: survivors GPU {r['survivors_a']}, oracle {r['survivors_b']}, common {r['common']}; "
+             f"{len(r['flips'])} flips from {len(r['roots'])} roots {kinds}, unexplained {len(r['unexplained'])} (bar 0)")
+    assert r["unexplained"] == [], r["unexplained"][:3]
+    # with ONE score order (the GPU's scores on both sides, each side its own boxes) only IoU decisions can differ: >= 0.99 common
+    r1 = SF.explain(scores_gpu[0], gb[0], scores_gpu[0], rb[0], 0.1, 0.1, 4096, 500, delta_score=0.0, delta_iou=di)
+    observed(f"test_gpu_e2e[{precision}, frame {frame_id}]: same score order: common {r1['common']} of {max(r1['survivors_a'], r1['survivors_b'])} (bar 0.99)")
+    assert r1["unexplained"] == [] and r1["common"] >= 0.99 * max(r1["survivors_a"], r1["survivors_b"], 1)
+    assert r["common"] >= 0.85 * max(r["survivors_a"], r["survivors_b"], 1)        # disaster bar; the statements above are the test
+    assert 10 < r["survivors_a"] <= 500
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3"])
+def test_forward_one_frame_matches_oracle(model_and_params, precision, observed):
+    """The whole detector against the CPU oracle, with the SAME thresholds for the exact fp32 convolutions and for the two
+    split-bf16 modes (bf16x6 = fp32 emulation, bf16x3 = three products)."""
+    cfg, model, params = model_and_params
+    _check_frame_against_oracle(cfg, model, params, 0, precision, observed)
+
+
+@pytest.mark.parametrize("frame_id", [1, 2, 3, 4, 5, 6, 7])
+def test_forward_every_pool_frame_matches_oracle(model_and_params, frame_id, observed):
+    """The other seven frames of bench.py's pool (frame 0: above)."""
+    cfg, model, params = model_and_params
+    _check_frame_against_oracle(cfg, model, params, frame_id, "fp32", observed)
+
+
+@pytest.mark.parametrize("frame_id", [0, 5])
+def test_forward_matches_oracle_at_the_benchmark_cls_bias(model_bench_bias, frame_id, observed):
+    """The weights bench.py times (conv_cls.bias -4.595: the post-processing at its maximum size)."""
+    cfg, model, params = model_bench_bias
+    _check_frame_against_oracle(cfg, model, params, frame_id, "fp32", observed)
+
+
+def _annos(pred_list, class_names):
+    from hvpr_amd import kitti_eval
+    calib = {"P2": np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]], np.float32),
+             "R0": np.eye(3, dtype=np.float32), "Tr_velo2cam": np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27]], np.float32)}
+    out = []
+    for i, p in enumerate(pred_list):
+        out += kitti_eval.generate_prediction_dicts({"calib": [calib], "image_shape": [np.array([375, 1242])], "frame_id": ["%06d" % i]},
+                                                    [p], class_names)
+    return out
+
+
+def _as_gt(dt, sel=None):
+    sel = np.ones(len(dt["name"]), bool) if sel is None else sel
+    return {"name": dt["name"][sel], "truncated": np.zeros(sel.sum()), "occluded": np.zeros(sel.sum(), np.int64), "alpha": dt["alpha"][sel],
+            "bbox": dt["bbox"][sel], "dimensions": dt["dimensions"][sel], "location": dt["location"][sel], "rotation_y": dt["rotation_y"][sel]}
+
+
+def test_matched_average_precision_gpu_pipeline_vs_oracle_pipeline(model_and_params, observed):
+    """north_star "matched KITTI 3D AP", as far as it can be shown without data: the same eight frames through the GPU pipeline and
+    through the CPU oracle pipeline, both detection sets through the KITTI evaluator (kitti_object_eval_python/eval.py:639 ->
+    kitti_eval.get_official_eval_result, pinned by G12), BEV and 3-D AP_R40 at every difficulty.
+
+      (1) ties broken identically — the oracle pipeline's boxes ranked by the GPU's scores (the two differ by <= 1.3e-5, but the
+          synthetic head gives hundreds of overlapping candidates scores that agree to a few ulp, and which of two such twins
+          survives is decided by the last bit) — as ground truth, the GPU pipeline's detections as detections: AP >= 99;
+      (2) each pipeline on its own scores: reported, bar 95 — every missing point is an order swap of score twins that
+          test_forward_*_matches_oracle traces id by id (a swapped twin pair costs one false positive + one miss at IoU 0.7);
+      (3) a common ground truth (the confident half of the oracle's detections): the two pipelines' AP within 0.2 of each other
+          with ties broken identically, within 3 on their own scores."""
+    from hvpr_amd import kitti_eval
+    cfg, model, params = model_and_params
+    gpu, cpu, cpu_same = [], [], []
+    for i in range(8):
+        f = synthetic.hvpr_frame(i)
+        with torch.no_grad():
+            preds, _, bd = model(_batch([f]))
+        gpu.append({k: preds[0][k].cpu().numpy() for k in ("pred_boxes", "pred_scores", "pred_labels")})
+        ref, inter = O.forward_frames([f], params, O.cfg_from_model_cfg(cfg))
+        cpu.append({k: np.asarray(ref[0][k]) for k in ("pred_boxes", "pred_scores", "pred_labels")})
+        rb, sg = inter["batch_box_preds"][0].numpy(), bd["batch_max_scores"][0].cpu().numpy()
+        sel, sc = O.class_agnostic_nms(sg, rb, 0.1, 0.1, 4096, 500)
+        cpu_same.append({"pred_boxes": rb[sel], "pred_scores": sc, "pred_labels": np.ones(len(sel), np.int64)})
+    dt_gpu, dt_cpu, dt_same = (_annos(x, cfg.CLASS_NAMES) for x in (gpu, cpu, cpu_same))
+    keys = [f"Car_{m}/{d}_R40" for m in ("bev", "3d") for d in ("easy", "moderate", "hard")]
+    fmt = lambda r: ", ".join(f"{k[4:-4]} {r[k]:.2f}" for k in keys)
+    _, r1 = kitti_eval.get_official_eval_result([_as_gt(d) for d in dt_same], dt_gpu, ["Car"])
+    _, r2 = kitti_eval.get_official_eval_result([_as_gt(d) for d in dt_cpu], dt_gpu, ["Car"])
+    observed("test_gpu_e2e matched AP_R40, GT = oracle detections, ties broken identically: " + fmt(r1) + " (bar 99)")
+    observed("test_gpu_e2e matched AP_R40, GT = oracle detections, own scores: " + fmt(r2) + " (bar 95)")
+    for k in keys:
+        assert r1[k] >= 99.0 and r2[k] >= 95.0, (k, r1[k], r2[k])
+    for name, src, bar in (("ties broken identically", dt_same, 0.2), ("own scores", dt_cpu, 3.0)):
+        gts = [_as_gt(d, d["score"] >= np.median(d["score"])) for d in src]
+        _, rg = kitti_eval.get_official_eval_result(gts, dt_gpu, ["Car"])
+        _, rc = kitti_eval.get_official_eval_result(gts, src, ["Car"])
+        observed(f"test_gpu_e2e matched AP_R40, common GT (confident half of the oracle's), {name}: gpu [{fmt(rg)}] oracle [{fmt(rc)}] (bar |diff| {bar})")
+        for k in keys:
+            assert abs(rg[k] - rc[k]) <= bar and rc[k] > 10, (name, k, rg[k], rc[k])
 
 
 def test_batch_of_two_and_padded_outputs(model_and_params):
