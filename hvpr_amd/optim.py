@@ -297,7 +297,10 @@ def model_fn_decorator():
         ret, tb_dict, disp_dict = model(batch_dict)
         loss = ret["loss"].mean()
         (model.module if hasattr(model, "module") else model).update_global_step()
-        return loss, tb_dict, disp_dict, disp_dict.get("items")
+        # the memory items travel as the fourth value (train_utils.py:38, printed once per epoch :100-101), NOT inside disp_dict:
+        # the loop hands disp_dict to tqdm's set_postfix (:45-51), and a (2000, 64) tensor does not belong in a progress bar
+        items = disp_dict.pop("items", None)
+        return loss, tb_dict, disp_dict, items
 
     return model_func
 

@@ -1048,6 +1048,89 @@ def g16_train_branch_gradients(R):
     return out
 
 
+def g17_stubs(log):
+    """Recording stand-ins for everything train_one_epoch is handed: (model, optimizer, lr_scheduler, tbar, model_func, clip, items,
+    loader).  Every call appends one line to `log`.  Shared with tests/train_fixture_cases.py, which drives the SAME stand-ins with
+    its own loop and must produce the same lines."""
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+
+        def train(self, mode=True):
+            log.append(f"model.train({mode})" if mode is not True else "model.train()")
+            return super().train(mode)
+
+        def parameters(self, recurse=True):
+            log.append("model.parameters()")
+            return super().parameters(recurse)
+
+    class Optimizer:
+        def __init__(self):
+            self._lr = 0.0
+
+        @property
+        def lr(self):
+            log.append("read optimizer.lr")
+            return self._lr
+
+        def zero_grad(self):
+            log.append("optimizer.zero_grad()")
+
+        def step(self):
+            log.append("optimizer.step()")
+
+    class Scheduler:
+        def __init__(self, opt):
+            self.opt = opt
+
+        def step(self, it):
+            log.append(f"lr_scheduler.step({it})")
+            self.opt._lr = 0.001 * (it + 1)
+
+    class Bar:
+        def set_postfix(self, d):
+            log.append("tbar.set_postfix(" + ", ".join(f"{k}:{type(v).__name__}" for k, v in d.items()) + ")")
+
+        def refresh(self):
+            log.append("tbar.refresh()")
+
+    model, opt = Model(), Optimizer()
+    items = torch.arange(6.0).view(3, 2)
+
+    def model_func(m, batch):
+        assert m is model
+        log.append(f"model_func(model, batch[{batch['id']}])")
+        loss = (m.w * float(batch["id"] + 1)).sum()
+        loss.register_hook(lambda g: log.append("loss.backward()"))
+        return loss, {"tb_scalar": 1.5}, {"disp_scalar": 2.5}, items
+
+    def clip(params, max_norm):
+        params = list(params)
+        log.append(f"clip_grad_norm_(<{len(params)} parameters of the model>, {max_norm})")
+        assert params[0] is model.w and model.w.grad is not None
+    return model, opt, Scheduler(opt), Bar(), model_func, clip, items, [{"id": i} for i in range(3)]
+
+
+def g17_train_loop_protocol(R):
+    """G17: the call protocol of the reference's training loop — tools/train_utils/train_utils.py:9-61 `train_one_epoch` run as it
+    is, with recording stand-ins (g17_stubs) for everything it is handed (model, optimizer, lr_scheduler, model_func, the data
+    loader, tbar) and for the `clip_grad_norm_` it imports.  Stored: the sequence of calls with their arguments for 3 iterations
+    starting at accumulated_iter = 7, what it returns, and what it puts into the progress bar.  The plugin objects of the product
+    (model_fn_decorator, FusedAdamOneCycle, OneCycle) must work when driven in exactly this order."""
+    tu = _load("tools_train_utils_g17", "tools/train_utils/train_utils.py")
+    log = []
+    model, opt, sched, bar, model_func, clip, items, loader = g17_stubs(log)
+    tu.clip_grad_norm_ = clip
+    cfg = EasyDict(GRAD_NORM_CLIP=10)
+    ret_it, ret_items = tu.train_one_epoch(model, opt, loader, model_func, sched, accumulated_iter=7, optim_cfg=cfg, rank=0,
+                                           tbar=bar, total_it_each_epoch=3, dataloader_iter=iter(loader), tb_log=None, leave_pbar=False)
+    assert ret_items is items
+    np.savez_compressed(os.path.join(OUT, "g17_train_loop_protocol.npz"), calls=np.array(log), start_iter=7, n_iters=3,
+                        returned_iter=ret_it, returns_items_of_last_model_func=True, grad_norm_clip=10)
+    return log
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     R = load_reference()
@@ -1066,6 +1149,7 @@ if __name__ == "__main__":
     g14_axis_aligned_iou(R)
     g15_post_processing(R)
     g16_train_branch_gradients(R)
+    g17_train_loop_protocol(R)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")

@@ -38,6 +38,83 @@ def test_g16_training_branch_gradient_semantics_on_gpu(golden_dir):
     print("G16 on gpu:", {k: f"{e:.1e}/{t:.0e}" for k, (e, t) in rep.items()})
 
 
+def test_g17_reference_loop_protocol_drives_the_product_objects(golden_dir):
+    """Boundary: the reference's own driver loop — train_one_epoch, tools/train_utils/train_utils.py:9-61, whose call
+    sequence fixture G17 records and train_fixture_cases.drive_like_g17 reproduces call for call (CPU test) — handed the PRODUCT's
+    plugin objects: model_fn_decorator() (4-tuple), FusedAdamOneCycle (`.lr`, zero_grad, step; gradients clipped from OUTSIDE by
+    torch's clip_grad_norm_(model.parameters()) as the reference does, not by the optimiser's device-side clip) and OneCycle.
+    Three iterations on the hvpr_car detector, against three optim.train_step iterations from the same state:
+      * clip inactive (GRAD_NORM_CLIP 1e9, both paths multiply by exactly 1): after ONE iteration every parameter outside the point
+        stream is bit-identical (the point stream's backward uses float atomics);
+      * the yaml's GRAD_NORM_CLIP 10 (active: the two paths form the total norm in different orders, so the coefficient may differ in
+        the last bit): first loss bit-identical, all three losses 1e-5, parameter updates norm-wise within 2e-3 of each other."""
+    import copy
+
+    import numpy as np
+    import torch
+
+    from hvpr_amd import detector, optim, synthetic_weights
+    from hvpr_amd.config import hvpr_car_cfg
+    from test_gpu_train import _train_batch
+
+    cfg = hvpr_car_cfg()
+    base = detector.build_network(cfg.MODEL, 1, detector.SyntheticDataset(cfg, training=True))
+    synthetic_weights.load_synthetic(base, seed=17, cls_bias=-4.595)
+    base = base.to(DEV).train()
+    rng = np.random.default_rng(17)
+    loader = [_train_batch([300 + 2 * i, 301 + 2 * i], rng) for i in range(3)]
+
+    class Bar:
+        shown = []
+
+        def set_postfix(self, d):
+            self.shown.append(dict(d))
+
+        def refresh(self):
+            pass
+
+    def run(clip_at, n_iter, protocol):
+        m = copy.deepcopy(base)
+        before = {k: v.detach().clone() for k, v in m.named_parameters()}
+        ocfg = copy.deepcopy(cfg.OPTIMIZATION)
+        opt = optim.build_optimizer(m, ocfg)
+        assert isinstance(opt, optim.FusedAdamOneCycle)
+        sched, _ = optim.build_scheduler(opt, total_iters_each_epoch=10, total_epochs=1, last_epoch=-1, optim_cfg=ocfg)
+        if protocol:
+            it, items, losses = C.drive_like_g17(m, opt, [dict(b) for b in loader[:n_iter]], optim.model_fn_decorator(), sched, 0, clip_at, Bar())
+            assert it == n_iter and items is m.map_to_bev_module.memory.weight
+        else:
+            losses = [float(optim.train_step(m, opt, sched, dict(b), i, clip_at)[0]) for i, b in enumerate(loader[:n_iter])]
+        assert m.global_step == n_iter
+        return losses, before, {k: v.detach().clone() for k, v in m.named_parameters()}
+
+    # clip inactive: one iteration, bit for bit outside the point stream
+    la, _, pa = run(1e9, 1, True)
+    lb, _, pb = run(1e9, 1, False)
+    assert la == lb
+    same = [k for k in pa if "backbone_3d" not in k]
+    assert len(same) > 50
+    for k in same:
+        assert torch.equal(pa[k], pb[k]), k
+    # the yaml's clip: three iterations
+    Bar.shown.clear()
+    la, before, pa = run(cfg.OPTIMIZATION.GRAD_NORM_CLIP, 3, True)
+    lb, _, pb = run(cfg.OPTIMIZATION.GRAD_NORM_CLIP, 3, False)
+    assert la[0] == lb[0]
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    errs = []
+    for k in pa:
+        upd = pb[k] - before[k]
+        if float(upd.norm()) > 0:
+            errs.append(float((pa[k] - pb[k]).norm() / upd.norm()))
+    print(f"G17 protocol vs train_step, 3 iterations: losses {la} vs {lb}; update difference median {np.median(errs):.2e} max {max(errs):.2e}")
+    assert np.median(errs) <= 2e-3
+    # what the loop showed in the progress bar: plain numbers only (loss, lr) — no tensors (train_utils.py:45-51)
+    assert len(Bar.shown) == 3
+    for d in Bar.shown:
+        assert set(d) == {"loss", "lr"} and all(isinstance(v, float) for v in d.values()), d
+
+
 def _g4_train_setup(golden_dir, tag):
     import numpy as np
     import torch

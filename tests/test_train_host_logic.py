@@ -38,6 +38,31 @@ def test_g16_torch_forms_fp32(golden_dir):
     C.run_g16(golden_dir, "cpu", torch.float32, value_rtol=1e-5, grad_tol=1e-5)
 
 
+def test_g17_driver_loop_makes_the_reference_loops_calls(golden_dir):
+    """The loop the GPU test drives the product's plugin objects with (train_fixture_cases.drive_like_g17) is call for call the
+    reference's train_one_epoch (fixture G17, recorded from tools/train_utils/train_utils.py:9-61 itself)."""
+    C.run_g17_protocol(golden_dir)
+
+
+def test_model_func_keeps_tensors_out_of_the_progress_bar():
+    """train_utils.py:45-51 hands disp_dict to tqdm's set_postfix: model_fn_decorator must return the memory items as the FOURTH
+    value (train_utils.py:38, printed per epoch :100-101) and keep them out of disp_dict."""
+    import torch
+    from hvpr_amd import optim
+
+    class M(torch.nn.Module):
+        global_step = 0
+
+        def update_global_step(self):
+            self.global_step += 1
+
+        def forward(self, batch_dict):
+            return {"loss": torch.ones(2)}, {"rpn_loss": torch.tensor(1.0)}, {"items": torch.zeros(2000, 64)}
+    m = M()
+    loss, tb, disp, items = optim.model_fn_decorator()(m, {})
+    assert loss.item() == 1.0 and items.shape == (2000, 64) and disp == {} and m.global_step == 1
+
+
 def test_training_modules_refuse_cpu_tensors():
     """The product path has no CPU fallback: get_score / the memory training branch / the backbone, head and VFE training forwards
     raise on CPU tensors; the torch forms the fixtures above run through live in tests/torch_forms.py."""

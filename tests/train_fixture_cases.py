@@ -218,3 +218,38 @@ def run_g16(golden_dir, dev="cpu", dtype=torch.float32, value_rtol=1e-5, grad_to
         report["total." + key] = (e, tol)
         assert e < tol, (key, e, tol)
     return report
+
+
+def drive_like_g17(model, optimizer, loader, model_func, lr_scheduler, accumulated_iter, grad_norm_clip, tbar, clip=None):
+    """A driver loop that makes the calls fixture G17 records from the reference's train_one_epoch (tools/train_utils/train_utils.py:
+    25-52), in that order, one iteration per batch of `loader`: scheduler, a read of optimizer.lr, model.train(), zero_grad,
+    model_func -> 4-tuple, backward, the EXTERNAL clip over model.parameters(), optimizer.step(), then the progress-bar update with
+    disp_dict + loss + lr.  Returns (accumulated_iter, items of the last iteration, [loss per iteration])."""
+    clip = clip or torch.nn.utils.clip_grad_norm_
+    items, losses = None, []
+    for batch in loader:
+        lr_scheduler.step(accumulated_iter)
+        shown_lr = float(optimizer.lr)
+        model.train()
+        optimizer.zero_grad()
+        loss, tb_dict, disp_dict, items = model_func(model, batch)
+        loss.backward()
+        clip(model.parameters(), grad_norm_clip)
+        optimizer.step()
+        accumulated_iter += 1
+        disp_dict.update(loss=loss.item(), lr=shown_lr)
+        tbar.set_postfix(disp_dict)
+        tbar.refresh()
+        losses.append(float(disp_dict["loss"]))
+    return accumulated_iter, items, losses
+
+
+def run_g17_protocol(golden_dir):
+    """drive_like_g17 on the recording stand-ins of make_golden.g17_stubs makes exactly the calls the reference's loop made."""
+    from make_golden import g17_stubs
+    z = _load(golden_dir, "g17_train_loop_protocol.npz")
+    log = []
+    model, opt, sched, bar, model_func, clip, items, loader = g17_stubs(log)
+    it, got_items, _ = drive_like_g17(model, opt, loader, model_func, sched, int(z["start_iter"]), int(z["grad_norm_clip"]), bar, clip)
+    assert log == [str(c) for c in z["calls"]], "\n".join(f"{a!s:60s} | {b!s}" for a, b in zip(log, z["calls"]))
+    assert it == int(z["returned_iter"]) and got_items is items
