@@ -806,7 +806,7 @@ def main():
                                                                      "unit": "frames/s", "ms_per_frame": round(1e3 * dt_single / args.steps, 4)},
         "stage_ms": {"voxelize+vfe+memory+scatter": round(float(stage[0]), 4), "backbone+head+decode": round(float(stage[1]), 4),
                      "topk+nms": round(float(stage[2]), 4)},
-        "roofline": {"kernel": "VFE+scatter group = hvpr_encode_fwd_f32: K1 keys, K2 rank scan, K3 arena fill, gather + pillar VFE + canvas clear, memory read-out (+ canvas cells): 5 launches",
+        "roofline": {"kernel": "VFE+scatter group = hvpr_encode_fwd_f32 (index_mode 1): k_index (cell keys, rank scan, arena fill as the phases of one launch), k_vfe_gather (voxel gather + pillar VFE + canvas clear), k_memory_readout (+ canvas cells): 3 launches (5 with index_mode 0 or beyond 32 768 points)",
                      "bound": "hbm", "achieved": round(group_bytes_ / group_s / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(group_bytes_ / group_s / 1e9 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": group_bytes_,
                      "avg_duration_us": round(group_s * 1e6, 2),

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 5          # hvpr_abi_version() of the library these wrappers were written against (csrc/abi.hip)
+ABI_VERSION = 6          # hvpr_abi_version() of the library these wrappers were written against (csrc/abi.hip)
 LIB_PATH = os.environ.get("HVPR_AMD_LIB", os.path.join(_HERE, "libhvpr_amd.so"))   # override: kernel experiments only
 
 _c = ctypes
@@ -23,6 +23,7 @@ SIGNATURES = {
     "hvpr_set_batchnorm_allreduce": (None, [_P, _P]),
     "hvpr_voxelize_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "hvpr_voxelize_workspace_reset": (_I, [_P, _Z, _I, _I, _I, _I, _I, _P]),
+    "hvpr_voxelize_workspace_status": (_I, [_P, _Z, _I, _I, _I, _I, _I, _P]),
     "hvpr_voxelize_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I,
                                _P, _P, _P, _P, _I, _P, _Z, _I, _I, _P]),
     "hvpr_pillar_vfe_fwd_f32": (_I, [_P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -34,7 +35,7 @@ SIGNATURES = {
     "hvpr_memory_scatter_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "hvpr_encode_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _F, _F, _F, _F, _F, _I, _I, _I, _I, _I, _I, _F, _F, _F,
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P,
-                                 _P, _P, _Z, _I, _I, _P]),
+                                 _P, _P, _Z, _I, _I, _I, _P]),
     "hvpr_scatter_bev_fwd_f32": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "hvpr_spatial_gate_f32": (_I, [_P, _I, _I, _I, _I, _P, _F, _F, _F, _P, _P]),
     "hvpr_head_decode_f32": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P]),

@@ -6,8 +6,9 @@
 // by 64) and the voxelizer workspace holds the one-launch index kernel's per-cell words and barrier flags (hvpr_voxelize_workspace_bytes
 // grew) — a caller that sized either buffer with a version-3 formula is too small: always size them with the two functions; 5: adds
 // hvpr_bn_train_affine_f32 and hvpr_bn_relu_fwd / bwd_slice_nhwc_f32; hvpr_conv2d_wino_wgrad_nhwc_f32 answers HVPR_ERR_UNSUPPORTED for images of 2 GB and more (32-bit offsets
-// inside an image; its workspace size is unchanged)
-extern "C" int hvpr_abi_version(void) { return 5; }
+// inside an image; its workspace size is unchanged); 6: hvpr_encode_fwd_f32 takes index_mode (the one-launch index kernel is opt-in and guarded),
+// hvpr_voxelize_workspace_status, HVPR_ERR_TIMEOUT
+extern "C" int hvpr_abi_version(void) { return 6; }
 
 extern "C" const char *hvpr_status_string(int status) {
     switch (status) {
@@ -16,6 +17,7 @@ extern "C" const char *hvpr_status_string(int status) {
         case HVPR_ERR_UNSUPPORTED: return "unsupported shape for this build of the kernels";
         case HVPR_ERR_WORKSPACE: return "workspace too small";
         case HVPR_ERR_LAUNCH: return "HIP launch failed";
+        case HVPR_ERR_TIMEOUT: return "a one-launch index kernel gave up a wait: reset the voxelizer workspace";
         default: return "unknown status";
     }
 }

@@ -161,7 +161,7 @@ struct WarmSmall { const float *p[8]; int n[8]; };
 HVPR_INTERNAL int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode,
                                      hipStream_t s, const float *vfe_w1 = nullptr, const float *vfe_b0 = nullptr,
                                      const void *warm0 = nullptr, size_t warm0_bytes = 0, const void *warm1 = nullptr, size_t warm1_bytes = 0,
-                                     const WarmSmall *warm_small = nullptr);
+                                     const WarmSmall *warm_small = nullptr, int index_mode = 0);
 // K4 fused into the pillar VFE: selects each voxel's points straight from the arena, writes voxels (optional) / coords /
 // num_points, the pillar and scale features and the pillar + scale cells of the NHWC canvases; extra workgroups of the same
 // launch clear every canvas cell that belongs to no pillar and return cell_first to idle (pair with for_encode above).

@@ -14,6 +14,8 @@
 //   K4 one wave per voxel: bitonic selection of the max_points smallest indices (ascending), gather.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "internal.h"
 
@@ -231,6 +233,28 @@ constexpr int kWarmParts = 32;   // L2 warmers per XCD (below)
 // Differences from the three kernels, none visible outside: the arena slot of a point is handed out in phase 1 (returning
 // atomicAdd: arrival order) instead of phase 3, phase 2 returns the count map to idle, pt_cell is not written.
 constexpr int kFusedMaxOwners = 32;   // one workgroup per CU of ONE XCD: all owners resident whatever else runs (they spin on each other)
+// Every wait of the one-launch kernel is BOUNDED: an owner that has waited kSpinLimitTicks of the constant 100 MHz clock
+// (s_memrealtime) — two seconds; a wait that is going to end ends within the run time of whatever else occupies the compute units
+// — or that sees the workspace's error word raised stops waiting, raises the (sticky) error word sync[4] and leaves through the
+// normal exit protocol, which returns the barrier words to idle.  The launch then reports ZERO pillars (voxel_offsets all 0), and so
+// does every later one-launch call on this workspace until hvpr_voxelize_workspace_reset: a launch that could not complete never
+// hangs the device and never hands out partial results (hvpr_voxelize_workspace_status reads the word).
+constexpr long long kSpinLimitTicks = 200000000ll;
+constexpr int kSyncExit = 3, kSyncError = 4;
+
+struct SpinWatch {
+    long long t0;
+    unsigned polls;
+    int *err;
+    __device__ __forceinline__ SpinWatch(int *error_word) : t0(0), polls(0), err(error_word) {}
+    // true when this wait has to be given up; looks at the clock / the error word every 256 polls only
+    __device__ __forceinline__ bool give_up() {
+        if ((++polls & 255u) != 0u) return false;
+        const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) t0 = now;
+        return now - t0 > kSpinLimitTicks || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    }
+};
 
 template <typename V>
 __device__ __forceinline__ void xstore(V *p, V v, bool local) {
@@ -315,7 +339,7 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
     if (blockIdx.x & 7) return;
     __shared__ unsigned s_wave_a[T / 64], s_wave_b[T / 64];
     __shared__ unsigned s_excl_a, s_excl_b;
-    __shared__ int s_local;
+    __shared__ int s_local, s_abort;
     const int tile = blockIdx.x >> 3, i = tile * T + (int)threadIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #ifdef HVPR_EXP_TIMING
@@ -325,7 +349,13 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
 #define IDX_STAMP(k)
 #endif
     IDX_STAMP(0);
-    unsigned long long *const census = reinterpret_cast<unsigned long long *>(w.sync);   // sync[0..1]; sync[3]: exits; sync[8..71]: barrier 2's flags
+    unsigned long long *const census = reinterpret_cast<unsigned long long *>(w.sync);   // sync[0..1]; sync[3]: exits; sync[4]: error; sync[8..71]: barrier 2's flags
+    int *const err_word = w.sync + kSyncError;
+    // a workspace whose error word is up (an earlier launch gave up a wait) is not touched: zero pillars until it is reset.  The word
+    // was written before this launch started (stream order), so every owner reads the same value and none waits for another.
+    // (requested here, looked at after the point has been loaded: the two round trips run side by side)
+    const int poisoned = __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_abort = 0;
 
     // ---- phase 1: cell key, first index and count of the cell; the point's arena slot = its arrival number in the cell
     if (threadIdx.x == 0) __hip_atomic_store(&w.tile_state[tile], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -341,6 +371,10 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
         if (cx >= 0.f && cx < (float)nx && cy >= 0.f && cy < (float)ny && cz >= 0.f && cz < (float)nz) {
             g = ((b * nz + (int)cz) * ny + (int)cy) * nx + (int)cx;
         }
+    }
+    if (poisoned != 0) {
+        if (tile == 0 && (int)threadIdx.x <= batch) voxel_offsets[threadIdx.x] = 0;
+        return;
     }
     {
         int head, len;
@@ -370,7 +404,9 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
         __builtin_amdgcn_s_sleep(4);
         unsigned long long c2 = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long c = c0;
+        SpinWatch watch(err_word);
         while (byte_sum(c) < (unsigned)point_blocks) {
+            if (watch.give_up()) { s_abort = 1; break; }
             c = c1; c1 = c2;
             __builtin_amdgcn_s_sleep(4);
             c2 = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -380,6 +416,9 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
     __syncthreads();
     const bool local = s_local != 0;       // the same answer in every owner: they all read the same final census
     IDX_STAMP(4);
+    bool done_ok = false;
+    do {       // (left with `break` when a wait was given up: straight to the exit protocol)
+    if (s_abort) break;
 
     // ---- phase 2: (is-first, count) scanned over the points -> voxel rank, arena offset
     unsigned fl = 0, ct = 0;
@@ -399,15 +438,20 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
     }
     if (wid == 0) {     // decoupled look-back as in k2_scan; all tiles are resident, tile order = owner order
         unsigned ea = 0, eb = 0;
+        bool lb_ok = true;
         if (lane == 0) xstore(&w.tile_state[tile], pack(tile == 0 ? 2u : 1u, tot_a, tot_b), local);
         for (int hi = tile - 1; hi >= 0; hi -= 64) {
             const int t = hi - lane;
             unsigned long long st = 0ull;
+            SpinWatch watch(err_word);
+            bool gave_up = false;
             for (;;) {
                 if (t >= 0 && (st >> 62) == 0) st = xload(&w.tile_state[t]);
                 if (__ballot(t >= 0 && (st >> 62) == 0) == 0ull) break;
+                if (__ballot(watch.give_up()) != 0ull) { gave_up = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
+            if (gave_up) { if (lane == 0) s_abort = 1; lb_ok = false; break; }
             const unsigned long long incl = __ballot(t >= 0 && (st >> 62) == 2);
             const int stop = incl ? __ffsll((long long)incl) - 1 : 63;
             unsigned pa = (t >= 0 && lane <= stop) ? (unsigned)((st >> 31) & 0x7fffffffu) : 0u;
@@ -417,12 +461,13 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
             ea += pa; eb += pb;
             if (incl) break;
         }
-        if (lane == 0) {
+        if (lane == 0 && lb_ok) {
             if (tile != 0) xstore(&w.tile_state[tile], pack(2u, ea + tot_a, eb + tot_b), local);
             s_excl_a = ea; s_excl_b = eb;
         }
     }
     __syncthreads();
+    if (s_abort) break;
     const unsigned ra = s_excl_a + wa + (ia - fl), rb = s_excl_b + wb + (ib - ct);   // exclusive prefixes of this point
     IDX_STAMP(6);
     if (i < n) {
@@ -448,9 +493,14 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
     if (wid == 0) {
         int *const flags = w.sync + 8;
         if (lane == 0) xstore(&flags[tile], 1, local);
-        while (__ballot(lane < point_blocks && xload(&flags[lane]) == 0) != 0ull) __builtin_amdgcn_s_sleep(1);
+        SpinWatch watch(err_word);
+        while (__ballot(lane < point_blocks && xload(&flags[lane]) == 0) != 0ull) {
+            if (__ballot(watch.give_up()) != 0ull) { if (lane == 0) s_abort = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
     }
     __syncthreads();
+    if (s_abort) break;
 
     IDX_STAMP(8);
     // ---- phase 3: every point files its record and itself at its arena position
@@ -472,6 +522,12 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
         w.arena_rec[pos] = make_int4(i, kept ? r : -1, cnt, g);
         if (kept) w.arena_pt[pos] = pt;
     }
+    done_ok = true;
+    } while (false);
+    if (!done_ok) {     // a wait was given up (here or in another owner): sticky error word, zero pillars
+        if (threadIdx.x == 0) __hip_atomic_store(err_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile == 0 && (int)threadIdx.x <= batch) voxel_offsets[threadIdx.x] = 0;
+    }
     IDX_STAMP(9);
 #ifdef HVPR_EXP_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -483,9 +539,10 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
 #endif
     // the last owner out returns the counters to idle (nobody is behind it: all have passed both barriers); device scope, so that
     // the next launch finds them whatever its placement
-    if (threadIdx.x == 0 && __hip_atomic_fetch_add(&w.sync[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == point_blocks - 1) {
+    // (an owner that gave up a wait comes through here as well: the words are idle again after ANY launch whose owners all ran)
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(&w.sync[kSyncExit], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == point_blocks - 1) {
         __hip_atomic_store(census, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&w.sync[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&w.sync[kSyncExit], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int t = 0; t < point_blocks; ++t) __hip_atomic_store(&w.sync[8 + t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -626,15 +683,58 @@ __global__ void __launch_bounds__(256) k4_gather(const float *__restrict__ pts, 
 
 }  // namespace
 
+// The one-launch index kernel's owners wait for each other on the compute units they occupy, so two such launches in flight at once
+// could each hold units the other's owners still need.  The library therefore takes the one-launch form only when it can tell that
+// no other one-launch kernel of this process is in flight on the device: the previous one went to the SAME stream (stream order
+// serialises them), or its completion event has fired.  Otherwise the three-launch form runs (same results, no waiting between
+// workgroups other than the scan's look-back).  One record per device, behind a mutex; it only ever selects between two
+// equivalent launch forms.  Inside a stream capture there is nothing to ask (the event would become part of the graph and the
+// decision is taken once for every replay): a capturing caller that passes index_mode 1 takes on the rule itself — replay such
+// graphs one at a time per device (the detector's frame pipeline has one encode lane).
+namespace {
+struct FusedInFlight { hipEvent_t done = nullptr; hipStream_t stream = nullptr; bool valid = false; };
+std::mutex g_fused_mutex;
+FusedInFlight g_fused[64];
+
+// 1: take the one-launch form (and, outside capture, `note_fused_launch` must follow the launch); 0: take the three launches
+int fused_allowed(hipStream_t s, bool *capturing) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    *capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (*capturing) return 1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    FusedInFlight &f = g_fused[dev];
+    if (!f.valid || f.stream == s) return 1;
+    return hipEventQuery(f.done) == hipSuccess ? 1 : 0;
+}
+
+void note_fused_launch(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    FusedInFlight &f = g_fused[dev];
+    if (!f.done && hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess) { f.done = nullptr; f.valid = false; return; }
+    f.valid = hipEventRecord(f.done, s) == hipSuccess;
+    f.stream = s;
+}
+}  // namespace
+
 int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_offsets, bool for_encode, hipStream_t s,
                        const float *vfe_w1, const float *vfe_b0, const void *warm0, size_t warm0_bytes, const void *warm1,
-                       size_t warm1_bytes, const WarmSmall *warm_small) {
+                       size_t warm1_bytes, const WarmSmall *warm_small, int index_mode) {
     if (for_encode && a.n_feat != 4) return HVPR_ERR_UNSUPPORTED;
-    // kernel experiments / tests only: HVPR_INDEX_FUSED=0 keeps the three launches, HVPR_INDEX_AGENT=1 makes the one-launch form take
-    // its placement-independent path (device-scope hand-offs) although its owners share an XCD
-    static const int fused = [] { const char *e = getenv("HVPR_INDEX_FUSED"); return e ? atoi(e) : 1; }();
+    // kernel experiments only: HVPR_INDEX_FUSED=0 / 1 overrides the caller's index_mode, HVPR_INDEX_AGENT=1 makes the one-launch form
+    // take its placement-independent path (device-scope hand-offs) although its owners share an XCD
+    static const int env_fused = [] { const char *e = getenv("HVPR_INDEX_FUSED"); return e ? atoi(e) : -1; }();
     static const int force_agent = [] { const char *e = getenv("HVPR_INDEX_AGENT"); return e ? atoi(e) : 0; }();
-    if (for_encode && fused && a.n_points <= kFusedMaxOwners * 1024) {
+    bool fused = for_encode && (env_fused >= 0 ? env_fused != 0 : index_mode == 1) && a.n_points <= kFusedMaxOwners * 1024;
+    bool capturing = false;
+    std::unique_lock<std::mutex> guard(g_fused_mutex, std::defer_lock);
+    if (fused) {
+        guard.lock();                      // held until the launch is noted: two host threads cannot both see "nothing in flight"
+        fused = fused_allowed(s, &capturing) != 0;
+        if (!fused) guard.unlock();
+    }
+    if (fused) {
         // one launch: the owners of the point tiles (every 8th of the first 8 x tiles blocks), the padded-slot workgroup, the
         // warmers.  512 points per owner up to 16 384 points (32 owners: in-frame 16.3 us against 17.8 with 1024), 1024 beyond
         const int T = a.n_points <= kFusedMaxOwners * 512 ? 512 : 1024;
@@ -650,6 +750,7 @@ int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_off
         };
         if (T == 1024) launch(k_index<1024>);
         else launch(k_index<512>);
+        if (!capturing) note_fused_launch(s);
         HVPR_CHECK_LAUNCH();
         return HVPR_OK;
     }
@@ -692,6 +793,18 @@ extern "C" int hvpr_voxelize_workspace_reset(void *workspace, size_t workspace_b
     hipLaunchKernelGGL(k_reset, dim3(1024), dim3(256), 0, (hipStream_t)stream, w.cell_first, w.cell_count, batch * ncell, w.sync);
     HVPR_CHECK_LAUNCH();
     return HVPR_OK;
+}
+
+extern "C" int hvpr_voxelize_workspace_status(const void *workspace, size_t workspace_bytes, int batch, int n_points, int nx, int ny,
+                                              int nz, hvpr_stream_t stream) {
+    if (!workspace || batch < 1 || n_points < 0 || nx < 1 || ny < 1 || nz < 1) return HVPR_ERR_INVALID_ARG;
+    const long long ncell = (long long)nx * ny * nz;
+    if (workspace_bytes < hvpr_vox_ws_bytes(batch, n_points > 0 ? n_points : 1, ncell)) return HVPR_ERR_WORKSPACE;
+    const VoxWs w = hvpr_vox_carve(const_cast<void *>(workspace), batch, n_points > 0 ? n_points : 1, ncell);
+    int word = 0;
+    if (hipMemcpyAsync(&word, w.sync + kSyncError, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return HVPR_ERR_LAUNCH;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return HVPR_ERR_LAUNCH;
+    return word == 0 ? HVPR_OK : HVPR_ERR_TIMEOUT;
 }
 
 extern "C" int hvpr_voxelize_f32(const float *points, int n_points, int point_stride, int xyz_col, int n_feat,

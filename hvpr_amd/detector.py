@@ -342,6 +342,7 @@ class MixAnchor_Memory(_VoxelizingDetector):
         # loader / VFE leave in batch_dict (nothing downstream reads them: data_processor.py:43-75 -> pillar_vfe.py:184-221 are
         # one entry point here).  Set to True to have hvpr_encode_fwd_f32 materialise them as well (tests do).
         self.export_voxels = bool(model_cfg.get("EXPORT_VOXELS", False))
+        self.index_mode = int(model_cfg.get("ENCODE_INDEX_MODE", 1))      # hvpr_encode_fwd_f32's index_mode (see encode_fused)
 
     def get_training_loss(self):
         """detectors/pointpillar.py:59-68 with the arity decision of SURVEY.md T2: loss = rpn + rpn_point + mem."""
@@ -365,8 +366,10 @@ class MixAnchor_Memory(_VoxelizingDetector):
                 int(self._voxel_cfg().MAX_POINTS_PER_VOXEL) <= 32 and m.memory.weight.shape[0] <= 2048 and m.k <= 32)
 
     def encode_fused(self, batch_dict):
-        """a1-a4 through hvpr_encode_fwd_f32 (five launches): fills every batch_dict key the module chain
-        voxelize_on_device -> vfe -> map_to_bev_module would."""
+        """a1-a4 through hvpr_encode_fwd_f32: fills every batch_dict key the module chain voxelize_on_device -> vfe ->
+        map_to_bev_module would.  The detector has ONE encode lane per device (the eager forward on the current stream; one encode
+        per step of the frame pipeline), which is what index_mode 1 asks of its caller (include/hvpr_amd.h): three launches
+        instead of five.  `self.index_mode = 0` switches to the form that is safe under any concurrency."""
         pts, B = batch_dict["points"].contiguous(), batch_dict["batch_size"]
         vg = self._voxel_generator(pts.device)
         m = self.map_to_bev_module
@@ -374,7 +377,8 @@ class MixAnchor_Memory(_VoxelizingDetector):
                                vg.max_num_points, vg.max_voxels, vg._workspace(B, pts.shape[0]),
                                self.vfe._fold.get(pts.device, self.vfe._build_folded), self.vfe.offsets,
                                m.memory.packed_bank(), m.k, xyz_col=1, cap_mode=vg.cap_mode, want_voxels=self.export_voxels,
-                               want_mask=self.export_voxels, out=batch_dict.get("_out_spatial"), state=batch_dict.get("_canvas_state"))
+                               want_mask=self.export_voxels, out=batch_dict.get("_out_spatial"), state=batch_dict.get("_canvas_state"),
+                               index_mode=self.index_mode)
         vo = r["voxel_offsets"]
         batch_dict.update(voxels=r["voxels"], voxel_coords=r["coords"], voxel_num_points=r["num_points"], voxel_offsets=vo,
                           voxel_count_device=vo[B:B + 1], pillar_features=r["pillar_features"],
@@ -453,7 +457,12 @@ class MixAnchor_Memory(_VoxelizingDetector):
             if m is getattr(self, "backbone_3d", None) or (fused and (m is self.vfe or m is self.map_to_bev_module)):
                 continue
             batch_dict = m(batch_dict)
-        return self.post_processing(batch_dict, sync=sync)
+        out = self.post_processing(batch_dict, sync=sync)
+        if fused and sync and self.index_mode == 1:
+            # the results have just been read back (host sync): also look at the voxelizer workspace's error word — a one-launch
+            # index kernel that had to give up a wait reported zero pillars; say so instead of returning an empty frame
+            self._voxel_generator(batch_dict["points"].device)._ws.status()
+        return out
 
 
 class _CapturedState:

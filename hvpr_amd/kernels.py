@@ -43,6 +43,13 @@ class VoxelizeWorkspace:
         check(lib().hvpr_voxelize_workspace_reset(self.buf.data_ptr(), self.buf.numel(), batch, n_points, nx, ny, nz,
                                                   _stream()), "hvpr_voxelize_workspace_reset")
 
+    def status(self):
+        """SYNCHRONISES the current stream; raises when a one-launch index kernel (encode_fwd(index_mode=1)) gave up a wait on this
+        workspace since its last reset (that call and every later one reported zero pillars): reset() it."""
+        batch, n_points, (nx, ny, nz), _ = self.key
+        check(lib().hvpr_voxelize_workspace_status(self.buf.data_ptr(), self.buf.numel(), batch, n_points, nx, ny, nz,
+                                                   _stream()), "hvpr_voxelize_workspace_status")
+
 
 def voxelize(points, frame_offsets, batch, point_cloud_range, voxel_size, grid, max_points, max_voxels, workspace,
              xyz_col=0, n_feat=None, cap_mode=0, capacity=None):
@@ -341,8 +348,10 @@ def frame_offsets(points, batch):
 
 
 def encode_fwd(points, frame_offsets, batch, point_cloud_range, voxel_size, grid, max_points, max_voxels, workspace, folded,
-               offsets, bank, k, xyz_col=0, cap_mode=0, capacity=None, want_voxels=True, want_mask=True, out=None, state=None):
-    """a1..a4 fused (hvpr_encode_fwd_f32): raw points -> canvases in five launches, bit-identical to voxelize ->
+               offsets, bank, k, xyz_col=0, cap_mode=0, capacity=None, want_voxels=True, want_mask=True, out=None, state=None,
+               index_mode=0):
+    """a1..a4 fused (hvpr_encode_fwd_f32): raw points -> canvases in five launches (three with index_mode=1: the index phase as ONE
+    launch, for a caller with a single encode lane per device — include/hvpr_amd.h), bit-identical to voxelize ->
     pillar_vfe_fwd -> memory_scatter_fwd.  Returns a dict with voxels|None, coords, num_points, voxel_offsets,
     pillar_features, pillar_scale_features, pillar_mask|None, memory_features, spatial (B,128,ny,nx), spatial_scale
     (B,32,ny,nx) (channels_last).  `out` = (spatial, spatial_scale) of an earlier call: write into those canvases.
@@ -386,7 +395,7 @@ def encode_fwd(points, frame_offsets, batch, point_cloud_range, voxel_size, grid
         _ptr(folded["b1"], torch.float32), _ptr(folded["ws0"], torch.float32), _ptr(folded["bs0"], torch.float32),
         _ptr(folded["ws1"], torch.float32), _ptr(folded["bs1"], torch.float32), *_bank_args(bank), int(k), _ptr(voxels), coords.data_ptr(), num.data_ptr(), offs.data_ptr(), capacity, pf.data_ptr(),
         sf.data_ptr(), _ptr(mask), mem.data_ptr(), spatial.data_ptr(), spatial_scale.data_ptr(), _ptr(state), workspace.buf.data_ptr(),
-        workspace.buf.numel(), workspace.key[0], workspace.key[1], _stream()), "hvpr_encode_fwd_f32")
+        workspace.buf.numel(), workspace.key[0], workspace.key[1], int(index_mode), _stream()), "hvpr_encode_fwd_f32")
     return {"voxels": voxels, "coords": coords, "num_points": num, "voxel_offsets": offs, "pillar_features": pf,
             "pillar_scale_features": sf, "pillar_mask": mask, "memory_features": mem,
             "spatial": spatial.permute(0, 3, 1, 2), "spatial_scale": spatial_scale.permute(0, 3, 1, 2)}

@@ -31,7 +31,8 @@ enum hvpr_status {
     HVPR_ERR_INVALID_ARG = -1,   /* null pointer, negative size, inconsistent dims            */
     HVPR_ERR_UNSUPPORTED = -2,   /* a shape the kernels are not built for (documented per op) */
     HVPR_ERR_WORKSPACE = -3,     /* workspace too small                                        */
-    HVPR_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after the launch           */
+    HVPR_ERR_LAUNCH = -4,        /* hipGetLastError() != hipSuccess after the launch           */
+    HVPR_ERR_TIMEOUT = -5        /* hvpr_voxelize_workspace_status: a one-launch index kernel gave up a wait (workspace needs a reset) */
 };
 
 int hvpr_abi_version(void);     /* 5 (history: csrc/abi.hip); size every workspace / packed buffer with the *_bytes / *_floats functions */
@@ -74,6 +75,12 @@ size_t hvpr_voxelize_workspace_bytes(int max_batch, int max_points, int nx, int 
  * each call returns it to idle. */
 int hvpr_voxelize_workspace_reset(void *workspace, size_t workspace_bytes, int max_batch, int max_points, int nx, int ny,
                                   int nz, hvpr_stream_t stream);
+/* SYNCHRONISES `stream` and reads the workspace's error word (dimensions as it was sized with): HVPR_OK, or HVPR_ERR_TIMEOUT when a
+ * one-launch index kernel (hvpr_encode_fwd_f32, index_mode 1) gave up a wait since the last reset — that call and every later
+ * mode-1 call on this workspace reported zero pillars; reset the workspace before using it again.  Call it where the caller
+ * synchronises anyway (the detector does when it reads its results back). */
+int hvpr_voxelize_workspace_status(const void *workspace, size_t workspace_bytes, int max_batch, int max_points, int nx, int ny,
+                                   int nz, hvpr_stream_t stream);
 int hvpr_voxelize_f32(const float *points, int n_points, int point_stride, int xyz_col, int n_feat,
                       const int32_t *frame_offsets, int batch, float lo_x, float lo_y, float lo_z, float vs_x,
                       float vs_y, float vs_z, int nx, int ny, int nz, int max_points, int max_voxels, int cap_mode,
@@ -164,7 +171,7 @@ int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale
                                 float *memory_features, float *spatial, float *spatial_scale, void *workspace,
                                 size_t workspace_bytes, hvpr_stream_t stream);
 
-/* a1..a4 fused — points to BEV canvases in three launches (five beyond 32 768 points), the form the detector's eval forward uses when it is handed raw
+/* a1..a4 fused — points to BEV canvases in five launches (three with index_mode 1), the form the detector's eval forward uses when it is handed raw
  *     points.  Same results, bit for bit, as hvpr_voxelize_f32 -> hvpr_pillar_vfe_fwd_f32 -> hvpr_memory_scatter_fwd_f32
  *     (data_processor.py:43-75, pillar_vfe.py:184-221, memory_module.py:60-77, pointpillar_scatter.py:169-222) with
  *       - the voxel gather fused into the VFE (the padded `voxels` tensor becomes an optional OUTPUT, may be NULL),
@@ -173,11 +180,20 @@ int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale
  *     Arguments as in the three separate calls; n_feat must be 4, nz 1, max_points <= 32, channels 64 + 64 + 32.
  *     voxel_offsets[batch] is the live pillar count M (device word); rows >= M of the per-pillar outputs are unspecified.
  *     capacity below M truncates: the first `capacity` rows are written, the canvas cells of the dropped pillars stay zero.
- *     Up to 32 768 points the index phase is one launch whose (at most 32) workgroups wait for each other at two grid barriers on
- *     the compute units of one XCD.  Kernels that finish make room for them, so other work on the device only delays them — but
- *     such launches wait for EACH OTHER'S compute units when several are in flight at once: keep at most two calls of this size
- *     in flight per device (one XCD holds the workgroups of four; the detector's frame pipeline has one), or set HVPR_INDEX_FUSED=0
- *     in the environment to take the three-launch index phase, which has no such constraint (a frame's encode is ~2.6 us longer).
+ *     index_mode selects the launch form of the index phase (cell keys -> voxel ranks -> arena), same results either way:
+ *       0  three launches (K1 keys, K2 rank scan, K3 arena fill).  No workgroup waits for another one beyond the scan's look-back:
+ *          safe for any number of calls in flight on any number of streams, and for several processes sharing a GPU.  The default
+ *          every C caller should use unless it has read the next paragraph.
+ *       1  ONE launch (up to 32 768 points; beyond that mode 0 is taken) whose at most 32 owner workgroups meet at two grid
+ *          barriers on the compute units of one XCD — 2.6 us less per hvpr_car frame.  Owners that are resident wait for the ones
+ *          that are not, so two such launches in flight at once could each hold compute units the other one needs.  The library
+ *          rules that out inside a process: it takes the one-launch form only if the previous one-launch kernel on this device
+ *          went to the same stream or has completed (one event query), and falls back to the three launches otherwise.  It
+ *          cannot see other processes, and it cannot decide anything inside a stream capture (a captured call with index_mode 1
+ *          always holds the one-launch form: replay such graphs one at a time per device — the detector's frame pipeline has one
+ *          encode lane).  Every wait inside the kernel is bounded (2 s): a launch that could not complete raises a sticky error word
+ *          in the workspace, reports zero pillars (voxel_offsets all 0), leaves the barrier words idle, and so does every later
+ *          mode-1 call on that workspace until hvpr_voxelize_workspace_reset; hvpr_voxelize_workspace_status reads the word.
  *     pillar_mask may be NULL.  workspace: hvpr_voxelize_workspace_bytes / _reset, as for hvpr_voxelize_f32.
  *     Weight / bias pointers 16-byte aligned.
  *     canvas_state (may be NULL): [batch * ny * nx] bytes that travel with ONE pair of canvases the caller keeps between calls.
@@ -193,7 +209,7 @@ int hvpr_encode_fwd_f32(const float *points, int n_points, int point_stride, int
                         const float *bank_packed, int n_items, int k, float *voxels, int32_t *coords, int32_t *num_points, int32_t *voxel_offsets,
                         int capacity, float *pillar_features, float *pillar_scale_features, float *pillar_mask,
                         float *memory_features, float *spatial, float *spatial_scale, uint8_t *canvas_state, void *workspace,
-                        size_t workspace_bytes, int ws_max_batch, int ws_max_points, hvpr_stream_t stream);
+                        size_t workspace_bytes, int ws_max_batch, int ws_max_points, int index_mode, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a5/a6  BEV backbone + head convolutions: implicit GEMM on the fp32 matrix cores, NHWC.

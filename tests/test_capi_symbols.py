@@ -33,7 +33,7 @@ def test_binding_table_matches_header(built):
     assert sorted(_lib.SIGNATURES) == _declared()
     L = _lib.lib()
     from hvpr_amd import _lib
-    assert L.hvpr_abi_version() == _lib.ABI_VERSION == 5
+    assert L.hvpr_abi_version() == _lib.ABI_VERSION == 6
     assert L.hvpr_status_string(0) == b"ok"
     assert L.hvpr_status_string(-2).startswith(b"unsupported")
 

@@ -335,9 +335,11 @@ def _encode_both(frames, max_voxels, cap_mode=0, seed=40, RNG=RNG, VS=VS, GRID=G
     mem, sp, sc = kernels.memory_scatter_fwd(pf, sf, c, W, 20, B, GRID[0], GRID[1], kernels.scatter_workspace(B, GRID[0], GRID[1], DEV),
                                              m_device=md)
     outs = []
-    for _ in range(2):   # the second call proves the voxelizer workspace came back to idle and stale canvases are cleared
+    # both forms of the index phase (index_mode 1: one launch, 0: three), each twice: the second call proves the voxelizer workspace
+    # came back to idle and stale canvases are cleared
+    for index_mode in (1, 1, 0, 0):
         r = kernels.encode_fwd(tp, offs, B, RNG, VS, GRID, P, max_voxels, ws, folded, vfe_off, W, 20, xyz_col=1, cap_mode=cap_mode,
-                               out=None if not outs else (outs[0]["spatial"], outs[0]["spatial_scale"]))
+                               out=None if not outs else (outs[0]["spatial"], outs[0]["spatial_scale"]), index_mode=index_mode)
         torch.cuda.synchronize()
         outs.append(r)
         m = int(vo[B])
@@ -511,7 +513,7 @@ def test_encode_fused_index_phase_under_load_many_times():
     for f in frames:
         p = torch.from_numpy(np.concatenate([np.zeros((len(f), 1), np.float32), f], 1)).to(DEV)
         o = torch.cat([one, torch.tensor([len(f)], dtype=torch.int32, device=DEV)])
-        r = kernels.encode_fwd(p, o, 1, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1)
+        r = kernels.encode_fwd(p, o, 1, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1, index_mode=0)
         torch.cuda.synchronize()
         pts.append(p); offs.append(o); ref.append({k: v.clone() for k, v in r.items() if v is not None})
     side = torch.cuda.Stream()
@@ -525,7 +527,7 @@ def test_encode_fused_index_phase_under_load_many_times():
     bad = 0
     for it in range(stop):
         j = it & 1
-        r = kernels.encode_fwd(pts[j], offs[j], 1, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1)
+        r = kernels.encode_fwd(pts[j], offs[j], 1, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1, index_mode=1)
         m = int(ref[j]["voxel_offsets"][1])
         ok = torch.equal(r["voxel_offsets"], ref[j]["voxel_offsets"])
         for k in ("coords", "num_points", "voxels", "pillar_features", "memory_features"):
@@ -534,9 +536,88 @@ def test_encode_fused_index_phase_under_load_many_times():
         bad += 0 if ok else 1
     torch.cuda.synchronize()
     assert bad == 0, f"{bad} of {stop} encodes differ"
+    ws.status()
 
 
-@pytest.mark.parametrize("env", [{"HVPR_INDEX_FUSED": "0"}, {"HVPR_INDEX_AGENT": "1"}], ids=["three_launches", "one_launch_device_scope"])
+def _encode_lane(seed, n_pts, index_mode):
+    """Everything ONE caller of hvpr_encode_fwd_f32 owns: points, workspace, weights; and the reference result (three launches)."""
+    f = synthetic.hvpr_frame(seed, shuffle=True)[:n_pts]
+    p = torch.from_numpy(np.concatenate([np.zeros((len(f), 1), np.float32), f], 1)).to(DEV)
+    o = torch.tensor([0, len(f)], dtype=torch.int32, device=DEV)
+    folded = _folded_from(_vfe_params(seed))
+    vfe_off = [VS[0] / 2 + RNG[0], VS[1] / 2 + RNG[1], VS[2] / 2 + RNG[2]]
+    W = torch.from_numpy(np.random.default_rng(seed).uniform(-0.125, 0.125, (2000, 64)).astype(np.float32)).to(DEV)
+    ws = kernels.VoxelizeWorkspace(1, 16384, GRID, DEV)
+    call = lambda mode=index_mode: kernels.encode_fwd(p, o, 1, RNG, VS, GRID, 32, 40000, ws, folded, vfe_off, W, 20, xyz_col=1, index_mode=mode)
+    ref = {k: v.clone() for k, v in call(0).items() if v is not None}
+    torch.cuda.synchronize()
+    return call, ref, ws
+
+
+def _same(r, ref):
+    m = int(ref["voxel_offsets"][1])
+    ok = torch.equal(r["voxel_offsets"], ref["voxel_offsets"])
+    for k in ("coords", "num_points", "pillar_features", "memory_features"):
+        ok = ok and torch.equal(r[k][:m], ref[k][:m])
+    return ok and torch.equal(r["spatial"], ref["spatial"]) and torch.equal(r["spatial_scale"], ref["spatial_scale"])
+
+
+@pytest.mark.parametrize("index_mode", [0, 1])
+def test_concurrent_encode_calls_on_four_streams_complete(index_mode):
+    """the entry points are re-entrant.  Four callers, each with its own stream, workspace and buffers, keep
+    hvpr_encode_fwd_f32 calls in flight at the same time, 200 rounds, while a fifth stream keeps every compute unit busy — all of
+    them must complete and give the bits a lone call gives.  index_mode 0 has no workgroup waiting for another; with index_mode 1
+    the library takes the one-launch index kernel only when no other one is in flight on the device (same stream as the previous
+    one, or that one finished) and the three launches otherwise, so the kernel's owners never wait for compute units held by
+    another launch's owners (include/hvpr_amd.h; round 5 documented "at most two in flight" instead of enforcing it)."""
+    lanes = [_encode_lane(60 + i, 16384 - 1500 * i, index_mode) for i in range(4)]
+    streams = [torch.cuda.Stream() for _ in lanes]
+    busy = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(busy):
+        for _ in range(40):
+            torch.mm(a, a)
+    bad = 0
+    for it in range(200):
+        rs = []
+        for (call, ref, ws), st in zip(lanes, streams):
+            with torch.cuda.stream(st):
+                rs.append(call())
+        if it % 20 == 19:
+            for st in streams:
+                st.synchronize()
+            bad += sum(0 if _same(r, ref) else 1 for r, (_, ref, _) in zip(rs, lanes))
+    torch.cuda.synchronize()              # "must complete": a hang ends the test through pytest-timeout / the box's limit
+    assert bad == 0
+    for _, _, ws in lanes:
+        ws.status()
+
+
+def test_one_launch_index_kernel_refuses_a_poisoned_workspace_until_reset():
+    """Every wait of the one-launch index kernel is bounded; an owner that gives one up raises a sticky error word in the workspace,
+    the launch reports zero pillars, and so does every later one-launch call until the workspace is reset (a launch that could not
+    complete must neither hang the device nor hand out partial results).  The give-up itself needs a 2 s stall, so the word is
+    raised by hand here (the last carved field of the workspace: 72 ints in a 512-byte slot, error word = int 4)."""
+    call, ref, ws = _encode_lane(70, 12000, 1)
+    assert _same(call(), ref)
+    ws.status()
+    words = ws.buf[ws.buf.numel() - 512:].view(torch.int32)
+    assert int(words[:72].abs().sum()) == 0                   # census, exit counter, flags: idle after the calls above
+    words[4] = 1
+    r = call()
+    torch.cuda.synchronize()
+    assert int(r["voxel_offsets"].abs().sum()) == 0
+    assert float(r["spatial"].abs().sum()) == 0.0 and float(r["spatial_scale"].abs().sum()) == 0.0   # zero pillars: empty canvases
+    with pytest.raises(RuntimeError, match="gave up a wait"):
+        ws.status()
+    assert int(words[:4].abs().sum()) == 0 and int(words[5:72].abs().sum()) == 0    # the barrier words were not touched
+    ws.reset()
+    ws.status()
+    assert _same(call(), ref)
+
+
+@pytest.mark.parametrize("env", [{"HVPR_INDEX_FUSED": "0"}, {"HVPR_INDEX_FUSED": "1", "HVPR_INDEX_AGENT": "1"}], ids=["three_launches", "one_launch_device_scope"])
 def test_encode_other_index_forms_in_a_child_process(env):
     """The index phase of hvpr_encode_fwd_f32 has two forms — K1 / K2 / K3 as three launches (what more than 32 768 points take;
     forced here for the small cases too) and the one-launch kernel, whose hand-offs stay in one XCD's L2 when its owners share
