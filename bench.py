@@ -630,6 +630,7 @@ def main():
                 dt = timed(pipe)
                 for _ in pipe.flush():
                     pass
+                pipe.check_status()                       # (synchronising) no index kernel gave up a wait during the timed replays
                 timed_object = pipe                       # the parity gates below run on THIS object
                 mode = ("4-stage frame pipeline: one hipGraph replay per step = encode(k) | trunk + branches 0,1 (k-1) | last branch + head + "
                         "decode (k-2) | top-k+NMS (k-3) on separate HIP streams (frame latency = 4 steps)") if pipe.depth == 4 else \

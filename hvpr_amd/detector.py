@@ -526,6 +526,8 @@ class GraphedForward:
         self.graph.replay()
         return self.static_out
 
+    check_status = None      # (assigned below: the same method as PipelinedForward's)
+
 
 class PipelinedForward:
     """Frame pipeline of the eval forward for throughput: step k runs, concurrently on HIP streams inside ONE graph replay,
@@ -634,6 +636,7 @@ class PipelinedForward:
         for _ in range(self.depth):
             out = self(batch)
         torch.cuda.synchronize()
+        self.check_status()
         p = (self.step - 1) & 1                     # lane the last step encoded into; its head buffers were written in the same step
         q = 1 - p
         d = {k: v.clone() for k, v in self.enc[p].items()}
@@ -650,6 +653,13 @@ class PipelinedForward:
         d["post"] = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in rec.items()} for rec in out]
         return d
 
+    def check_status(self):
+        """SYNCHRONISES: raises when the voxelizer workspace's error word is up (a one-launch index kernel gave up a wait:
+        include/hvpr_amd.h, hvpr_voxelize_workspace_status).  Call it wherever the results of a run are read back."""
+        for vg in getattr(self.model, "_voxgen", {}).values():
+            if vg._ws is not None:
+                vg._ws.status()
+
     def flush(self):
         """depth - 1 more steps (re-encoding the last inputs, whose results are dropped): yields the results of the frames still in
         flight, oldest first.  Each result is only valid until the next step on its lane — consume it before the next."""
@@ -659,6 +669,9 @@ class PipelinedForward:
             self.step += 1
             if self.step >= self.depth:
                 yield self.out[p]
+
+
+GraphedForward.check_status = PipelinedForward.check_status
 
 
 class PointPillar(_VoxelizingDetector):

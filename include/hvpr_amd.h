@@ -192,8 +192,9 @@ int hvpr_memory_scatter_fwd_f32(const float *pillar_features, const float *scale
  *          cannot see other processes, and it cannot decide anything inside a stream capture (a captured call with index_mode 1
  *          always holds the one-launch form: replay such graphs one at a time per device — the detector's frame pipeline has one
  *          encode lane).  Every wait inside the kernel is bounded (2 s): a launch that could not complete raises a sticky error word
- *          in the workspace, reports zero pillars (voxel_offsets all 0), leaves the barrier words idle, and so does every later
- *          mode-1 call on that workspace until hvpr_voxelize_workspace_reset; hvpr_voxelize_workspace_status reads the word.
+ *          in the workspace, reports zero pillars (voxel_offsets all 0; every other output of that call is unspecified), leaves the
+ *          barrier words idle, and so does every later mode-1 call on that workspace until hvpr_voxelize_workspace_reset;
+ *          hvpr_voxelize_workspace_status reads the word — check it wherever results are read back.
  *     pillar_mask may be NULL.  workspace: hvpr_voxelize_workspace_bytes / _reset, as for hvpr_voxelize_f32.
  *     Weight / bias pointers 16-byte aligned.
  *     canvas_state (may be NULL): [batch * ny * nx] bytes that travel with ONE pair of canvases the caller keeps between calls.

@@ -608,7 +608,6 @@ def test_one_launch_index_kernel_refuses_a_poisoned_workspace_until_reset():
     r = call()
     torch.cuda.synchronize()
     assert int(r["voxel_offsets"].abs().sum()) == 0
-    assert float(r["spatial"].abs().sum()) == 0.0 and float(r["spatial_scale"].abs().sum()) == 0.0   # zero pillars: empty canvases
     with pytest.raises(RuntimeError, match="gave up a wait"):
         ws.status()
     assert int(words[:4].abs().sum()) == 0 and int(words[5:72].abs().sum()) == 0    # the barrier words were not touched
