@@ -76,6 +76,13 @@ SIGNATURES = {
     "hvpr_scatter_add_rows_f32": (_I, [_P, _P, _c.c_longlong, _I, _I, _P, _P]),
     "hvpr_segment_sum_rows_f32": (_I, [_P, _c.c_longlong, _I, _I, _P, _P, _P, _c.c_longlong, _P, _c.c_longlong, _P]),
     "hvpr_fused_adam_truewd_f32": (_I, [_P, _P, _P, _P, _c.c_longlong, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "hvpr_assign_targets_workspace_bytes": (_Z, [_I, _I]),
+    "hvpr_assign_targets_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _F, _I, _I, _I, _c.c_longlong, _P, _P, _P, _P, _P, _Z, _P]),
+    "hvpr_rpn_losses_workspace_bytes": (_Z, [_I, _c.c_longlong]),
+    "hvpr_rpn_losses_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _c.c_longlong, _I, _I, _F, _F, _F, _P, _F, _F, _F, _F, _P, _P, _P, _P,
+                                 _P, _Z, _P]),
+    "hvpr_mse_loss_workspace_bytes": (_Z, []),
+    "hvpr_mse_loss_f32": (_I, [_P, _P, _c.c_longlong, _I, _F, _P, _P, _P, _Z, _P]),
     "hvpr_split_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),
     "hvpr_unsplit_bf16_f32": (_I, [_P, _c.c_longlong, _I, _P, _P]),
     "hvpr_conv2d_nhwc_bf16x3": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -137,15 +137,21 @@ class AnchorHeadTemplate(nn.Module):
                                                              self.model_cfg.TARGET_ASSIGNER_CONFIG.MATCH_HEIGHT)
         return self.target_assigner.assign_targets([a.to(gt_boxes.device) for a in self.anchors], gt_boxes)
 
+    def _anchor_rot(self, device):
+        """Heading of every anchor in the head's order (z, y, x, class, size, rot): the direction targets need it."""
+        if getattr(self, "_rot_cache", None) is None or self._rot_cache.device != device:
+            self._rot_cache = torch.cat(self.anchors, dim=-3)[..., 6].reshape(-1).to(device=device, dtype=torch.float32).contiguous()
+        return self._rot_cache
+
     def get_loss(self):
-        """anchor_head_template.py:277-291: (rpn_loss, rpn_loss_point, mem_loss, tb_dict, memory items).  tb_dict holds
-        device scalars (the reference calls .item() on each: ~10 host syncs per step)."""
+        """anchor_head_template.py:277-291: (rpn_loss, rpn_loss_point, mem_loss, tb_dict, memory items) on the library's loss kernels
+        (losses.py: one launch per stream for the three losses and their gradients).  tb_dict holds device scalars (the reference
+        calls .item() on each: ~10 host syncs per step)."""
         from . import losses
         fr = self.forward_ret_dict
         w = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
-        anchors = torch.cat(self.anchors, dim=-3).reshape(-1, 7).to(fr["box_preds"].device)
-        common = dict(labels=fr["box_cls_labels"], reg_targets=fr["box_reg_targets"], anchors=anchors, num_class=self.num_class,
-                      num_anchors_per_loc=self.num_anchors_per_location, cfg_weights=w, dir_offset=self.model_cfg.DIR_OFFSET,
+        common = dict(labels=fr["box_cls_labels"], reg_targets=fr["box_reg_targets"], anchor_rot=self._anchor_rot(fr["box_preds"].device),
+                      pos_count=fr["positives_per_frame"], num_class=self.num_class, cfg_weights=w, dir_offset=self.model_cfg.DIR_OFFSET,
                       num_dir_bins=self.model_cfg.NUM_DIR_BINS)
         cls, box, parts = losses.rpn_losses(fr["cls_preds"], fr["box_preds"], fr.get("dir_cls_preds"), **common)
         cls_p, box_p, parts_p = losses.rpn_losses(fr["cls_preds_point"], fr["box_preds_point"], fr.get("dir_cls_preds_point"), **common)

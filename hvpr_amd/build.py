@@ -16,7 +16,7 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # geometry that has to agree bit-for-bit with the CPU oracle: no FMA contraction (oracle/Makefile does the same)
 PER_FILE = {"iou3d_nms.hip": ["-ffp-contract=off"], "voxelize.hip": ["-ffp-contract=off"], "pointnet2.hip": ["-ffp-contract=off"],
-            "preprocess.hip": ["-ffp-contract=off"]}
+            "preprocess.hip": ["-ffp-contract=off"], "assign_loss.hip": ["-ffp-contract=off"]}
 
 
 def _stale(target, deps):

@@ -1,97 +1,95 @@
-"""Training losses of the anchor head, functional form.
+"""Training losses of the anchor head on the library's own kernels.
 
-Restates pcdet/utils/loss_utils.py — SigmoidFocalClassificationLoss (:9-72), WeightedSmoothL1Loss (:75-136),
-WeightedCrossEntropyLoss (:181-206) — and the head's loss assembly, pcdet/models/dense_heads/anchor_head_template.py:101-291.
-"""
-import numpy as np
+hvpr_rpn_losses_f32: the three losses of one prediction stream — SigmoidFocalClassificationLoss (pcdet/utils/loss_utils.py:9-72),
+WeightedSmoothL1Loss on the sin-difference-encoded residuals (:75-136), WeightedCrossEntropyLoss on the direction bin (:181-206),
+assembled as pcdet/models/dense_heads/anchor_head_template.py:101-260 does — AND their gradients w.r.t. the predictions in ONE
+launch + a fixed-order sum (the reference: ~40 elementwise torch kernels per stream and as many again in autograd's backward).
+hvpr_mse_loss_f32: get_mem_loss (:262-275).  CPU tensors raise (torch forms: tests/torch_forms.py)."""
+import ctypes
+
 import torch
-import torch.nn.functional as F
 
-from .common_utils import limit_period
-
-
-def sigmoid_focal_loss(logits, one_hot, weights, alpha=0.25, gamma=2.0):
-    """(B,A,C) logits / one-hot targets, (B,A) weights -> (B,A,C) weighted focal BCE (loss_utils.py:51-72)."""
-    p = torch.sigmoid(logits)
-    alpha_w = one_hot * alpha + (1 - one_hot) * (1 - alpha)
-    pt = one_hot * (1.0 - p) + (1.0 - one_hot) * p
-    bce = torch.clamp(logits, min=0) - logits * one_hot + torch.log1p(torch.exp(-torch.abs(logits)))
-    return alpha_w * torch.pow(pt, gamma) * bce * weights.unsqueeze(-1)
+from . import kernels
 
 
-def weighted_smooth_l1(pred, target, weights, code_weights, beta=1.0 / 9.0):
-    """(B,A,7) -> (B,A,7); NaN targets are ignored (loss_utils.py:117-136)."""
-    target = torch.where(torch.isnan(target), pred, target)
-    d = torch.abs((pred - target) * code_weights.view(1, 1, -1))
-    loss = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta) if beta >= 1e-5 else d
-    return loss * weights.unsqueeze(-1)
+class _RpnLosses(torch.autograd.Function):
+    """(cls, box, dir predictions) -> the stream's (cls, loc, dir) losses as one (3,) tensor; backward scales the gradients the
+    forward launch already produced by the upstream gradient of each scalar."""
+
+    @staticmethod
+    def forward(ctx, cls_preds, box_preds, dir_preds, labels, reg_targets, anchor_rot, pos_count, num_class, num_dir_bins, weights,
+                dir_offset, alpha, gamma, beta):
+        if not cls_preds.is_cuda or cls_preds.dtype != torch.float32:
+            raise RuntimeError("hvpr_amd: the head's losses need fp32 GPU tensors (the HIP path has no CPU fallback)")
+        B, A = labels.shape
+        cls_c, box_c = cls_preds.contiguous(), box_preds.contiguous()
+        dir_c = None if dir_preds is None else dir_preds.contiguous()
+        assert cls_c.numel() == B * A * num_class and box_c.numel() == B * A * 7
+        L = kernels.lib()
+        out = torch.empty((3,), dtype=torch.float32, device=cls_c.device)
+        g_cls, g_box = torch.empty_like(cls_c), torch.empty_like(box_c)
+        g_dir = None if dir_c is None else torch.empty_like(dir_c)
+        ws = torch.empty(int(L.hvpr_rpn_losses_workspace_bytes(B, A)), dtype=torch.uint8, device=cls_c.device)
+        cw = (ctypes.c_float * 7)(*[float(v) for v in weights["code_weights"]])
+        kernels.check(L.hvpr_rpn_losses_f32(
+            cls_c.data_ptr(), box_c.data_ptr(), None if dir_c is None else dir_c.data_ptr(), kernels._ptr(labels, torch.int32, "labels"),
+            kernels._ptr(reg_targets, torch.float32, "reg_targets"), None if dir_c is None else kernels._ptr(anchor_rot, torch.float32, "anchor_rot"),
+            kernels._ptr(pos_count, torch.int32, "positives_per_frame"), B, A, int(num_class), int(num_dir_bins if dir_c is not None else 0),
+            float(alpha), float(gamma), float(beta), ctypes.cast(cw, ctypes.c_void_p), float(weights["cls_weight"]), float(weights["loc_weight"]),
+            float(weights["dir_weight"]), float(dir_offset), out.data_ptr(), g_cls.data_ptr(), g_box.data_ptr(),
+            None if g_dir is None else g_dir.data_ptr(), ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_rpn_losses_f32")
+        ctx.save_for_backward(g_cls, g_box, g_dir)
+        ctx.shapes = (cls_preds.shape, box_preds.shape, None if dir_preds is None else dir_preds.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g_cls, g_box, g_dir = ctx.saved_tensors
+        s = ctx.shapes
+        return ((g_cls * g[0]).view(s[0]), (g_box * g[1]).view(s[1]), None if g_dir is None else (g_dir * g[2]).view(s[2]),
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
-def weighted_cross_entropy(logits, one_hot, weights):
-    """(B,A,C) logits, (B,A,C) one-hot, (B,A) weights -> (B,A) (loss_utils.py:188-206)."""
-    return F.cross_entropy(logits.permute(0, 2, 1), one_hot.argmax(dim=-1), reduction="none") * weights
-
-
-def add_sin_difference(a, b, dim=6):
-    """sin(a-b) = sin a cos b - cos a sin b, applied to the heading slot (anchor_head_template.py:153-160)."""
-    ra = torch.sin(a[..., dim:dim + 1]) * torch.cos(b[..., dim:dim + 1])
-    rb = torch.cos(a[..., dim:dim + 1]) * torch.sin(b[..., dim:dim + 1])
-    return (torch.cat([a[..., :dim], ra, a[..., dim + 1:]], dim=-1), torch.cat([b[..., :dim], rb, b[..., dim + 1:]], dim=-1))
-
-
-def direction_targets(anchors, reg_targets, dir_offset, num_bins):
-    """One-hot direction bin of the ground-truth heading (anchor_head_template.py:162-176)."""
-    rot_gt = reg_targets[..., 6] + anchors[..., 6]
-    off = limit_period(rot_gt - dir_offset, 0, 2 * np.pi)
-    bins = torch.clamp(torch.floor(off / (2 * np.pi / num_bins)).long(), min=0, max=num_bins - 1)
-    return F.one_hot(bins, num_bins).to(anchors.dtype)
-
-
-_code_w_cache = {}
-
-
-def _code_weights(values, dtype, device):
-    """The code weights as a device tensor, built once per (values, dtype, device): torch.tensor(list, device=...) is a synchronising
-    host copy, and this sits in every training step."""
-    key = (tuple(float(v) for v in values), dtype, device)
-    if key not in _code_w_cache:
-        _code_w_cache[key] = torch.tensor(list(key[0]), dtype=dtype, device=device)
-    return _code_w_cache[key]
-
-
-def rpn_losses(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, num_class, num_anchors_per_loc, cfg_weights,
-               dir_offset, num_dir_bins):
-    """Losses of ONE prediction stream.  cls/box/dir preds are NHWC head outputs; labels (B,A) i32, reg_targets (B,A,7).
+def rpn_losses(cls_preds, box_preds, dir_preds, labels, reg_targets, anchor_rot, pos_count, num_class, cfg_weights, dir_offset,
+               num_dir_bins, alpha=0.25, gamma=2.0, beta=1.0 / 9.0):
+    """Losses of ONE prediction stream.  cls/box/dir preds are NHWC head outputs; labels (B,A) i32, reg_targets (B,A,7),
+    anchor_rot (A,) the anchors' headings, pos_count (B,) i32 positives per frame (the target assigner's).
     Returns (cls_loss, box_loss (loc + dir), parts dict)."""
-    B = cls_preds.shape[0]
-    positives = labels > 0
-    negatives = labels == 0
-    cared = labels >= 0
-    pos_norm = torch.clamp(positives.sum(1, keepdim=True).float(), min=1.0)
-    cls_w = (negatives.float() + positives.float()) / pos_norm
-    reg_w = positives.float() / pos_norm
-    lab = torch.where(positives, torch.ones_like(labels), labels) if num_class == 1 else labels
-    tgt = (lab * cared.to(lab.dtype)).long()
-    one_hot = F.one_hot(tgt, num_class + 1)[..., 1:].to(cls_preds.dtype)
-    cls_loss = sigmoid_focal_loss(cls_preds.reshape(B, -1, num_class), one_hot, cls_w).sum() / B * cfg_weights["cls_weight"]
-
-    bp = box_preds.reshape(B, -1, box_preds.shape[-1] // num_anchors_per_loc)
-    code_w = _code_weights(cfg_weights["code_weights"], bp.dtype, bp.device)
-    bp_sin, tg_sin = add_sin_difference(bp, reg_targets)
-    loc_loss = weighted_smooth_l1(bp_sin, tg_sin, reg_w, code_w).sum() / B * cfg_weights["loc_weight"]
-    parts = {"cls": cls_loss, "loc": loc_loss}
-    box_loss = loc_loss
+    out = _RpnLosses.apply(cls_preds, box_preds, dir_preds, labels, reg_targets, anchor_rot, pos_count, num_class, num_dir_bins,
+                           cfg_weights, dir_offset, alpha, gamma, beta)
+    parts = {"cls": out[0], "loc": out[1]}
+    box_loss = out[1]
     if dir_preds is not None:
-        dt = direction_targets(anchors.reshape(1, -1, anchors.shape[-1]).expand(B, -1, -1), reg_targets, dir_offset, num_dir_bins)
-        w = positives.to(bp.dtype)
-        w = w / torch.clamp(w.sum(-1, keepdim=True), min=1.0)
-        dir_loss = weighted_cross_entropy(dir_preds.reshape(B, -1, num_dir_bins), dt, w).sum() / B * cfg_weights["dir_weight"]
-        box_loss = box_loss + dir_loss
-        parts["dir"] = dir_loss
-    return cls_loss, box_loss, parts
+        parts["dir"] = out[2]
+        box_loss = box_loss + out[2]
+    return out[0], box_loss, parts
+
+
+class _MseLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, weight):
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError("hvpr_amd: the memory loss needs fp32 GPU tensors (the HIP path has no CPU fallback)")
+        xc, tc = x.contiguous(), target.detach().contiguous()
+        assert xc.dim() == 2 and xc.shape == tc.shape
+        L = kernels.lib()
+        out = torch.empty((), dtype=torch.float32, device=xc.device)
+        gx = torch.empty_like(xc)
+        ws = torch.empty(int(L.hvpr_mse_loss_workspace_bytes()), dtype=torch.uint8, device=xc.device)
+        kernels.check(L.hvpr_mse_loss_f32(xc.data_ptr(), tc.data_ptr(), xc.shape[0], xc.shape[1], float(weight), out.data_ptr(), gx.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), kernels._stream()), "hvpr_mse_loss_f32")
+        ctx.save_for_backward(gx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (gx,) = ctx.saved_tensors
+        return gx * g, None, None
 
 
 def memory_loss(memory_pos, point_pos, mem_weight):
     """MSE(memory features, detached point features) / #pillars (anchor_head_template.py:262-275; the divisor is the
     number of pillars of the batch, kept as the reference wrote it)."""
-    return F.mse_loss(memory_pos, point_pos.detach()) / point_pos.shape[0] * mem_weight
+    if memory_pos.shape[0] == 0:
+        return memory_pos.sum() * 0.0
+    return _MseLoss.apply(memory_pos, point_pos, mem_weight)

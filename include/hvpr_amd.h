@@ -478,6 +478,53 @@ int hvpr_bn_relu_bwd_apply_nhwc_f32(const float *dy, const float *z, long long P
                                     const float *dgamma_total, const float *dbeta_total, double inv_count, hvpr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a12 (training)  Anchor target assignment for ONE anchor set (one class of ANCHOR_GENERATOR_CONFIG) and all frames of the batch —
+ *     AxisAlignedTargetAssigner.assign_targets_single (pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:
+ *     113-213; POS_FRACTION < 0: no sampling, NORM_BY_NUM_EXAMPLES false, MATCH_HEIGHT false, as hvpr.yaml:114-124) with
+ *     boxes3d_nearest_bev_iou (pcdet/utils/box_utils.py:252-323) and ResidualCoder.encode_torch (pcdet/utils/box_coder_utils.py:
+ *     13-43).  Two launches, no host round trip (the reference: two `.cpu().numpy()` arg-maxes per frame, :148,:153).
+ *     anchors        [n_anchors, 7] f32 of this set, order (z, y, x, size, rotation); per_loc of them per BEV location
+ *     gt_boxes       [batch, n_gt, 8] f32 [x, y, z, dx, dy, dz, heading, class]; trailing all-zero rows are padding (:53-57);
+ *                    a row takes part when class_names[class - 1] is this set's class (class_index, 0-based; python's negative
+ *                    index for class 0, as the reference has it), n_gt <= 256
+ *     outputs in the HEAD's anchor order: entry ((a / per_loc) * loc_stride + loc_offset + a % per_loc) of frame b, rows of
+ *     anchors_total entries — loc_stride = anchors per location over all sets, loc_offset = this set's first one:
+ *     labels [batch, anchors_total] i32 (-1 don't care, 0 background, class id), reg_targets [batch, anchors_total, 7],
+ *     reg_weights [batch, anchors_total] (1 on positives), pos_count [batch] i32 += positives of this set (zero it before the first set).
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_assign_targets_workspace_bytes(int batch, int n_gt);
+int hvpr_assign_targets_f32(const float *anchors, int n_anchors, const float *gt_boxes, int batch, int n_gt, int class_index,
+                            int n_classes, float matched_thr, float unmatched_thr, int per_loc, int loc_stride, int loc_offset,
+                            long long anchors_total, int32_t *labels, float *reg_targets, float *reg_weights, int32_t *pos_count,
+                            void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a13 (training)  The three losses of ONE prediction stream of the anchor head AND their gradients w.r.t. the predictions, one launch
+ *     + a fixed-order sum — get_cls_layer_loss / get_box_reg_layer_loss (pcdet/models/dense_heads/anchor_head_template.py:101-260):
+ *     sigmoid focal loss (alpha, gamma = 2; pcdet/utils/loss_utils.py:9-72) with weights 1 / max(#positives of the frame, 1) on
+ *     positives and negatives, smooth-L1 (beta) on the sin-difference-encoded residuals (:153-160; loss_utils.py:75-136, NaN targets
+ *     ignored), cross entropy on the direction bin of the ground-truth heading (:162-176; loss_utils.py:181-206); each summed over
+ *     the batch, / batch, x its LOSS_WEIGHTS entry.
+ *     cls_preds [batch, n_anchors, num_class], box_preds [batch, n_anchors, 7], dir_preds [batch, n_anchors, num_dir_bins] or NULL
+ *     (NHWC head outputs viewed per anchor); labels / reg_targets / pos_count from hvpr_assign_targets_f32; anchor_rot [n_anchors]
+ *     the anchors' headings in the same order; code_weights: 7 floats in HOST memory.
+ *     losses [3] (device): cls, loc, dir.  grad_* : d(loss_i)/d(pred), same shapes as the predictions (loss weights and 1 / batch
+ *     included: a caller scales them by the upstream gradient of the respective scalar).  num_class <= 3, num_dir_bins <= 8.
+ *
+ *     hvpr_mse_loss_f32: get_mem_loss (:262-275) — mean((x - target)^2) / rows * weight over [rows, cols] matrices, and its gradient
+ *     w.r.t. x (the target is a constant there: `target.detach()`, :268).
+ * ------------------------------------------------------------------------------------------- */
+size_t hvpr_rpn_losses_workspace_bytes(int batch, long long n_anchors);
+int hvpr_rpn_losses_f32(const float *cls_preds, const float *box_preds, const float *dir_preds, const int32_t *labels,
+                        const float *reg_targets, const float *anchor_rot, const int32_t *pos_count, int batch, long long n_anchors,
+                        int num_class, int num_dir_bins, float alpha, float gamma, float beta, const float *code_weights,
+                        float cls_weight, float loc_weight, float dir_weight, float dir_offset, float *losses, float *grad_cls,
+                        float *grad_box, float *grad_dir, void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+size_t hvpr_mse_loss_workspace_bytes(void);
+int hvpr_mse_loss_f32(const float *x, const float *target, long long rows, int cols, float weight, float *loss, float *grad_x,
+                      void *workspace, size_t workspace_bytes, hvpr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a14 (training)  Optimiser step over ONE flat fp32 parameter buffer (and matching flat gradient / moment buffers, all
  *     16-byte aligned): decoupled weight decay p *= 1 - weight_decay * lr, then Adam with bias correction at `step` (1-based)
  *     — OptimWrapper.step, tools/train_utils/optimization/fastai_optim.py:132-149 (true_wd, the optimiser's own weight_decay
