@@ -531,7 +531,7 @@ def train_step_line(device, which="car", batch=16, steps=3, warmup=2, ddp=False)
            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
            "kernels": "every training module on the library's HIP kernels: voxelizer, point-stream index ops + gathers, VFE forward/backward, "
                       "get_score top-k, memory addressing, scatter, backbone + head convolutions fwd/dgrad/wgrad (Winograd F(2x2,3x3) where 3x3 "
-                      "stride 1), train-mode BatchNorm, flat fused Adam; target assigner + losses are device-side torch code"}
+                      "stride 1), train-mode BatchNorm, target assigner, the head's losses with their gradients, flat fused Adam"}
     del model, opt, pool
     torch.cuda.empty_cache()
     return res
