@@ -642,75 +642,85 @@ def main():
         # with TWO frames per graph replay — every convolution launch sees twice the tiles (4.6 / 2.5 / 1.25 rounds of the resident
         # workgroups instead of 2.3 / 1.25 / 0.63), frame latency doubles, per-frame results are those of batch 1 bit for bit
         # (tests/test_gpu_e2e.py: a frame alone == the frame inside a batch)
-        two = None
-        if world == 1 and not args.no_extras and not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32":
-            def pair(i):
-                a, b = frames[i % N_POOL], frames[(i + 1) % N_POOL]
-                pts = np.concatenate([np.concatenate([np.full((len(f), 1), j, np.float32), f], 1) for j, f in enumerate((a, b))])
-                return {"points": torch.from_numpy(pts).to(device), "batch_size": 2,
-                        "point_frame_offsets": torch.tensor([0, len(a), len(a) + len(b)], dtype=torch.int32, device=device)}
-            pairs = [pair(2 * i) for i in range(N_POOL // 2)]
-            p2 = detector.PipelinedForward(model, pairs[0])
-            n2 = max(args.steps // 2, 1)
-            for i in range(max(args.warmup // 2, 4)):
-                p2(pairs[i % len(pairs)])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(n2):
-                p2(pairs[i % len(pairs)])
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t0
-            for _ in p2.flush():
-                pass
-            del p2, pairs
-            two = {"value": round(2 * n2 / dt2, 2), "unit": "frames/s", "ms_per_replay_of_two_frames": round(1e3 * dt2 / n2, 4),
-                   "what": "PipelinedForward with two frames per graph replay (batch 2 through every stage); NOT `value`"}
-        if args.alt and not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32":
-            # reported next to the headline, never as `value`: the same pipeline with the trunk/SFM 3x3 convolutions on the bf16
-            # matrix cores with split operands
-            alt = []
-            for prec, what, tol in (
-                    ("bf16x6", "operands split into 3 bf16 planes (exact), 6 products, fp32 accumulate: fp32 emulation — per-layer error vs "
-                               "float64 1.2e-6..1.8e-6, the same as the exact fp32 kernel (1.3e-6..1.8e-6)", "fp32-grade (tests/test_gpu_conv.py: 4e-6)"),
-                    ("bf16x3", "operands split into 2 bf16 planes, 3 products, fp32 accumulate: ~2^-16 per product",
-                     "features / boxes within 1e-3 relative of the fp32 path (tests/test_gpu_e2e.py), observed ~1e-5")):
-                model.backbone_2d.set_conv_precision(prec)
-                p3 = detector.PipelinedForward(model, batches[0])
-                dt3 = timed(p3)
-                for _ in p3.flush():
+        def run_two_frames_per_replay():
+            """Runs AFTER the parity gates: a batch-2 pipeline re-allocates the model's post-processing workspace, which the batch-1
+            graphs that were timed (and that the gates re-use) hold by address."""
+            two = None
+            if world == 1 and not args.no_extras and not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32":
+                def pair(i):
+                    a, b = frames[i % N_POOL], frames[(i + 1) % N_POOL]
+                    pts = np.concatenate([np.concatenate([np.full((len(f), 1), j, np.float32), f], 1) for j, f in enumerate((a, b))])
+                    return {"points": torch.from_numpy(pts).to(device), "batch_size": 2,
+                            "point_frame_offsets": torch.tensor([0, len(a), len(a) + len(b)], dtype=torch.int32, device=device)}
+                pairs = [pair(2 * i) for i in range(N_POOL // 2)]
+                p2 = detector.PipelinedForward(model, pairs[0])
+                n2 = max(args.steps // 2, 1)
+                for i in range(max(args.warmup // 2, 4)):
+                    p2(pairs[i % len(pairs)])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n2):
+                    p2(pairs[i % len(pairs)])
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+                for _ in p2.flush():
                     pass
-                del p3
-                sg3, bb_ms = StagedGraphs(model, batches[0]), 0.0       # backbone + head + decode alone, HIP events
-                for i in range(10):
-                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-                    sg3.run(batches[i % N_POOL], ev)
-                    torch.cuda.synchronize()
-                    bb_ms += ev[1].elapsed_time(ev[2]) / 10
-                del sg3
-                nprod = {"bf16x6": 6, "bf16x3": 3}[prec]
-                fl_all, fl_split = conv_flops(model, int(ds.grid_size[1]), int(ds.grid_size[0])), split_conv_flops(model, int(ds.grid_size[1]), int(ds.grid_size[0]), prec)
-                executed = nprod * fl_split          # bf16 products executed on the bf16 matrix cores (the rest runs on the fp32 kernel)
-                alt.append({"mode": prec, "what": what + "; v_mfma_f32_32x32x16_bf16; everything else as in `value` (opt-in: "
-                            "HVPR_CONV_PRECISION=" + prec + ")", "value": round(world * args.steps / dt3, 2), "unit": "frames/s",
-                            "ms_per_step": round(1e3 * dt3 / args.steps, 4), "tolerance": tol,
-                            "mfma": {"backbone_head_decode_ms": round(bb_ms, 4), "algorithmic_TFLOPs": round(fl_all / (bb_ms * 1e-3) / 1e12, 1),
-                                     "executed_bf16_TFLOPs": round(executed / (bb_ms * 1e-3) / 1e12, 1), "bf16_dense_peak_TFLOPs": 2500.0,
-                                     "frac_of_bf16_peak": round(executed / (bb_ms * 1e-3) / 1e12 / 2500.0, 4),
-                                     "note": "executed = products x FLOPs of the layers that run split; fp32 peak for comparison 157.3"}})
-            model.backbone_2d.set_conv_precision("fp32")
-            # the same pipeline with every convolution on the direct fp32 kernel (round 1's configuration)
-            os.environ["HVPR_CONV_ALGO"] = "direct"
-            model.backbone_2d._fold.invalidate()
-            pd = detector.PipelinedForward(model, batches[0])
-            dtd = timed(pd)
-            for _ in pd.flush():
-                pass
-            del pd
-            del os.environ["HVPR_CONV_ALGO"]
-            model.backbone_2d._fold.invalidate()
-            alt.append({"mode": "conv_algo_direct", "what": "HVPR_CONV_ALGO=direct: the stride-1 3x3 layers on the direct implicit-GEMM kernel "
-                        "(hvpr_conv2d_nhwc_f32) instead of Winograd F(2x2,3x3); same fp32 arithmetic, 2.25x the multiplies",
-                        "value": round(world * args.steps / dtd, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dtd / args.steps, 4)})
+                del p2, pairs
+                two = {"value": round(2 * n2 / dt2, 2), "unit": "frames/s", "ms_per_replay_of_two_frames": round(1e3 * dt2 / n2, 4),
+                       "what": "PipelinedForward with two frames per graph replay (batch 2 through every stage); NOT `value`"}
+            return two
+        def run_alt_modes():
+            """The opt-in precision / algorithm modes (--alt), AFTER the parity gates: switching the convolution mode re-packs the
+            weights the timed graphs hold by address."""
+            alt = None
+            if args.alt and world == 1 and not args.no_graph and not args.no_pipeline and args.conv_precision == "fp32":
+                # reported next to the headline, never as `value`: the same pipeline with the trunk/SFM 3x3 convolutions on the bf16
+                # matrix cores with split operands
+                alt = []
+                for prec, what, tol in (
+                        ("bf16x6", "operands split into 3 bf16 planes (exact), 6 products, fp32 accumulate: fp32 emulation — per-layer error vs "
+                                   "float64 1.2e-6..1.8e-6, the same as the exact fp32 kernel (1.3e-6..1.8e-6)", "fp32-grade (tests/test_gpu_conv.py: 4e-6)"),
+                        ("bf16x3", "operands split into 2 bf16 planes, 3 products, fp32 accumulate: ~2^-16 per product",
+                         "features / boxes within 1e-3 relative of the fp32 path (tests/test_gpu_e2e.py), observed ~1e-5")):
+                    model.backbone_2d.set_conv_precision(prec)
+                    p3 = detector.PipelinedForward(model, batches[0])
+                    dt3 = timed(p3)
+                    for _ in p3.flush():
+                        pass
+                    del p3
+                    sg3, bb_ms = StagedGraphs(model, batches[0]), 0.0       # backbone + head + decode alone, HIP events
+                    for i in range(10):
+                        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                        sg3.run(batches[i % N_POOL], ev)
+                        torch.cuda.synchronize()
+                        bb_ms += ev[1].elapsed_time(ev[2]) / 10
+                    del sg3
+                    nprod = {"bf16x6": 6, "bf16x3": 3}[prec]
+                    fl_all, fl_split = conv_flops(model, int(ds.grid_size[1]), int(ds.grid_size[0])), split_conv_flops(model, int(ds.grid_size[1]), int(ds.grid_size[0]), prec)
+                    executed = nprod * fl_split          # bf16 products executed on the bf16 matrix cores (the rest runs on the fp32 kernel)
+                    alt.append({"mode": prec, "what": what + "; v_mfma_f32_32x32x16_bf16; everything else as in `value` (opt-in: "
+                                "HVPR_CONV_PRECISION=" + prec + ")", "value": round(world * args.steps / dt3, 2), "unit": "frames/s",
+                                "ms_per_step": round(1e3 * dt3 / args.steps, 4), "tolerance": tol,
+                                "mfma": {"backbone_head_decode_ms": round(bb_ms, 4), "algorithmic_TFLOPs": round(fl_all / (bb_ms * 1e-3) / 1e12, 1),
+                                         "executed_bf16_TFLOPs": round(executed / (bb_ms * 1e-3) / 1e12, 1), "bf16_dense_peak_TFLOPs": 2500.0,
+                                         "frac_of_bf16_peak": round(executed / (bb_ms * 1e-3) / 1e12 / 2500.0, 4),
+                                         "note": "executed = products x FLOPs of the layers that run split; fp32 peak for comparison 157.3"}})
+                model.backbone_2d.set_conv_precision("fp32")
+                # the same pipeline with every convolution on the direct fp32 kernel (round 1's configuration)
+                os.environ["HVPR_CONV_ALGO"] = "direct"
+                model.backbone_2d._fold.invalidate()
+                pd = detector.PipelinedForward(model, batches[0])
+                dtd = timed(pd)
+                for _ in pd.flush():
+                    pass
+                del pd
+                del os.environ["HVPR_CONV_ALGO"]
+                model.backbone_2d._fold.invalidate()
+                alt.append({"mode": "conv_algo_direct", "what": "HVPR_CONV_ALGO=direct: the stride-1 3x3 layers on the direct implicit-GEMM kernel "
+                            "(hvpr_conv2d_nhwc_f32) instead of Winograd F(2x2,3x3); same fp32 arithmetic, 2.25x the multiplies",
+                            "value": round(world * args.steps / dtd, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dtd / args.steps, 4)})
+
+            return alt
 
         # ---- per-stage probe (untimed): HIP events on the launch stream ----
         stage = np.zeros(3)
@@ -849,8 +859,6 @@ def main():
                                   "(DESIGN.md §4.2), i.e. ~132 TFLOP/s attainable.  alt_precision[mode=conv_algo_direct] is the same frame "
                                   "with every layer on the direct kernel"},
     }
-    res["alt_precision"] = alt
-    res["pipeline_two_frames_per_replay"] = two
     res["train_step_ddp"] = train_ddp
     # cpu_baseline + parity gates while the timed object is still alive: the oracle's frames go through it as well
     gates = None
@@ -868,6 +876,9 @@ def main():
                 _no_grad(gates)(f, *O.forward_frames([f], params, O.cfg_from_model_cfg(cfg)))
     res["parity"] = None if gates is None else gates.result()
     del timed_object
+    with torch.no_grad():
+        res["pipeline_two_frames_per_replay"] = run_two_frames_per_replay()
+        res["alt_precision"] = run_alt_modes()
     if world == 1 and not args.no_extras:
         # driver-visible numbers for the other BASELINE.json configs (bounded step counts): the same group at batch 16 and on
         # the dense scene (configs[4]); the full train step (configs[2])
