@@ -100,8 +100,10 @@ __global__ void __launch_bounds__(256) k_head_decode(const float *__restrict__ h
         float dm = dp[0];
         for (int b = 1; b < nbins; ++b) if (dp[b] > dm) { dm = dp[b]; dl = b; }
         const float v = rg - dir_offset;
-        const float rot = v - floorf(v / period + dir_limit_offset) * period;   // limit_period
-        rg = rot + dir_offset + period * (float)dl;
+        // limit_period (common_utils.py:20-23) with the reference's roundings: product and difference rounded separately (a fused
+        // multiply-subtract differs in the last bit for ~18 % of the headings: fixture G7, tests/test_gpu_eval_fixtures.py)
+        const float rot = __fsub_rn(v, __fmul_rn(floorf(__fadd_rn(v / period, dir_limit_offset)), period));
+        rg = __fadd_rn(__fadd_rn(rot, dir_offset), __fmul_rn(period, (float)dl));
     }
     o[6] = rg;
 }
