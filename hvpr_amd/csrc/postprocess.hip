@@ -102,8 +102,13 @@ __global__ void __launch_bounds__(256) k_head_decode(const float *__restrict__ h
         const float v = rg - dir_offset;
         // limit_period (common_utils.py:20-23) with the reference's roundings: product and difference rounded separately (a fused
         // multiply-subtract differs in the last bit for ~18 % of the headings: fixture G7, tests/test_gpu_eval_fixtures.py)
-        const float rot = __fsub_rn(v, __fmul_rn(floorf(__fadd_rn(v / period, dir_limit_offset)), period));
-        rg = __fadd_rn(__fadd_rn(rot, dir_offset), __fmul_rn(period, (float)dl));
+        {
+#pragma clang fp contract(off)
+            const float turns = floorf(v / period + dir_limit_offset);
+            const float back = turns * period;
+            const float rot = v - back;
+            rg = (rot + dir_offset) + period * (float)dl;
+        }
     }
     o[6] = rg;
 }
