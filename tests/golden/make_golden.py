@@ -253,7 +253,7 @@ def g2_g3_memory_scatter(R):
 
 def g4_backbone(R):
     for tag, (C, filt, sfilt, H, W, seed) in {
-        "small": (32, [32, 48, 64], [8, 12, 16], 16, 24, 404),
+        "small": (32, [32, 48, 64], [8, 16, 24], 16, 24, 404),     # channel counts the kernels take: multiples of 8
         "full": (128, [128, 256, 512], [32, 64, 128], 8, 12, 405),
     }.items():
         gen = torch.Generator().manual_seed(seed)
