@@ -547,273 +547,6 @@ __global__ void __launch_bounds__(T) k_index(const float *__restrict__ pts, int 
     }
 }
 
-// ---- the index phase of ONE frame with the cell maps in LDS (round 6) ---------------------------------------------------------------
-// k_index above pays ~12 dependent memory-side round trips (cell-map atomics, two grid barriers, a look-back scan, the per-cell
-// words).  For one frame of up to 16 384 points on a grid of up to 98 304 cells the maps fit the LDS of kBands workgroups: owner
-// `band` owns the contiguous range of cell ids [band * cells_band, (band + 1) * cells_band) and keeps its first-index and count
-// maps in its own LDS (16 bytes per cell: 76 KB at hvpr_car).  Every owner reads ALL points (256 KB out of the L2), and
-//   A  files the points of its band with LDS atomics (first index by minimum, count by add) and remembers them in an LDS list,
-//      then publishes per point i ONE 8-byte word {cell, is-first, count of the cell} — each point by exactly one owner
-//      (out-of-range points by owner 0);
-//   -- one grid barrier (the census of k_index: device-scope, bounded wait, same exit protocol) --
-//   B  scans the words of all points in index order (1024 threads x 16 consecutive words: voxel rank = first-touch order, arena
-//      offset = running count) and keeps rank / count / offset of ITS cells in LDS, writing their per-voxel records;
-//   C  walks its list and files every point at offset + (an LDS down-counter of the cell): arrival order inside a voxel is
-//      arbitrary, as with k_index (the pillar kernel orders a voxel's points by index itself).
-// One exchange through memory instead of five.  What the next kernels read is what k_index leaves: arena_rec / arena_pt, vox_rec,
-// cell_vid, frame_base, arena_total, voxel_offsets, and the global first-index map marking the occupied cells for the canvas clear
-// (the global count map is never touched: it stays idle).
-constexpr int kBands = 16, kBandThreads = 1024, kBandItems = 16;
-constexpr int kBandMaxCells = 6144;          // per owner: 96 KB of LDS for the maps
-constexpr int kBandList = 4096;              // in-band points an owner remembers (16 KB); the ones beyond take a slow path
-
-// floor(fl(fl(x - lo) / vs)) — the reference's cell coordinate, bit for bit — without a division in the common case: the product
-// with fl(1 / vs) is within 3 ulp of the quotient, so unless it lies within 8 ulp of an integer its floor IS the floor of the
-// correctly rounded quotient; the rare rest (and NaN / infinity) takes the division.
-__device__ __forceinline__ float cell_coord(float x, float lo, float vs, float inv_vs) {
-    const float t = __fsub_rn(x, lo);
-    const float q = t * inv_vs, c = floorf(q), f = q - c;
-    const float d = 4.8e-7f * fmaxf(fabsf(q), 1.f);
-    if (f > d && f < 1.f - d) return c;
-    return floorf(__fdiv_rn(t, vs));
-}
-
-__global__ void __launch_bounds__(kBandThreads) k_index_bands(const float *__restrict__ pts, int n, int stride, int xyz_col, float lox,
-                                                              float loy, float loz, float vsx, float vsy, float vsz, int nx, int ny,
-                                                              int cells_band, int max_voxels, VoxWs w, int *__restrict__ voxel_offsets,
-                                                              const float *__restrict__ vfe_w1, const float *__restrict__ vfe_b0,
-                                                              int warm_parts, const float4 *__restrict__ warm0, long long warm0_v4,
-                                                              const float4 *__restrict__ warm1, long long warm1_v4, WarmSmall small,
-                                                              int *__restrict__ sink) {
-    constexpr int T = kBandThreads, E = kBandItems;
-    const int owners_end = 8 * kBands;         // owner `band` is block 8 band: the blocks a round-robin deal puts on ONE XCD
-    if ((int)blockIdx.x > owners_end) {        // L2 warmers (internal.h)
-        warm_l2<T>(((int)blockIdx.x - owners_end - 1) >> 3, warm_parts, warm0, warm0_v4, warm1, warm1_v4, small, sink);
-        return;
-    }
-    if ((int)blockIdx.x == owners_end) {       // the pillar VFE's padded-slot column (internal.h)
-        if (vfe_w1 && threadIdx.x < 64) {
-            const int lane = threadIdx.x, h = lane >> 5, slot = lane & 31;
-            float aw[2][8], b0h[8];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) aw[mb][t] = vfe_w1[(32 * mb + slot) * 32 + 8 * (t >> 2) + 4 * h + (t & 3)];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) b0h[t] = vfe_b0[8 * (t >> 2) + 4 * h + (t & 3)];
-            hvpr_vfe_padded_slot(aw, b0h, w.vfe_aux);
-        }
-        return;
-    }
-    if (blockIdx.x & 7) return;
-    extern __shared__ __attribute__((aligned(16))) char band_smem[];
-    int *const s_first = reinterpret_cast<int *>(band_smem);                                  // [cells_band] first point index, kIdle: empty
-    int *const s_count = s_first + cells_band;                                               // [cells_band] points of the cell; phase C counts it down
-    unsigned long long *const s_pack = reinterpret_cast<unsigned long long *>(s_count + cells_band);   // [cells_band] rank | count << 20 | offset << 40
-    unsigned *const s_list = reinterpret_cast<unsigned *>(s_pack + cells_band);               // [kBandList] point index | band-local cell << 14
-    __shared__ unsigned s_wave_a[T / 64], s_wave_b[T / 64];
-    __shared__ int s_abort, s_n;
-    const int band = blockIdx.x >> 3, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g_lo = band * cells_band, g_hi = g_lo + cells_band;
-    unsigned long long *const census = reinterpret_cast<unsigned long long *>(w.sync);
-    int *const err_word = w.sync + kSyncError;
-    const int poisoned = __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int c = tid; c < cells_band; c += T) { s_first[c] = kIdle; s_count[c] = 0; }
-    if (tid == 0) { s_abort = 0; s_n = 0; }
-    // ---- phase A: every point's cell; the band's points go into the LDS maps and the list
-    const float ivx = 1.f / vsx, ivy = 1.f / vsy, ivz = 1.f / vsz;
-    const float *const p_thread = pts + (size_t)tid * stride + xyz_col;      // point tid + T k sits k * (T * stride) floats behind it
-    const unsigned k_step = (unsigned)T * (unsigned)stride;
-    float px[E], py[E], pz[E];
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-        px[k] = py[k] = pz[k] = 0.f;
-        if (tid + T * k < n) {
-            const float *p = p_thread + (size_t)(k_step * (unsigned)k);
-            px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
-        }
-    }
-    if (poisoned != 0) {        // (see k_index: a workspace whose error word is up is not touched)
-        if (band == 0 && tid <= 1) voxel_offsets[tid] = 0;
-        return;
-    }
-    __syncthreads();
-    unsigned oor = 0u, ovf = 0u;               // bit k: point tid + T k lies outside the grid / did not fit the list
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-        const int i = tid + T * k;
-        const float cx = cell_coord(px[k], lox, vsx, ivx), cy = cell_coord(py[k], loy, vsy, ivy), cz = cell_coord(pz[k], loz, vsz, ivz);
-        const bool in_grid = i < n && cx >= 0.f && cx < (float)nx && cy >= 0.f && cy < (float)ny && cz >= 0.f && cz < 1.f;
-        const int g = in_grid ? (int)cy * nx + (int)cx : -1;
-        if (i < n && !in_grid) oor |= 1u << k;
-        const bool mine = g >= g_lo && g < g_hi;
-        const unsigned long long m = __ballot(mine);
-        if (m != 0ull) {                                          // wave-uniform
-            int base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&s_n, __popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1, 64);
-            if (mine) {
-                const int c = g - g_lo;
-                atomicMin(&s_first[c], i);
-                atomicAdd(&s_count[c], 1);
-                const int at = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (at < kBandList) s_list[at] = (unsigned)i | ((unsigned)c << 14);
-                else ovf |= 1u << k;
-            }
-        }
-    }
-    __syncthreads();
-    const int n_mine = s_n, n_list = n_mine < kBandList ? n_mine : kBandList;
-    // one word per point, by the owner of its cell: cell << 32 | first << 31 | count (device scope: the readers sit on other CUs,
-    // possibly other XCDs)
-    for (int e = tid; e < n_list; e += T) {
-        const unsigned v = s_list[e];
-        const int i = (int)(v & 0x3fffu), c = (int)(v >> 14);
-        const unsigned lo = s_first[c] == i ? (0x80000000u | (unsigned)s_count[c]) : 0u;
-        __hip_atomic_store(&w.cell_pack[i], ((unsigned long long)(unsigned)(c + g_lo) << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (band == 0 && oor != 0u) {
-#pragma unroll
-        for (int k = 0; k < E; ++k)
-            if ((oor >> k) & 1u)
-                __hip_atomic_store(&w.cell_pack[tid + T * k], 0xffffffff00000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (ovf != 0u) {            // (a band with more than kBandList points: the rest, one by one)
-#pragma unroll 1
-        for (int k = 0; k < E; ++k)
-            if ((ovf >> k) & 1u) {
-                const int i = tid + T * k;
-                const float *p = pts + (size_t)i * stride + xyz_col;
-                const int c = (int)cell_coord(p[1], loy, vsy, ivy) * nx + (int)cell_coord(p[0], lox, vsx, ivx) - g_lo;
-                const unsigned lo = s_first[c] == i ? (0x80000000u | (unsigned)s_count[c]) : 0u;
-                __hip_atomic_store(&w.cell_pack[i], ((unsigned long long)(unsigned)(c + g_lo) << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- the grid barrier: k_index's census (every owner adds 1 to the byte of its XCD; bounded wait)
-    if (tid == 0) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcc &= 7u;
-        __hip_atomic_fetch_add(census, 1ull << (8 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long c0 = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_sleep(4);
-        unsigned long long c1 = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_sleep(4);
-        unsigned long long c2 = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long c = c0;
-        SpinWatch watch(err_word);
-        while (byte_sum(c) < (unsigned)kBands) {
-            if (watch.give_up()) { s_abort = 1; break; }
-            c = c1; c1 = c2;
-            __builtin_amdgcn_s_sleep(4);
-            c2 = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    if (!s_abort) {
-        // ---- phase B: scan of (is-first, count) over the points in index order; E consecutive words per thread
-        const int per = (n + T - 1) / T;                       // <= E
-        const unsigned *const words = reinterpret_cast<const unsigned *>(w.cell_pack);      // [2 i]: is-first << 31 | count, [2 i + 1]: cell
-        unsigned ent[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int j = tid * per + e;
-            ent[e] = (e < per && j < n) ? __hip_atomic_load(words + 2 * (size_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        }
-        unsigned ta = 0, tb = 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            ta += ent[e] >> 31;
-            tb += (ent[e] >> 31) ? (ent[e] & 0x7fffffffu) : 0u;
-        }
-        // the cells of the first points (~5 per thread), all requested at once (a load per use would be sixteen round trips in a row)
-        int cell[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            cell[e] = (ent[e] >> 31) ? (int)__hip_atomic_load(words + 2 * (size_t)(tid * per + e) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        const unsigned ia = wave_scan_incl(ta), ib = wave_scan_incl(tb);
-        if (lane == 63) { s_wave_a[wid] = ia; s_wave_b[wid] = ib; }
-        __syncthreads();
-        unsigned wa = 0, wb = 0, tot_a = 0, tot_b = 0;
-#pragma unroll
-        for (int k = 0; k < T / 64; ++k) {
-            if (k < wid) { wa += s_wave_a[k]; wb += s_wave_b[k]; }
-            tot_a += s_wave_a[k]; tot_b += s_wave_b[k];
-        }
-        unsigned ra = wa + (ia - ta), rb = wb + (ib - tb);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (ent[e] >> 31) {
-                const int j = tid * per + e, cnt = (int)(ent[e] & 0x7fffffffu), g = cell[e];
-                if (g >= g_lo && g < g_hi) {
-                    s_pack[g - g_lo] = (unsigned long long)ra | ((unsigned long long)cnt << 20) | ((unsigned long long)rb << 40);
-                    w.vox_rec[ra] = make_int4(g, cnt, (int)rb, j);
-                    w.cell_vid[g] = (int)ra;
-                    w.cell_first[g] = j;                       // the occupied cells, for the canvas clear of the pillar launch
-                }
-                ra += 1u; rb += (unsigned)cnt;
-            }
-        }
-        if (band == 0 && tid == 0) {
-            voxel_offsets[0] = 0;
-            voxel_offsets[1] = (int)tot_a < max_voxels ? (int)tot_a : max_voxels;
-            w.frame_base[0] = 0;
-            w.frame_base[1] = (int)tot_a;
-            *w.arena_total = (int)tot_b;
-        }
-        __syncthreads();
-        // ---- phase C: the band's points to their arena positions (list entries tid, tid + T, ...: their points requested together)
-        constexpr int kPer = kBandList / T;
-        int ci[kPer], cc[kPer];
-        float4 cp[kPer];
-#pragma unroll
-        for (int m = 0; m < kPer; ++m) {
-            const int e = tid + T * m;
-            const unsigned v = s_list[e < n_list ? e : 0];
-            ci[m] = (int)(v & 0x3fffu); cc[m] = (int)(v >> 14);
-            const float *p = pts + (size_t)ci[m] * stride + xyz_col;
-            cp[m] = n_list > 0 ? make_float4(p[0], p[1], p[2], p[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int m = 0; m < kPer; ++m) {
-            if (tid + T * m < n_list) {
-                const unsigned long long pk = s_pack[cc[m]];
-                const int r = (int)(pk & 0xfffffull), cnt = (int)((pk >> 20) & 0xfffffull), off = (int)(pk >> 40);
-                const int pos = off + atomicSub(&s_count[cc[m]], 1) - 1;
-                const bool kept = r < max_voxels;
-                w.arena_rec[pos] = make_int4(ci[m], kept ? r : -1, cnt, cc[m] + g_lo);
-                if (kept) w.arena_pt[pos] = cp[m];
-            }
-        }
-        if (ovf != 0u) {
-#pragma unroll 1
-            for (int k = 0; k < E; ++k)
-                if ((ovf >> k) & 1u) {
-                    const int i = tid + T * k;
-                    const float *p = pts + (size_t)i * stride + xyz_col;
-                    const float4 pt = make_float4(p[0], p[1], p[2], p[3]);
-                    const int c = (int)cell_coord(pt.y, loy, vsy, ivy) * nx + (int)cell_coord(pt.x, lox, vsx, ivx) - g_lo;
-                    const unsigned long long pk = s_pack[c];
-                    const int r = (int)(pk & 0xfffffull), cnt = (int)((pk >> 20) & 0xfffffull), off = (int)(pk >> 40);
-                    const int pos = off + atomicSub(&s_count[c], 1) - 1;
-                    const bool kept = r < max_voxels;
-                    w.arena_rec[pos] = make_int4(i, kept ? r : -1, cnt, c + g_lo);
-                    if (kept) w.arena_pt[pos] = pt;
-                }
-        }
-    } else {
-        if (tid == 0) __hip_atomic_store(err_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (band == 0 && tid <= 1) voxel_offsets[tid] = 0;
-    }
-    // the last owner out returns the census to idle (k_index's exit protocol)
-    if (tid == 0 && __hip_atomic_fetch_add(&w.sync[kSyncExit], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kBands - 1) {
-        __hip_atomic_store(census, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&w.sync[kSyncExit], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 __global__ void __launch_bounds__(256) k3_fill(int n, const int *__restrict__ foff, int batch, int max_voxels, VoxWs w,
                                                int *__restrict__ voxel_offsets, int for_encode, int have_slots,
                                                const float *__restrict__ pts, int stride, int xyz_col,
@@ -1000,27 +733,6 @@ int hvpr_i_voxel_index(const VoxelizeArgs &a, const VoxWs &w, int32_t *voxel_off
         guard.lock();                      // held until the launch is noted: two host threads cannot both see "nothing in flight"
         fused = fused_allowed(s, &capturing) != 0;
         if (!fused) guard.unlock();
-    }
-    static const int env_bands = [] { const char *e = getenv("HVPR_INDEX_BANDS"); return e ? atoi(e) : 1; }();
-    const long long ncell_all = (long long)a.nx * a.ny * a.nz;
-    if (fused && env_bands && a.batch == 1 && a.nz == 1 && a.n_points <= kBandThreads * kBandItems && ncell_all >= a.n_points &&
-        ncell_all <= (long long)kBands * kBandMaxCells) {
-        // one frame, cell maps in the LDS of kBands workgroups (k_index_bands)
-        int cells_band = (int)((ncell_all + kBands - 1) / kBands);
-        cells_band += cells_band & 1;                                   // (the 8-byte array behind the two 4-byte ones stays aligned)
-        const int lds = cells_band * 16 + kBandList * 4;
-        static unsigned long long lds_done = 0ull;
-        if (hvpr_ensure_dyn_lds((const void *)k_index_bands, kBandMaxCells * 16 + kBandList * 4 + 64, &lds_done) != 0) return HVPR_ERR_LAUNCH;
-        const int parts = kWarmParts * 256 / kBandThreads;
-        const int warmers = (vfe_w1 && (warm0 || warm1)) ? 8 * parts : 0;
-        hipLaunchKernelGGL(k_index_bands, dim3(8 * kBands + 1 + warmers), dim3(kBandThreads), lds, s, a.points, a.n_points, a.point_stride,
-                           a.xyz_col, a.lo_x, a.lo_y, a.lo_z, a.vs_x, a.vs_y, a.vs_z, a.nx, a.ny, cells_band, a.max_voxels, w, voxel_offsets,
-                           vfe_w1, vfe_b0, parts, (const float4 *)warm0, (long long)(warm0 ? warm0_bytes / 16 : 0), (const float4 *)warm1,
-                           (long long)(warm1 ? warm1_bytes / 16 : 0), (warm_small && warmers) ? *warm_small : WarmSmall{},
-                           (int *)(w.vfe_aux + 64));
-        if (!capturing) note_fused_launch(s);
-        HVPR_CHECK_LAUNCH();
-        return HVPR_OK;
     }
     if (fused) {
         // one launch: the owners of the point tiles (every 8th of the first 8 x tiles blocks), the padded-slot workgroup, the
