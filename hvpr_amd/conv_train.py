@@ -14,6 +14,8 @@ Activations are NHWC tensors (N, H, W, C) — what torch calls channels_last —
                       hvpr_bn_relu_fwd_nhwc_f32, hvpr_bn_relu_bwd_nhwc_f32; running statistics updated like nn.BatchNorm2d
                       (momentum, unbiased variance, one update per CALL — SURVEY.md B.5).
 """
+import os
+
 import torch
 
 from . import kernels
@@ -197,6 +199,9 @@ def _affine(mean, var, invstd, gamma, beta, count, running):
                                          kernels._ptr(beta.detach(), torch.float32, "beta"), float(m), float(mu), kernels._ptr(rm, torch.float32, "running_mean"),
                                          kernels._ptr(rv, torch.float32, "running_var"), kernels._ptr(nbt, torch.int64, "num_batches_tracked"),
                                          scale.data_ptr(), shift.data_ptr(), kernels._stream()), "hvpr_bn_train_affine_f32")
+    if rm is not None:      # the kernel wrote the buffers through raw pointers: let torch's version counters know (no launch)
+        for t in (rm, rv, nbt):
+            torch.autograd.graph.increment_version(t)
     return scale, shift, rm is not None
 
 
@@ -232,6 +237,9 @@ def _bn_backward(dy, z, P, C, scale, shift, mean, invstd, relu, gate, dgate, cou
 
 _wino_pack_cache = {}
 _weights_epoch = [0]
+# HVPR_DEBUG_PACK_CACHE=1: every cache hit re-checks a checksum of the weight (a host sync per convolution: debugging only; the GPU
+# test suite runs one training test this way)
+_DEBUG_PACK_CACHE = os.environ.get("HVPR_DEBUG_PACK_CACHE", "0") == "1"
 
 
 def weights_changed():
@@ -252,11 +260,17 @@ def _packed(weight, kind, build):
     state = (weight._version, weight.data_ptr())
     hit = _wino_pack_cache.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == state:
+        if _DEBUG_PACK_CACHE and float(weight.detach().double().sum()) != hit[3]:
+            raise RuntimeError("hvpr_amd.conv_train: a parameter was written without a version bump (through `.data` or a raw pointer) and "
+                               "without conv_train.weights_changed(): its cached packed filter is stale")
         return hit[2]
     pc = build()
     if len(_wino_pack_cache) > 1024:
         _wino_pack_cache.clear()
-    _wino_pack_cache[key] = (weakref.ref(weight), state, pc)
+    # the entry goes when its tensor does (fuzz / gradcheck loops create thousands of short-lived weights: their packed copies would
+    # otherwise stay until the size bound above)
+    _wino_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key: _wino_pack_cache.pop(k, None)), state, pc,
+                             float(weight.detach().double().sum()) if _DEBUG_PACK_CACHE else None)
     return pc
 
 

@@ -257,6 +257,8 @@ class Detector3DTemplate(nn.Module):
         update = {k: v for k, v in disk.items() if k in state and state[k].shape == v.shape}
         state.update(update)
         self.load_state_dict(state)
+        from . import conv_train
+        conv_train.weights_changed()         # (load_state_dict bumps the versions itself; a restore is rare enough to be explicit)
         if logger is not None:
             for k in state:
                 if k not in update:

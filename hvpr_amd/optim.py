@@ -140,6 +140,8 @@ class FusedAdamOneCycle:
                 p.data = view
         self._grad_views = [self.flat_g[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
         self._point_grads()
+        from . import conv_train
+        conv_train.weights_changed()        # every parameter has just moved into the flat buffer
         self.wd, self._lr, self._mom, self.beta2, self.eps = wd, lr, 0.9, beta2, eps
         self.steps = 0
         self._scale = None

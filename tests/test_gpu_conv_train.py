@@ -264,3 +264,31 @@ def test_bn_relu_with_fused_sfm_gate_matches_torch(shape):
     want = torch.autograd.grad(yr, (zr, ref.weight, ref.bias, gr, rr), dy)
     for a_, b_, what in zip(got, want, ("dz", "dgamma", "dbeta", "dgate", "dresid")):
         _close(a_, b_, what=what)
+
+
+def test_packed_filter_cache_debug_check_catches_a_write_behind_torchs_back(monkeypatch):
+    """conv_train keeps packed filters per (parameter object, version, data pointer).  A write through `.data` keeps all three: without
+    conv_train.weights_changed() the cached image is stale.  With HVPR_DEBUG_PACK_CACHE=1 every hit re-checks a checksum of the weight:
+    a silent stale-weights forward becomes an error; an announced write (weights_changed) and a versioned in-place write pass."""
+    import torch
+    from hvpr_amd import conv_train as ct
+    monkeypatch.setattr(ct, "_DEBUG_PACK_CACHE", True)
+    ct.weights_changed()
+    w = torch.nn.Parameter(torch.randn(64, 32, 3, 3, device="cuda:0") * 0.1)
+    x = torch.randn(1, 24, 40, 32, device="cuda:0")
+    y0 = ct.conv_fwd_raw(x, w)
+    assert torch.equal(ct.conv_fwd_raw(x, w), y0)                      # hit, checksum agrees
+    w.data.mul_(2.0)                                                    # behind torch's back: same object, version, pointer
+    import pytest
+    with pytest.raises(RuntimeError, match="stale"):
+        ct.conv_fwd_raw(x, w)
+    ct.weights_changed()                                                # announced: re-packed
+    torch.testing.assert_close(ct.conv_fwd_raw(x, w), 2.0 * y0, rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        w.mul_(0.5)                                                     # versioned in-place write: detected by the version
+    torch.testing.assert_close(ct.conv_fwd_raw(x, w), y0, rtol=1e-5, atol=1e-6)
+    # entries go with their tensors
+    n0 = len(ct._wino_pack_cache)
+    for _ in range(5):
+        ct.conv_fwd_raw(x, torch.randn(64, 32, 3, 3, device="cuda:0"))
+    assert len(ct._wino_pack_cache) <= n0 + 1
