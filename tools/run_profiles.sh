@@ -7,7 +7,7 @@ O=gpurun_out/${1:-r05a}
 export TMPDIR=/tmp
 mkdir -p $O
 T="timeout 280"
-B="--no-cpu-baseline --no-extras"
+B="--no-cpu-baseline --no-extras --no-parity"
 # latency mode, the backbone's branches on their own HIP streams (what `single_graph_latency_mode` of the bench line runs)
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_single -o bench -- python3 bench.py --no-pipeline $B --steps 50 --warmup 5 > $O/stats_single.log 2>&1
 # SERIAL: the same frame graph with every kernel on ONE stream (HVPR_BEV_STREAMS=1): kernel durations do not overlap, so
