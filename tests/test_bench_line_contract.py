@@ -42,3 +42,20 @@ def test_bench_line_has_the_contract_fields_and_is_self_consistent():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     mf = r["roofline_mfma"]
     assert mf["bound"] == "mfma" and abs(mf["frac"] - mf["achieved"] / mf["peak"]) < 1e-3
+
+
+def test_bench_line_carries_the_parity_gates_of_survey_8d():
+    """Round 6 on: the line holds `parity` — the timed pipeline against the CPU oracle on the cpu_baseline frames (SURVEY.md §8d
+    "parity gates run with every benchmark") — and every gate is green in the committed line."""
+    path = _latest()
+    if int(re.match(r"r(\d+)_", os.path.basename(path)).group(1)) < 6:
+        return
+    p = json.load(open(path))["parity"]
+    for k in ("ok", "frames", "voxel_exact", "pillar_rel", "canvas_rel", "feat2d_rel", "box_rel", "nms_exact_on_gpu_logits", "survivors_common",
+              "survivors_common_same_score_order", "survivor_flips", "survivor_flips_unexplained", "rtol"):
+        assert k in p, k
+    assert p["ok"] is True and p["frames"] >= 10 and p["voxel_exact"] is True and p["nms_exact_on_gpu_logits"] is True
+    assert max(p["pillar_rel"], p["canvas_rel"], p["feat2d_rel"], p["box_rel"]) <= p["rtol"] == 1e-3
+    assert p["survivor_flips_unexplained"] == 0
+    a, b = p["survivors_common_same_score_order"]
+    assert a >= 0.99 * b > 0
