@@ -63,8 +63,14 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
                                                              const int4 *__restrict__ coords, int batch, int nx, int ny,
                                                              int *__restrict__ cell_map, float *__restrict__ canvas,
                                                              int canvas_channels, int canvas_offset) {
-    __shared__ __attribute__((aligned(16))) float s_f[kPillars * kC];
-    __shared__ __attribute__((aligned(16))) float s_pm[kPillars * 64];       // per-lane maxima: [pillar][wave * 4 + quarter]
+    // LDS pitches (round 6, SQ_LDS_BANK_CONFLICT 41 % -> see DESIGN.md §4.1): a pillar's feature row is kFP = 68 floats apart from the
+    // next one (the 16 lanes of a b128 service group then land in distinct banks: with 64 they all hit the same four), the per-lane
+    // maxima are stored [wave * 4 + quarter][pillar] with pitch 17, the hit counts [pillar][wave] with pitch 17, and a pillar's 16
+    // candidate segments are kRowC = 196 ints apart from the next pillar's (16 x 12 + 4: the segments of the same wave of the 16
+    // pillars start in 16 distinct banks instead of one)
+    constexpr int kFP = kC + 4, kPmP = 17, kCntP = 17;
+    __shared__ __attribute__((aligned(16))) float s_f[kPillars * kFP];
+    __shared__ __attribute__((aligned(16))) float s_pm[64 * kPmP];           // per-lane maxima: [wave * 4 + quarter][pillar]
     __shared__ float s_tau[kPillars];
     // The items are dealt to 16 VIRTUAL waves (tile t belongs to virtual wave t mod 16, eight tiles each); a physical wave of the
     // 8-wave form plays two of them (v = wid, wid + 8).  Maxima, candidate segments and their order are those of the virtual waves,
@@ -72,10 +78,11 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     constexpr int kThreads = 64 * WAVES, kWaves = 16, kMaxTiles = 8, VPW = 16 / WAVES, PPW = kPillars / WAVES;
     constexpr int kSeg = 12;                        // candidate slots per (pillar, virtual wave); 1.6 expected, more than kSeg: slow path
     constexpr int kSlots = 4;                       // lanes per segment when the pillar's list is put together
-    __shared__ int s_cnt[kPillars * kWaves];                                 // hits of wave w for pillar p: [p][w]
+    constexpr int kRowC = kWaves * kSeg + 4;        // ints between the candidate segments of consecutive pillars
+    __shared__ int s_cnt[kPillars * kCntP];                                  // hits of wave w for pillar p: [p][w]
     // their item ids: [p][w][slot]; once every wave is through with them the same 12 KB hold the exact logits of ALL items of one
     // pillar (the rare exact path at the end)
-    __shared__ union { int cand[kPillars * kWaves * kSeg]; float logit[kItemsPad]; } s_u;
+    __shared__ union { int cand[kPillars * kRowC]; float logit[kItemsPad]; } s_u;
     int *const s_cand = s_u.cand;
     __shared__ int s_tot[kPillars], s_flag[kPillars];                        // candidates of a pillar over all waves; 1: no filtered path for it
     __shared__ int s_list[WAVES * 64];                                       // per physical wave: candidate ids of a round
@@ -120,7 +127,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     const float wm = wmax[lane];
     const float wsum = wmax[kC], wtop = wmax[kC + 1];     // sum_c wmax_c, max_c wmax_c (k_wmax_stats)
 #pragma unroll
-    for (int j = 0; j < kFeat; ++j) s_f[tid + j * kThreads] = fv[j];
+    for (int j = 0; j < kFeat; ++j) s_f[((tid + j * kThreads) / kC) * kFP + (tid + j * kThreads) % kC] = fv[j];
 #pragma unroll
     for (int h = 0; h < PPW; ++h) s_key[(wid * PPW + h) * 64 + lane] = 0ull;     // step 4's key lists end in zeros
     if (tid < kPillars) { s_tot[tid] = 0; s_flag[tid] = 0; }
@@ -136,7 +143,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
         f16x8_t bfrag[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float *fp = s_f + l15 * kC + 32 * h + 8 * q;
+            const float *fp = s_f + l15 * kFP + 32 * h + 8 * q;
             const float4 lo = *(const float4 *)fp, hi = *(const float4 *)(fp + 4);
             const unsigned w0 = f16_rne(lo.x) | (f16_rne(lo.y) << 16), w1 = f16_rne(lo.z) | (f16_rne(lo.w) << 16);
             const unsigned w2 = f16_rne(hi.x) | (f16_rne(hi.y) << 16), w3 = f16_rne(hi.z) | (f16_rne(hi.w) << 16);
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
                     lmax = vmaxr(vmaxr(lmax, vmaxr(c[0], c[1])), vmaxr(c[2], c[3]));
                 }
             }
-            s_pm[l15 * 64 + v * 4 + q] = lmax;
+            s_pm[(v * 4 + q) * kPmP + l15] = lmax;
         }
     }
     RO_STAMP(2);
@@ -191,7 +198,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     for (int j = 0; j < PPW; ++j) {
         const int p = wid + WAVES * j;
         if (p < np) {
-            const float fa = fabsf(s_f[p * kC + lane]);                      // lane = channel
+            const float fa = fabsf(s_f[p * kFP + lane]);                     // lane = channel
             // 2 eps_p: the bound on |A - L| of this pillar, doubled (see the header); infinite outside the fp16 range
             float term = fmaf(kRelErr * wm, fa, kAbsErr * fa);
             if (!(fa <= kHalfMax)) term = INFINITY;                          // (rides the sum: no second reduction)
@@ -199,7 +206,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
             if (!(wtop <= kHalfMax)) eps2 = INFINITY;
             if (!(eps2 < INFINITY) && lane == 0) s_flag[p] = 1;      // outside the fp16 range: no pre-filter for this pillar
             // tau <= k-th largest of the 64 lane maxima (its 16 leading bits): a lower bound of the k-th largest A
-            const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(s_pm[p * 64 + lane]), k));
+            const float tau = ord_to_float(wave_kth_largest_hi16(ord_bits(s_pm[lane * kPmP + p]), k));
             // tau = -inf or eps2 = inf / NaN let every live item through; the -inf padding past n_items never passes
             if (lane == 0) s_tau[p] = fmaxf(tau - eps2, -3.4028235e38f);
         }
@@ -224,11 +231,11 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
         const int c1 = __shfl_up(mine, 16, 64), c2 = __shfl_up(mine, 32, 64), c3 = __shfl_up(mine, 48, 64);
         int pos = (q >= 1 ? c1 : 0) + (q >= 2 ? c2 : 0) + (q >= 3 ? c3 : 0);
         if (q == 3) {
-            s_cnt[l15 * kWaves + v] = pos + mine;
+            s_cnt[l15 * kCntP + v] = pos + mine;
             atomicAdd(&s_tot[l15], pos + mine);
             if (pos + mine > kSeg) s_flag[l15] = 1;
         }
-        int *seg = s_cand + (l15 * kWaves + v) * kSeg;
+        int *seg = s_cand + l15 * kRowC + v * kSeg;
         while (__ballot(hits != 0u) != 0ull) {
             if (hits != 0u) {
                 const int b = __clz((int)hits);           // 4 i + r, ascending item order
@@ -255,7 +262,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
     const int hrow = lane >> 4, hh = lane >> 5;
     // candidate counts: row h of the wave (lanes 16 h ..) looks at the 16 virtual-wave segments of slot h
     const int p_row = wid + WAVES * hrow;
-    const int cw = (hrow < PPW && p_row < np) ? s_cnt[p_row * kWaves + (lane & 15)] : 0;
+    const int cw = (hrow < PPW && p_row < np) ? s_cnt[p_row * kCntP + (lane & 15)] : 0;
     // the pillars of the workgroup without a filtered path: the same word in every wave
     const unsigned slowm = (unsigned)__ballot(lane < np && (s_flag[lane & 15] != 0 || s_tot[lane & 15] > 64)) & 0xffffu;
     int pf = cw;                                          // inclusive prefix inside every 16-lane row
@@ -315,7 +322,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
                 const int cw2 = __shfl(cw, 16 * h + w2, 64), base2 = (u ? na : 0) + __shfl(pf - cw, 16 * h + w2, 64);
 #pragma unroll
                 for (int r = 0; r < kSeg / kSlots; ++r)
-                    if (s2 + kSlots * r < cw2) list[base2 + s2 + kSlots * r] = s_cand[(pp * kWaves + w2) * kSeg + s2 + kSlots * r];
+                    if (s2 + kSlots * r < cw2) list[base2 + s2 + kSlots * r] = s_cand[pp * kRowC + w2 * kSeg + s2 + kSlots * r];
             }
         }
         // lane c owns candidate c of the round
@@ -343,7 +350,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
         for (int g = 0; g < 4; ++g) {
             if (g < 2 || tot > 32) {
                 const int pcg = wid + WAVES * (sa + ((both && 16 * g + c4 >= na) ? 1 : 0));
-                const float4 *fp = (const float4 *)(s_f + pcg * kC + 16 * qq);
+                const float4 *fp = (const float4 *)(s_f + pcg * kFP + 16 * qq);
                 float4 fq = fp[0];
                 float a0 = rv[g][0].x * fq.x, a1 = rv[g][0].y * fq.y, a2 = rv[g][0].z * fq.z, a3 = rv[g][0].w * fq.w;
 #pragma unroll
@@ -394,7 +401,7 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_memory_readout(const float *_
 #pragma unroll
                     for (int i = 0; i < kC / 4; ++i) {
                         const float4 rw = rowp[i];
-                        const float4 fv4 = *(const float4 *)(s_f + p * kC + 4 * i);
+                        const float4 fv4 = *(const float4 *)(s_f + p * kFP + 4 * i);
                         a0 = fmaf(rw.x, fv4.x, a0); a1 = fmaf(rw.y, fv4.y, a1); a2 = fmaf(rw.z, fv4.z, a2); a3 = fmaf(rw.w, fv4.w, a3);
                     }
                     sacc = (a0 + a1) + (a2 + a3);
