@@ -707,7 +707,9 @@ int fused_allowed(hipStream_t s, bool *capturing) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     FusedInFlight &f = g_fused[dev];
     if (!f.valid || f.stream == s) return 1;
-    return hipEventQuery(f.done) == hipSuccess ? 1 : 0;
+    const hipError_t q = hipEventQuery(f.done);
+    if (q != hipSuccess) (void)hipGetLastError();      // "not ready" is an answer, not a failure: it must not reach HVPR_CHECK_LAUNCH
+    return q == hipSuccess ? 1 : 0;
 }
 
 void note_fused_launch(hipStream_t s) {
