@@ -48,15 +48,33 @@ class MemoryUnit_Agg(nn.Module):
             return self._forward_train(input1, k, input2)
         return {"output": kernels.memory_readout_fwd(input1.contiguous(), self.packed_bank(), k)}
 
+    def _check_train(self, t, d):
+        if not t.is_cuda:
+            raise RuntimeError("hvpr_amd: the memory training branch needs GPU tensors (the HIP path has no CPU fallback)")
+        if d != 64 or self.mem_dim > 2048 or not self.shrink_thres > 0:
+            raise ValueError("hvpr_amd: the memory training branch is built for 64 channels, <= 2048 items and SHRINK_TH > 0 (hvpr.yaml:83-85)")
+
     def _forward_train(self, pillars, k, positives):
         """Hard-shrink addressing through hvpr_memory_train_fwd/bwd_f32: the (nv*k, items) attention is never materialised ('att'
         is not returned: nothing on the path consumes it, pointpillar_scatter.py:133-138).  Torch form: tests/torch_forms.py."""
         nv, _, d = positives.shape
-        if not positives.is_cuda:
-            raise RuntimeError("hvpr_amd: the memory training branch needs GPU tensors (the HIP path has no CPU fallback)")
-        if d != 64 or self.mem_dim > 2048 or not self.shrink_thres > 0:
-            raise ValueError("hvpr_amd: the memory training branch is built for 64 channels, <= 2048 items and SHRINK_TH > 0 (hvpr.yaml:83-85)")
+        self._check_train(positives, d)
         mem = _MemoryTrain.apply(positives.reshape(-1, d), self.weight, float(self.shrink_thres)).reshape(nv, k, d)
+        agg = torch.softmax((mem * pillars.unsqueeze(1)).sum(dim=2), dim=1)
+        return {"output": (agg.detach().unsqueeze(2) * mem).sum(dim=1)}
+
+    def forward_train_indexed(self, pillars, k, points, idx, plan=None):
+        """The training branch when the k positives of every pillar are ROWS OF ONE POINT TENSOR, positives = points[idx] (what
+        the scatter module's training branch has, pointpillar_scatter.py:75-76,133): the addressing of memory_module.py:36-50 is a
+        function of the row alone — softmax(x W^T) -> hard shrink -> L1 normalise -> . W — so it is evaluated ONCE PER POINT and
+        gathered, instead of once per (pillar, k) pair: a point is picked by 4.8 pillars on average at hvpr.yaml's sizes (16 384
+        points against ~3 900 pillars x 20 per frame), some by hundreds.  Same values per row (a row's result does not depend on its
+        neighbours in the launch); the gradients reach the points as J^T (sum of the picks' dy) instead of sum of J^T dy —
+        round-off apart the same thing.  idx (nv, k) int64 rows of `points`; plan: the shared _EdgePlan of idx (optional)."""
+        nv, d = idx.shape[0], points.shape[1]
+        self._check_train(points, d)
+        mem_points = _MemoryTrain.apply(points, self.weight, float(self.shrink_thres))      # (N, d)
+        mem = _GatherRows.apply(mem_points, idx, plan)                                       # (nv, k, d)
         agg = torch.softmax((mem * pillars.unsqueeze(1)).sum(dim=2), dim=1)
         return {"output": (agg.detach().unsqueeze(2) * mem).sum(dim=1)}
 
@@ -106,7 +124,7 @@ class _GatherRows(torch.autograd.Function):
     hvpr_scatter_add_rows_f32, are not reproducible run to run)."""
 
     @staticmethod
-    def forward(ctx, rows, idx):
+    def forward(ctx, rows, idx, plan=None):
         rows = rows.contiguous()
         flat = idx.reshape(-1).to(torch.int32).contiguous()
         out = torch.empty((flat.numel(), rows.shape[1]), dtype=torch.float32, device=rows.device)
@@ -114,6 +132,7 @@ class _GatherRows(torch.autograd.Function):
                                                          flat.numel(), out.data_ptr(), kernels._stream()), "hvpr_gather_rows_f32")
         ctx.save_for_backward(flat)
         ctx.n = rows.shape[0]
+        ctx.plan = plan
         return out.view(*idx.shape, rows.shape[1])
 
     @staticmethod
@@ -122,9 +141,23 @@ class _GatherRows(torch.autograd.Function):
         grad = grad.contiguous()
         c = grad.shape[-1]
         # a point may be picked by many pillars: its gradient is summed pick by pick in ascending order (no float atomics)
-        order, chunk_ptr, dest_ptr = kernels.edges_by_destination(flat.to(torch.int64), ctx.n)
+        order, chunk_ptr, dest_ptr = ctx.plan.get() if ctx.plan is not None else kernels.edges_by_destination(flat.to(torch.int64), ctx.n)
         g = kernels.segment_sum_rows(grad.reshape(-1, c), 0, c, order, None, chunk_ptr, dest_ptr, ctx.n)
-        return g, None
+        return g, None, None
+
+
+class _EdgePlan:
+    """The picks idx -> rows of an (n, C) tensor grouped by destination (kernels.edges_by_destination: one stable argsort + a
+    handful of scans), built on first use and shared by every gather of the SAME index tensor — the training branch gathers the point
+    features and the per-point memory read-out with one idx."""
+
+    def __init__(self, idx, n):
+        self.idx, self.n, self._plan = idx, n, None
+
+    def get(self):
+        if self._plan is None:
+            self._plan = kernels.edges_by_destination(self.idx.reshape(-1).to(torch.int64), self.n)
+        return self._plan
 
 
 class _ScatterCanvas(torch.autograd.Function):
@@ -290,10 +323,12 @@ class PointPillarScatter_Agg_Memory_1_scale(_ScatterBase):
                 picks = [self._topk_points(pf[v0:v1].detach(), point_f[p0:p1].detach()) + p0
                          for (v0, v1), (p0, p1) in zip(vr, pr) if v1 > v0]
             idx = torch.cat(picks, 0) if picks else torch.zeros((0, self.k), dtype=torch.long, device=pf.device)
-            positives = _GatherRows.apply(point_f, idx)                                        # (M, k, C)
+            plan = _EdgePlan(idx, point_f.shape[0])
+            positives = _GatherRows.apply(point_f, idx, plan)                                  # (M, k, C)
             wgt = torch.softmax((pf.unsqueeze(1) * positives).sum(dim=2), dim=1)               # get_score, :76-83
             pos_point = (wgt.detach().unsqueeze(2) * positives).sum(dim=1)
-            pos_mem = self.memory(pf, self.k, positives)["output"]
+            # the memory's second input IS positives = point_f[idx] (T1): addressed once per point, then gathered (MemoryUnit_Agg)
+            pos_mem = self.memory.forward_train_indexed(pf, self.k, point_f, idx, plan)["output"]
         else:       # rows not grouped by frame: the reference's boolean masks, frame by frame
             for b in range(B):
                 agg, positives = self.get_score(point_f[point_c[:, 0] == b], pf[coords[:, 0] == b])

@@ -555,3 +555,35 @@ def test_sync_batchnorm_hook_failure_is_reported_not_swallowed():
         lib().hvpr_set_batchnorm_allreduce(None, None)
     gate, _, _ = ct.spatial_gate_train(y, w, one, one, one, 1e-3)
     assert bool(torch.isfinite(gate).all())
+
+
+def test_memory_addressing_once_per_point_equals_once_per_pick():
+    """MemoryUnit_Agg.forward_train_indexed (the addressing evaluated once per point, then gathered: what the scatter module's training
+    branch runs) against _forward_train on the materialised positives points[idx] (memory_module.py:31-59 as written, one row per
+    (pillar, k) pair): the SAME bits forward (a row's result does not depend on its neighbours in the launch), gradients w.r.t. the
+    points, the pillars and the bank equal to round-off (J^T applied to the summed dy of a point's picks instead of summed J^T dy)."""
+    from hvpr_amd import map_to_bev
+    g = torch.Generator().manual_seed(77)
+    N, M, k = 5000, 700, 20
+    mem = map_to_bev.MemoryUnit_Agg(2000, 64, 0.0025).to(DEV).train()
+    mem.weight.data.mul_(4.0)                                   # supports of 10-80 items per row (G16's regime)
+    points0 = (torch.relu(torch.randn(N, 64, generator=g)) * 0.5).to(DEV)
+    pillars0 = torch.relu(torch.randn(M, 64, generator=g)).to(DEV)
+    # picks concentrated on a tenth of the points: every picked point serves ~30 (pillar, k) pairs
+    idx = (torch.randint(0, N // 10, (M, k), generator=g) * 10).to(DEV)
+    cot = torch.randn(M, 64, generator=g).to(DEV)
+    res = []
+    for indexed in (False, True):
+        pts, pil = points0.clone().requires_grad_(True), pillars0.clone().requires_grad_(True)
+        mem.weight.grad = None
+        if indexed:
+            out = mem.forward_train_indexed(pil, k, pts, idx, map_to_bev._EdgePlan(idx, N))["output"]
+        else:
+            out = mem(pil, k, map_to_bev._GatherRows.apply(pts, idx))["output"]
+        (out * cot).sum().backward()
+        res.append((out.detach(), pts.grad.clone(), mem.weight.grad.clone(), pil.grad))
+    (o0, gp0, gw0, gq0), (o1, gp1, gw1, gq1) = res
+    assert torch.equal(o0, o1)
+    assert gq0 is None and gq1 is None                         # the pillars only enter through detached aggregation weights (:53-57)
+    assert float((gp1 - gp0).norm() / gp0.norm()) < 1e-5 and float((gw1 - gw0).norm() / gw0.norm()) < 1e-5
+    assert float(gp0.norm()) > 0 and float(gw0.norm()) > 0
