@@ -310,9 +310,9 @@ __device__ __forceinline__ void warm_l2(int part, int parts, const float4 *__res
 }
 
 template <int T>
-// (second launch bound = eight waves per SIMD, i.e. at most 64 VGPRs, so that TWO 1024-thread owners / four 512-thread owners fit a CU — the 32 owners of a 32 768-point
+// (1024-thread form: second launch bound = eight waves per SIMD, i.e. at most 64 VGPRs, so that TWO 1024-thread owners / four 512-thread owners fit a CU — the 32 owners of a 32 768-point
 // call then need 16 CUs of their XCD, not all 32: with 65 registers the batch-2 frame pipeline lost 12 % waiting for them, round 6)
-__global__ void __launch_bounds__(T, 8) k_index(const float *__restrict__ pts, int n, int stride, int xyz_col,
+__global__ void __launch_bounds__(T, T == 1024 ? 8 : 1) k_index(const float *__restrict__ pts, int n, int stride, int xyz_col,
                                              const int *__restrict__ foff, int batch, float lox, float loy, float loz, float vsx,
                                              float vsy, float vsz, int nx, int ny, int nz, int max_voxels, VoxWs w,
                                              int *__restrict__ voxel_offsets, const float *__restrict__ vfe_w1,
