@@ -530,7 +530,7 @@ def train_step_line(device, which="car", batch=16, steps=3, warmup=2, ddp=False)
            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
            "kernels": "every training module on the library's HIP kernels: voxelizer, point-stream index ops + gathers, VFE forward/backward, "
-                      "get_score top-k, memory addressing, scatter, backbone + head convolutions fwd/dgrad/wgrad (Winograd F(2x2,3x3) where 3x3 "
+                      "get_score top-k, memory addressing (once per point, then gathered), scatter, backbone + head convolutions fwd/dgrad/wgrad (Winograd F(2x2,3x3) where 3x3 "
                       "stride 1), train-mode BatchNorm, target assigner, the head's losses with their gradients, flat fused Adam"}
     del model, opt, pool
     torch.cuda.empty_cache()
